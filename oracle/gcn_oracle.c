@@ -1,0 +1,271 @@
+/*
+ * TEST INFRASTRUCTURE ONLY.  CPU restatement ("oracle") of the walexi/gnn.cpp GCN hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object, and only as the checker / the reported CPU baseline.  The product path
+ * (gnn.cpp_amd/, include/gnnx.h, libgnnx_hip.so) never links, imports or falls back to it.
+ *
+ * Parity status: PINNED.  Every function below is checked bit-for-bit (modulo the sign of zero)
+ * against outputs of the real reference compiled by oracle/build_ref.sh (oracle/_ref/ref_driver);
+ * those outputs are committed as tests/golden/<case>.npz by tests/golden/make_golden.py.
+ * The reference's own tests pin nothing numerically on this path.
+ *
+ * What is restated (reference file:line):
+ *   adjacency semantics   graph.cpp:21-44 (A[r][c] = 1, duplicates collapse), graph.cpp:68-75 with
+ *                         fillValue 0 (diagonal zeroed => self loops REMOVED), graph.cpp:46-67
+ *                         (row-major scan => edges sorted by (src,dst))
+ *   degree / norm         graph.cpp:177-185: deg = rowsum(A) + 1; s = pow(deg,-0.5); norm = (A.s) * s
+ *   transform             nn.cpp:205-211: H = x.mm(W.t(-1,-2))     (GCNConv's lin has no bias, graph.cpp:162)
+ *   aggregate             graph.cpp:204-212: agg = A.mm(H); agg = agg * norm ; graph.cpp:188: + bias
+ *   backward              operation.h:114-128 (Add), :144-167 (Mul), :504-534 (MatMul), :416-433
+ *                         (Transpose), tensor.h:618-638 (sum_to_size), tensor.h:260-276 (_grad +=)
+ *
+ * Arithmetic order (this is what makes bit-exact parity possible):
+ *   functional::matmul (functional.h:433-439) computes every output element as
+ *   `(r_slice * l_slice).sum()`.  That is libstdc++'s expression-template _Expr::sum()
+ *   (bits/valarray_after.h:293-305) which starts from the LAST element and walks DOWN:
+ *       s = p[n-1]; s += p[n-2]; ... ; s += p[0];      p[k] = fl32(l[k] * r[k])
+ *   i.e. sequential fp32, DESCENDING k, product rounded before the add (no FMA).
+ *   For the adjacency products p[k] is either H[k] exactly (A=1) or +-0 (A=0, an exact no-op),
+ *   so a CSR walk over the row's neighbours in DESCENDING column order reproduces the dense
+ *   result exactly (up to the sign of a zero result).
+ *   functional::sum (functional.h:267-296) materialises a valarray first, and valarray::sum()
+ *   (bits/valarray_array.h:348-354) walks UP (ascending): used for deg and for dbias.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC (oracle/Makefile).  -ffp-contract=off keeps
+ * mul and add separately rounded exactly like the reference's x86-64 baseline build.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define API __attribute__((visibility("default")))
+
+static int cmp_u64(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y);
+}
+
+/*
+ * COO [2,E] -> CSR with the reference's adjacency semantics (graph.cpp:21-75):
+ * duplicates collapse (assignment at graph.cpp:40), self loops dropped (fill_diagonal_(0) at
+ * graph.cpp:72), entries ordered row-major (scan at graph.cpp:52-60).
+ * rowptr has N+1 entries, colidx capacity E.  Returns nnz, or -1 if an index is out of [0,N)
+ * (the reference would write out of bounds, graph.cpp:40; Data's ctor rejects it, graph.cpp:89).
+ */
+API int64_t gcn_oracle_coo_to_csr(const int32_t *src, const int32_t *dst, int64_t E, int32_t N,
+                                  int64_t *rowptr, int32_t *colidx)
+{
+    uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(E > 0 ? E : 1));
+    int64_t m = 0;
+    for (int64_t e = 0; e < E; e++) {
+        int32_t r = src[e], c = dst[e];
+        if (r < 0 || c < 0 || r >= N || c >= N) { free(keys); return -1; }
+        if (r == c) continue;
+        keys[m++] = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
+    }
+    qsort(keys, (size_t)m, sizeof(uint64_t), cmp_u64);
+    memset(rowptr, 0, sizeof(int64_t) * ((size_t)N + 1));
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < m; i++) {
+        if (i && keys[i] == keys[i - 1]) continue;
+        colidx[nnz++] = (int32_t)(keys[i] & 0xffffffffu);
+        rowptr[(keys[i] >> 32) + 1]++;
+    }
+    for (int32_t i = 0; i < N; i++) rowptr[i + 1] += rowptr[i];
+    free(keys);
+    return nnz;
+}
+
+/* CSR of A^T (columns ascending inside each row): what MatMul::_backward's dense transpose of A
+ * (operation.h:524-527) turns into when A is never materialised. */
+API void gcn_oracle_csr_transpose(const int64_t *rowptr, const int32_t *colidx, int32_t N,
+                                  int64_t *rowptrT, int32_t *colidxT)
+{
+    int64_t nnz = rowptr[N];
+    memset(rowptrT, 0, sizeof(int64_t) * ((size_t)N + 1));
+    for (int64_t e = 0; e < nnz; e++) rowptrT[colidx[e] + 1]++;
+    for (int32_t i = 0; i < N; i++) rowptrT[i + 1] += rowptrT[i];
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * ((size_t)N + 1));
+    memcpy(cur, rowptrT, sizeof(int64_t) * ((size_t)N + 1));
+    for (int32_t i = 0; i < N; i++)
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; e++) colidxT[cur[colidx[e]]++] = i;
+    free(cur);
+}
+
+/* graph.cpp:177-185.  s_i = powf(1 + outdeg_i, -0.5f);  norm_i = fl(fl(sum_j A_ij s_j) * s_i),
+ * inner sum sequential over DESCENDING j (matmul order, see header). */
+API void gcn_oracle_degree_norm(const int64_t *rowptr, const int32_t *colidx, int32_t N, float *s, float *norm)
+{
+#pragma omp parallel for schedule(static)
+    for (int32_t i = 0; i < N; i++) {
+        float deg = (float)(rowptr[i + 1] - rowptr[i]) + 1.0f; /* ascending sum of 1.0f's is exact below 2^24 */
+        s[i] = powf(deg, -0.5f);
+    }
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int32_t i = 0; i < N; i++) {
+        float acc = 0.0f;
+        for (int64_t e = rowptr[i + 1] - 1; e >= rowptr[i]; e--) acc += s[colidx[e]];
+        norm[i] = acc * s[i];
+    }
+}
+
+/* nn.cpp:205-211 via functional.h:433-439:  H[i,o] = sum_{k desc} fl(X[i,k] * W[o,k]). */
+API void gcn_oracle_linear_fwd(const float *X, const float *W, int64_t N, int32_t Fin, int32_t Fout, float *H)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++) {
+        const float *x = X + i * Fin;
+        for (int32_t o = 0; o < Fout; o++) {
+            const float *w = W + (int64_t)o * Fin;
+            float acc = 0.0f;
+            if (Fin > 0) {
+                acc = x[Fin - 1] * w[Fin - 1];
+                for (int32_t k = Fin - 2; k >= 0; k--) acc += x[k] * w[k];
+            }
+            H[i * Fout + o] = acc;
+        }
+    }
+}
+
+/* graph.cpp:208-209 (+ graph.cpp:188 when bias != NULL):
+ *   out[i,:] = fl(fl(sum_{j in N(i), DESCENDING j} H[j,:]) * norm[i]) (+ bias).  norm may be NULL (plain A.H). */
+API void gcn_oracle_aggregate_fwd(const int64_t *rowptr, const int32_t *colidx, int32_t N, int32_t F,
+                                  const float *H, const float *norm, const float *bias, float *out)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int32_t i = 0; i < N; i++) {
+        float *o = out + (int64_t)i * F;
+        int64_t b = rowptr[i], e = rowptr[i + 1];
+        if (e == b) {
+            for (int32_t f = 0; f < F; f++) o[f] = 0.0f;
+        } else {
+            const float *h = H + (int64_t)colidx[e - 1] * F;
+            for (int32_t f = 0; f < F; f++) o[f] = h[f];
+            for (int64_t p = e - 2; p >= b; p--) {
+                h = H + (int64_t)colidx[p] * F;
+                for (int32_t f = 0; f < F; f++) o[f] += h[f];
+            }
+        }
+        if (norm) {
+            float nv = norm[i];
+            for (int32_t f = 0; f < F; f++) o[f] = o[f] * nv;
+        }
+        if (bias)
+            for (int32_t f = 0; f < F; f++) o[f] = o[f] + bias[f];
+    }
+}
+
+/* Backward of the aggregate (operation.h:144-167 then :524-531):
+ *   G' = fl(G (.) norm);  dH[j,:] = sum_{i : A_ij = 1, DESCENDING i} G'[i,:]  (rows of A^T). */
+API void gcn_oracle_aggregate_bwd(const int64_t *rowptrT, const int32_t *colidxT, int32_t N, int32_t F,
+                                  const float *G, const float *norm, float *dH)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int32_t j = 0; j < N; j++) {
+        float *o = dH + (int64_t)j * F;
+        int64_t b = rowptrT[j], e = rowptrT[j + 1];
+        for (int32_t f = 0; f < F; f++) o[f] = 0.0f;
+        for (int64_t p = e - 1; p >= b; p--) {
+            int32_t i = colidxT[p];
+            const float *g = G + (int64_t)i * F;
+            float nv = norm ? norm[i] : 1.0f;
+            if (p == e - 1)
+                for (int32_t f = 0; f < F; f++) o[f] = g[f] * nv;
+            else
+                for (int32_t f = 0; f < F; f++) o[f] += g[f] * nv;
+        }
+    }
+}
+
+/* dbias (operation.h:114-128 -> tensor.h:618-638 -> functional.h:285-288): column sums, ASCENDING row order. */
+API void gcn_oracle_colsum(const float *G, int64_t N, int32_t F, float *out)
+{
+    for (int32_t f = 0; f < F; f++) out[f] = 0.0f;
+    if (N == 0) return;
+    for (int32_t f = 0; f < F; f++) out[f] = G[f];
+    for (int64_t i = 1; i < N; i++)
+        for (int32_t f = 0; f < F; f++) out[f] += G[i * F + f];
+}
+
+/* Backward of the transform (operation.h:516-531, :416-433):
+ *   dX[i,k] = sum_{o desc} fl(dH[i,o] * W[o,k])          (G . (W^T)^T)
+ *   dW[o,k] = sum_{i desc} fl(X[i,k] * dH[i,o])          (x^T . G, then transposed back) */
+API void gcn_oracle_linear_bwd(const float *dH, const float *X, const float *W, int64_t N, int32_t Fin,
+                               int32_t Fout, float *dX, float *dW)
+{
+    if (dX) {
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < N; i++)
+            for (int32_t k = 0; k < Fin; k++) {
+                float acc = 0.0f;
+                if (Fout > 0) {
+                    acc = dH[i * Fout + Fout - 1] * W[(int64_t)(Fout - 1) * Fin + k];
+                    for (int32_t o = Fout - 2; o >= 0; o--) acc += dH[i * Fout + o] * W[(int64_t)o * Fin + k];
+                }
+                dX[i * Fin + k] = acc;
+            }
+    }
+    if (dW) {
+#pragma omp parallel for schedule(static)
+        for (int32_t o = 0; o < Fout; o++)
+            for (int32_t k = 0; k < Fin; k++) {
+                float acc = 0.0f;
+                if (N > 0) {
+                    acc = X[(N - 1) * Fin + k] * dH[(N - 1) * Fout + o];
+                    for (int64_t i = N - 2; i >= 0; i--) acc += X[i * Fin + k] * dH[i * Fout + o];
+                }
+                dW[(int64_t)o * Fin + k] = acc;
+            }
+    }
+}
+
+/*
+ * Literal dense restatement of graph.cpp:204-212 for tiny N (O(N^2 F)); used by the tests to show
+ * that the CSR walk above equals the dense matmul the reference actually runs.
+ * A is built as graph.cpp:21-44 does (assignment), the diagonal is NOT touched here (callers pass
+ * the already-stripped edge list, as GCNConv::forward does after add_self_loops).
+ */
+API void gcn_oracle_dense_aggregate(const int32_t *src, const int32_t *dst, int64_t E, int32_t N, int32_t F,
+                                    const float *H, const float *norm, float *out)
+{
+    float *A = (float *)calloc((size_t)N * N, sizeof(float));
+    for (int64_t e = 0; e < E; e++) A[(int64_t)src[e] * N + dst[e]] = 1.0f;
+    for (int32_t i = 0; i < N; i++)
+        for (int32_t f = 0; f < F; f++) {
+            float acc = A[(int64_t)i * N + N - 1] * H[(int64_t)(N - 1) * F + f];
+            for (int32_t k = N - 2; k >= 0; k--) acc += A[(int64_t)i * N + k] * H[(int64_t)k * F + f];
+            out[(int64_t)i * F + f] = norm ? acc * norm[i] : acc;
+        }
+    free(A);
+}
+
+/* out[d] = powf((float)d, -0.5f) for d in [0,n): the libm call behind functional.h:253 (std::pow on valarrays),
+ * exposed so the tests can measure where a device-side (float)(1/sqrt((double)d)) differs from it. */
+API void gcn_oracle_powf_table(int32_t n, float *out)
+{
+    for (int32_t d = 0; d < n; d++) out[d] = powf((float)d, -0.5f);
+}
+
+API void gcn_oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+API int gcn_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,178 @@
+"""ctypes binding of oracle/libgcn_oracle.so (TEST INFRASTRUCTURE ONLY).
+
+Each wrapper mirrors one function of gcn_oracle.c; see that file for the reference file:line each
+one restates and for the summation-order argument that makes bit-exact parity possible.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgcn_oracle.so")
+_lib = None
+
+__all__ = ["build", "coo_to_csr", "csr_transpose", "degree_norm", "linear_fwd", "aggregate_fwd",
+           "aggregate_bwd", "colsum", "linear_bwd", "dense_aggregate", "set_threads", "max_threads",
+           "powf_table", "gcn_layer_fwd", "gcn_layer_bwd", "ref_driver_path"]
+
+
+def build():
+    src = os.path.join(_HERE, "gcn_oracle.c")
+    if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "libgcn_oracle.so"])
+    return _SO
+
+
+def ref_driver_path():
+    """Path of the compiled real reference (oracle/_ref/ref_driver) or None."""
+    p = os.path.join(_HERE, "_ref", "ref_driver")
+    return p if os.path.exists(p) else None
+
+
+def _L():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.gcn_oracle_coo_to_csr.restype = C.c_int64
+        _lib.gcn_oracle_max_threads.restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def set_threads(n):
+    _L().gcn_oracle_set_threads(C.c_int(int(n)))
+
+
+def max_threads():
+    return int(_L().gcn_oracle_max_threads())
+
+
+def coo_to_csr(src, dst, n_nodes):
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    dst = np.ascontiguousarray(dst, dtype=np.int32)
+    E = src.shape[0]
+    rowptr = np.zeros(n_nodes + 1, dtype=np.int64)
+    colidx = np.zeros(max(E, 1), dtype=np.int32)
+    nnz = _L().gcn_oracle_coo_to_csr(_p(src), _p(dst), C.c_int64(E), C.c_int32(n_nodes), _p(rowptr), _p(colidx))
+    if nnz < 0:
+        raise RuntimeError("edge index out of range")
+    return rowptr, colidx[:nnz].copy()
+
+
+def csr_transpose(rowptr, colidx, n_nodes):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    rT = np.zeros(n_nodes + 1, dtype=np.int64)
+    cT = np.zeros(max(colidx.shape[0], 1), dtype=np.int32)
+    _L().gcn_oracle_csr_transpose(_p(rowptr), _p(colidx), C.c_int32(n_nodes), _p(rT), _p(cT))
+    return rT, cT[:colidx.shape[0]].copy()
+
+
+def degree_norm(rowptr, colidx, n_nodes):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    s = np.zeros(n_nodes, dtype=np.float32)
+    norm = np.zeros(n_nodes, dtype=np.float32)
+    _L().gcn_oracle_degree_norm(_p(rowptr), _p(colidx), C.c_int32(n_nodes), _p(s), _p(norm))
+    return s, norm
+
+
+def linear_fwd(X, W):
+    X, W = _f32(X), _f32(W)
+    N, Fin = X.shape
+    Fout = W.shape[0]
+    H = np.zeros((N, Fout), dtype=np.float32)
+    _L().gcn_oracle_linear_fwd(_p(X), _p(W), C.c_int64(N), C.c_int32(Fin), C.c_int32(Fout), _p(H))
+    return H
+
+
+def aggregate_fwd(rowptr, colidx, H, norm=None, bias=None):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    H = _f32(H)
+    N, F = H.shape
+    out = np.zeros((N, F), dtype=np.float32)
+    norm = None if norm is None else _f32(norm)
+    bias = None if bias is None else _f32(bias)
+    _L().gcn_oracle_aggregate_fwd(_p(rowptr), _p(colidx), C.c_int32(N), C.c_int32(F), _p(H),
+                                  _p(norm) if norm is not None else None,
+                                  _p(bias) if bias is not None else None, _p(out))
+    return out
+
+
+def aggregate_bwd(rowptrT, colidxT, G, norm=None):
+    rowptrT = np.ascontiguousarray(rowptrT, dtype=np.int64)
+    colidxT = np.ascontiguousarray(colidxT, dtype=np.int32)
+    G = _f32(G)
+    N, F = G.shape
+    dH = np.zeros((N, F), dtype=np.float32)
+    norm = None if norm is None else _f32(norm)
+    _L().gcn_oracle_aggregate_bwd(_p(rowptrT), _p(colidxT), C.c_int32(N), C.c_int32(F), _p(G),
+                                  _p(norm) if norm is not None else None, _p(dH))
+    return dH
+
+
+def colsum(G):
+    G = _f32(G)
+    N, F = G.shape
+    out = np.zeros(F, dtype=np.float32)
+    _L().gcn_oracle_colsum(_p(G), C.c_int64(N), C.c_int32(F), _p(out))
+    return out
+
+
+def linear_bwd(dH, X, W, need_dx=True, need_dw=True):
+    dH, X, W = _f32(dH), _f32(X), _f32(W)
+    N, Fin = X.shape
+    Fout = W.shape[0]
+    dX = np.zeros((N, Fin), dtype=np.float32) if need_dx else None
+    dW = np.zeros((Fout, Fin), dtype=np.float32) if need_dw else None
+    _L().gcn_oracle_linear_bwd(_p(dH), _p(X), _p(W), C.c_int64(N), C.c_int32(Fin), C.c_int32(Fout),
+                               _p(dX) if need_dx else None, _p(dW) if need_dw else None)
+    return dX, dW
+
+
+def dense_aggregate(src, dst, n_nodes, H, norm=None):
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    dst = np.ascontiguousarray(dst, dtype=np.int32)
+    H = _f32(H)
+    F = H.shape[1]
+    out = np.zeros((n_nodes, F), dtype=np.float32)
+    norm = None if norm is None else _f32(norm)
+    _L().gcn_oracle_dense_aggregate(_p(src), _p(dst), C.c_int64(src.shape[0]), C.c_int32(n_nodes), C.c_int32(F),
+                                    _p(H), _p(norm) if norm is not None else None, _p(out))
+    return out
+
+
+def powf_table(n):
+    out = np.zeros(n, dtype=np.float32)
+    _L().gcn_oracle_powf_table(C.c_int32(n), _p(out))
+    return out
+
+
+def gcn_layer_fwd(src, dst, n_nodes, X, W, bias):
+    """Hot-path forward as the reference chains it (graph.cpp:172-173,177-188, without BatchNorm/ReLU)."""
+    rowptr, colidx = coo_to_csr(src, dst, n_nodes)
+    s, norm = degree_norm(rowptr, colidx, n_nodes)
+    H = linear_fwd(X, W)
+    out = aggregate_fwd(rowptr, colidx, H, norm, bias)
+    return dict(rowptr=rowptr, colidx=colidx, s=s, norm=norm, H=H, out=out)
+
+
+def gcn_layer_bwd(fwd, X, W, G):
+    """Backward of gcn_layer_fwd for upstream gradient G (see gcn_oracle.c header for file:line)."""
+    n = fwd["rowptr"].shape[0] - 1
+    rT, cT = csr_transpose(fwd["rowptr"], fwd["colidx"], n)
+    dbias = colsum(G)
+    dH = aggregate_bwd(rT, cT, G, fwd["norm"])
+    dX, dW = linear_bwd(dH, X, W)
+    return dict(dbias=dbias, dH=dH, dX=dX, dW=dW)
