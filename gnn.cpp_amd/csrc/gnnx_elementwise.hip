@@ -1,0 +1,241 @@
+// Small HBM-bound ops on the GCN path: dbias column sum, unfused row-scale / bias / axpy, and the halo
+// pack / unpack (row gather, row scatter-add).  All are streaming kernels: 16 B per lane where alignment
+// allows, grid capped at 2048 workgroups with a grid-stride loop.
+#include "gnnx_common.h"
+
+using namespace gnnx;
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks/CU
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- colsum: stage 1 -- each workgroup reduces a contiguous slab of rows to one partial row ---------
+// Thread t owns feature columns {t, t+256, ...} (coalesced along the row), walks its slab's rows
+// sequentially; stage 2 adds the partial rows in slab order.  Fixed grid => deterministic.
+__global__ __launch_bounds__(256) void colsum_stage1(const float *G, int64_t ldg, int64_t n_rows, int32_t n_feat,
+                                                      int64_t rows_per_block, float *partial)
+{
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+    for (int32_t f = threadIdx.x; f < n_feat; f += 256) {
+        float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+        int64_t r = r0;
+        for (; r + 4 <= r1; r += 4) {
+            acc0 += G[r * ldg + f];
+            acc1 += G[(r + 1) * ldg + f];
+            acc2 += G[(r + 2) * ldg + f];
+            acc3 += G[(r + 3) * ldg + f];
+        }
+        for (; r < r1; r++) acc0 += G[r * ldg + f];
+        partial[(int64_t)blockIdx.x * n_feat + f] = (acc0 + acc1) + (acc2 + acc3);
+    }
+}
+
+// For narrow matrices (n_feat < 256) pack several rows per workgroup pass: thread t -> (row t / fw, col t % fw)
+__global__ __launch_bounds__(256) void colsum_stage1_narrow(const float *G, int64_t ldg, int64_t n_rows, int32_t n_feat,
+                                                             int32_t fw, int64_t rows_per_block, float *partial)
+{
+    __shared__ float red[256];
+    const int rpp = 256 / fw;  // rows per pass
+    const int f = threadIdx.x % fw, rr = threadIdx.x / fw;
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+    float acc = 0.f;
+    if (f < n_feat && rr < rpp)
+        for (int64_t r = r0 + rr; r < r1; r += rpp) acc += G[r * ldg + f];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < fw && threadIdx.x < n_feat) {
+        float s = 0.f;
+        for (int k = 0; k < rpp; k++) s += red[k * fw + threadIdx.x];
+        partial[(int64_t)blockIdx.x * n_feat + threadIdx.x] = s;
+    }
+}
+
+__global__ void colsum_stage2(const float *partial, int32_t n_blocks, int32_t n_feat, float beta, float *out)
+{
+    int32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_feat) return;
+    float acc = 0.f;
+    for (int32_t b = 0; b < n_blocks; b++) acc += partial[(int64_t)b * n_feat + f];
+    out[f] = beta != 0.f ? out[f] + acc : acc;
+}
+
+int colsum_blocks(int64_t n_rows)
+{
+    int64_t b = ceil_div(n_rows, 64);
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+// ---- row-wise elementwise -------------------------------------------------------------------------
+template <int OP>  // 0: Y = X * v[row]   1: Y = X + b[col]
+__global__ __launch_bounds__(256) void rowwise_kernel(const float *X, int64_t ldx, const float *v, int64_t n_rows,
+                                                       int32_t n_feat, float *Y, int64_t ldy)
+{
+    int64_t total = n_rows * n_feat;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i / n_feat;
+        int32_t f = (int32_t)(i - r * n_feat);
+        float x = X[r * ldx + f];
+        Y[r * ldy + f] = OP == 0 ? __fmul_rn(x, v[r]) : __fadd_rn(x, v[f]);
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(int64_t n, float a, const float *x, float *y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = __fadd_rn(y[i], __fmul_rn(a, x[i]));
+}
+
+// ---- halo pack / unpack: one G-lane group per row, 16 B per lane ---------------------------------------
+template <int VEC, bool SCATTER_ADD>
+__global__ __launch_bounds__(256) void rows_kernel(const float *in, int64_t ldi, const int32_t *idx, int64_t n_idx,
+                                                    int32_t n_feat, float *out, int64_t ldo, int lanes_per_row)
+{
+    const int rows_per_block = 256 / lanes_per_row;
+    const int li = threadIdx.x % lanes_per_row, rr = threadIdx.x / lanes_per_row;
+    for (int64_t k = (int64_t)blockIdx.x * rows_per_block + rr; k < n_idx; k += (int64_t)gridDim.x * rows_per_block) {
+        int64_t src_row = SCATTER_ADD ? k : idx[k];
+        int64_t dst_row = SCATTER_ADD ? idx[k] : k;
+        for (int32_t f = li * VEC; f < n_feat; f += lanes_per_row * VEC) {
+            if constexpr (VEC == 4) {
+                float4 v = *reinterpret_cast<const float4 *>(in + src_row * ldi + f);
+                float4 *d = reinterpret_cast<float4 *>(out + dst_row * ldo + f);
+                if constexpr (SCATTER_ADD) {
+                    float4 o = *d;
+                    v = make_float4(__fadd_rn(o.x, v.x), __fadd_rn(o.y, v.y), __fadd_rn(o.z, v.z), __fadd_rn(o.w, v.w));
+                }
+                *d = v;
+            } else {
+                float v = in[src_row * ldi + f];
+                float *d = out + dst_row * ldo + f;
+                *d = SCATTER_ADD ? __fadd_rn(*d, v) : v;
+            }
+        }
+    }
+}
+
+int pick_lanes(int32_t n_feat, int vec)
+{
+    int need = (n_feat + vec - 1) / vec;
+    int l = 4;
+    while (l < 64 && l < need) l <<= 1;
+    return l;
+}
+
+template <bool SCATTER_ADD>
+int launch_rows(const float *in, int64_t ldi, const int32_t *idx, int64_t n_idx, int32_t n_feat, float *out, int64_t ldo,
+                hipStream_t st)
+{
+    if (n_idx == 0 || n_feat == 0) return GNNX_OK;
+    const bool vec4 = n_feat % 4 == 0 && ldi % 4 == 0 && ldo % 4 == 0 && aligned16(in) && aligned16(out);
+    int lanes = pick_lanes(n_feat, vec4 ? 4 : 1);
+    int rows_per_block = 256 / lanes;
+    int64_t blocks = ceil_div(n_idx, rows_per_block);
+    if (blocks > 16 * kMaxBlocks) blocks = 16 * kMaxBlocks;
+    if (vec4)
+        hipLaunchKernelGGL((rows_kernel<4, SCATTER_ADD>), dim3((uint32_t)blocks), dim3(256), 0, st, in, ldi, idx, n_idx,
+                           n_feat, out, ldo, lanes);
+    else
+        hipLaunchKernelGGL((rows_kernel<1, SCATTER_ADD>), dim3((uint32_t)blocks), dim3(256), 0, st, in, ldi, idx, n_idx,
+                           n_feat, out, ldo, lanes);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+}  // namespace
+
+GNNX_API int gnnx_colsum_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes)
+{
+    GNNX_REQUIRE(bytes && n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    *bytes = sizeof(float) * (size_t)colsum_blocks(n_rows) * (size_t)(n_feat > 0 ? n_feat : 1);
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out,
+                             void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_feat == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_out, GNNX_ERR_INVALID_ARG, "out is null");
+    hipStream_t st = as_stream(stream);
+    int nb = colsum_blocks(n_rows);
+    size_t need = sizeof(float) * (size_t)nb * n_feat;
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu",
+                 workspace_bytes, need);
+    GNNX_REQUIRE(n_rows == 0 || (d_G && ldg >= n_feat), GNNX_ERR_INVALID_ARG, "G null or ld < n_feat");
+    float *partial = static_cast<float *>(d_workspace);
+    int64_t rpb = ceil_div(n_rows > 0 ? n_rows : 1, nb);
+    if (n_feat >= 128) {
+        hipLaunchKernelGGL(colsum_stage1, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial);
+    } else {
+        int fw = 1;
+        while (fw < n_feat) fw <<= 1;
+        hipLaunchKernelGGL(colsum_stage1_narrow, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, fw, rpb, partial);
+    }
+    GNNX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 256)), dim3(256), 0, st, partial, nb, n_feat, beta,
+                       d_out);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_rowscale_f32(const float *d_X, int64_t ldx, const float *d_v, int64_t n_rows, int32_t n_feat,
+                               float *d_Y, int64_t ldy, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0 || n_feat == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_X && d_v && d_Y && ldx >= n_feat && ldy >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    int64_t blocks = ceil_div(n_rows * n_feat, 256);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(rowwise_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, d_v, n_rows,
+                       n_feat, d_Y, ldy);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_bias_add_f32(const float *d_X, int64_t ldx, const float *d_b, int64_t n_rows, int32_t n_feat,
+                               float *d_Y, int64_t ldy, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0 || n_feat == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_X && d_b && d_Y && ldx >= n_feat && ldy >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    int64_t blocks = ceil_div(n_rows * n_feat, 256);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(rowwise_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, d_b, n_rows,
+                       n_feat, d_Y, ldy);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_axpy_f32(int64_t n, float a, const float *d_x, float *d_y, void *stream)
+{
+    GNNX_REQUIRE(n >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_x && d_y, GNNX_ERR_INVALID_ARG, "null pointer");
+    int64_t blocks = ceil_div(n, 256);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(axpy_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), n, a, d_x, d_y);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_gather_rows_f32(const float *d_X, int64_t ldx, const int32_t *d_idx, int64_t n_idx, int32_t n_feat,
+                                  float *d_out, int64_t ldo, void *stream)
+{
+    GNNX_REQUIRE(n_idx >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_idx == 0 || n_feat == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_X && d_idx && d_out && ldx >= n_feat && ldo >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    return launch_rows<false>(d_X, ldx, d_idx, n_idx, n_feat, d_out, ldo, as_stream(stream));
+}
+
+GNNX_API int gnnx_scatter_add_rows_f32(const float *d_in, int64_t ldi, const int32_t *d_idx, int64_t n_idx,
+                                       int32_t n_feat, float *d_Y, int64_t ldy, void *stream)
+{
+    GNNX_REQUIRE(n_idx >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_idx == 0 || n_feat == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_in && d_idx && d_Y && ldi >= n_feat && ldy >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    return launch_rows<true>(d_in, ldi, d_idx, n_idx, n_feat, d_Y, ldy, as_stream(stream));
+}

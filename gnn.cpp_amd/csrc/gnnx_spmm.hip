@@ -1,0 +1,391 @@
+// CSR SpMM for gfx950 (MI355X): the aggregation step of the GCN hot path.
+//
+// Replaces reference functional::matmul on the dense N x N adjacency (functional.h:399-441 called from
+// graph.cpp:208 and, in backward, operation.h:524-531) plus the broadcast multiply by norm
+// (graph.cpp:209) and the bias add (graph.cpp:188).
+//
+// Design (HBM-bound; DESIGN.md section "SpMM"):
+//   * one output row per G-lane group, G = ceil(F/4) rounded to a power of two (64 lanes = one wavefront
+//     at F = 256, two rows per wavefront at F = 128/100, ...); each lane owns 4 consecutive features and
+//     reads its 16-byte piece of every neighbour row with one global_load_dwordx4, so a neighbour row is
+//     one fully coalesced 4*F-byte burst (1 KiB per wave-instruction at F = 256);
+//   * U neighbour rows in flight per group (register staging; no LDS: a row is used by exactly one
+//     group, there is nothing to share), accumulated strictly in DESCENDING column order with separately
+//     rounded fp32 adds => bit-identical to the reference's sequential dense dot product;
+//   * at G = 64 the row is wave-uniform: rowptr/colidx are fetched with scalar loads, the row base
+//     address lives in SGPRs and the VMEM unit sees only the feature traffic;
+//   * power-law rows: an optional plan cuts rows longer than `chunk` into chunks that are gathered by
+//     separate wavefronts into a partial slab and combined in fixed chunk order by a second tiny kernel
+//     (deterministic; no float atomics).  Chunk items are placed first in the grid.
+#include "gnnx_common.h"
+
+using namespace gnnx;
+
+struct gnnx_spmm_plan {
+    int32_t n_rows = 0;
+    int32_t chunk = 0;
+    int32_t max_feat = 0;
+    int32_t n_split_rows = 0;   // rows with degree > chunk
+    int32_t n_chunks = 0;       // total chunk items
+    int4 *d_items = nullptr;    // [n_chunks] {row, first nz, end nz, partial slot}
+    int4 *d_rows = nullptr;     // [n_split_rows] {row, first slot, n_chunks, 0}
+    float *d_partial = nullptr; // [n_chunks, max_feat]
+    int32_t *d_counters = nullptr;
+};
+
+namespace {
+
+struct SpmmArgs {
+    int32_t n_rows;
+    int32_t n_feat;
+    const int32_t *rowptr;
+    const int32_t *colidx;
+    const float *vals;
+    const float *colscale;
+    const float *rowscale;
+    const float *bias;
+    const float *X;
+    int64_t ldx;
+    float *Y;
+    int64_t ldy;
+    int32_t beta;           // 0 or 1
+    int32_t split_threshold; // rows with degree > this are left to the chunk items (0 = none)
+    // chunk items (plan)
+    const int4 *items;
+    int32_t n_items;
+    float *partial;
+    int32_t partial_ld;
+};
+
+template <int VEC> struct Vec;
+template <> struct Vec<4> { using type = float4; };
+template <> struct Vec<1> { using type = float; };
+
+__device__ __forceinline__ float4 ld_vec(const float4 *p) { return *p; }
+__device__ __forceinline__ float ld_vec(const float *p) { return *p; }
+
+// Separately rounded ops: hipcc contracts a*b+c into an fma by default; the reference rounds the product
+// and the sum separately (x86-64 baseline, no FMA), so spell the roundings out.
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float4 add_rn(float4 a, float4 b)
+{
+    return make_float4(__fadd_rn(a.x, b.x), __fadd_rn(a.y, b.y), __fadd_rn(a.z, b.z), __fadd_rn(a.w, b.w));
+}
+__device__ __forceinline__ float4 mul_rn(float4 a, float s)
+{
+    return make_float4(__fmul_rn(a.x, s), __fmul_rn(a.y, s), __fmul_rn(a.z, s), __fmul_rn(a.w, s));
+}
+__device__ __forceinline__ void zero(float4 &v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void zero(float &v) { v = 0.f; }
+
+// MODE 0: plain gather-add (forward).  MODE 1: gathered row scaled by colscale[c] (backward: norm (.) G).
+// MODE 2: general (vals and/or colscale).
+//
+// Broadcast lane `src` (index inside the G-lane row group) of v to the whole group.  At G == 64 the source
+// lane is wave-uniform => v_readlane into an SGPR, so the neighbour row's base address is scalar and the
+// VMEM instruction is the saddr form; below 64 it is a ds_bpermute (LDS crossbar, no memory traffic).
+template <int G>
+__device__ __forceinline__ int32_t bcast(int32_t v, int src, int gbase)
+{
+    if constexpr (G == 64) return __builtin_amdgcn_readlane(v, src);
+    else return __shfl(v, gbase + src, 64);
+}
+
+// One batch of B neighbour rows: all B loads are issued before the first add (B rows in flight per group),
+// adds strictly in order k, k+1, ... (= descending column).  No load is predicated: hipcc turns a
+// conditional load into branch + s_waitcnt vmcnt(0) per element, which serialises the gather.
+template <int G, int VEC, int B, int MODE>
+__device__ __forceinline__ void gather_batch(typename Vec<VEC>::type &acc, int k, int32_t myc, float mysc, float myval,
+                                             int gbase, const float *xf, const SpmmArgs &a)
+{
+    using V = typename Vec<VEC>::type;
+    int32_t c[B];
+    V v[B];
+#pragma unroll
+    for (int u = 0; u < B; u++) c[u] = bcast<G>(myc, k + u, gbase);
+#pragma unroll
+    for (int u = 0; u < B; u++) v[u] = ld_vec(reinterpret_cast<const V *>(xf + (int64_t)c[u] * a.ldx));
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+        V t = v[u];
+        if constexpr (MODE >= 1) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(mysc), k + u, gbase)));
+        if constexpr (MODE == 2) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(myval), k + u, gbase)));
+        acc = add_rn(acc, t);
+    }
+}
+
+// Gather-accumulate nz range [b, e) of one row in DESCENDING column order (`s = p[n-1]; s += p[n-2]; ...`;
+// starting from 0 is the same thing except for the sign of a zero).
+// Indices are fetched G at a time with ONE coalesced vector load per group (lane li takes the li-th
+// neighbour from the top), together with their colscale / vals, then handed out by bcast().
+template <int G, int VEC, int U, int MODE>
+__device__ __forceinline__ typename Vec<VEC>::type gather_range(int32_t b, int32_t e, const float *xf, int li,
+                                                                const SpmmArgs &a)
+{
+    using V = typename Vec<VEC>::type;
+    constexpr int UE = U < G ? U : G;
+    V acc;
+    zero(acc);
+    const int gbase = (threadIdx.x & 63) - li;
+    for (int32_t hi = e; hi > b; hi -= G) {
+        int32_t q = hi - 1 - li;
+        q = q >= b ? q : b;
+        const int32_t myc = a.colidx[q];
+        float mysc = 1.f, myval = 1.f;
+        if constexpr (MODE == 1) mysc = a.colscale[myc];
+        if constexpr (MODE == 2) {
+            if (a.colscale) mysc = a.colscale[myc];
+            if (a.vals) myval = a.vals[q];
+        }
+        const int n = (hi - b) < G ? (hi - b) : G;
+        int k = 0;
+        for (; k + UE <= n; k += UE) gather_batch<G, VEC, UE, MODE>(acc, k, myc, mysc, myval, gbase, xf, a);
+        if constexpr (UE >= 8) if (k + 4 <= n) { gather_batch<G, VEC, 4, MODE>(acc, k, myc, mysc, myval, gbase, xf, a); k += 4; }
+        if constexpr (UE >= 4) if (k + 2 <= n) { gather_batch<G, VEC, 2, MODE>(acc, k, myc, mysc, myval, gbase, xf, a); k += 2; }
+        if constexpr (UE >= 2) if (k + 1 <= n) { gather_batch<G, VEC, 1, MODE>(acc, k, myc, mysc, myval, gbase, xf, a); k += 1; }
+    }
+    return acc;
+}
+
+template <int VEC>
+__device__ __forceinline__ void epilogue_store(typename Vec<VEC>::type acc, int32_t row, int32_t f0, const SpmmArgs &a)
+{
+    using V = typename Vec<VEC>::type;
+    if (a.rowscale) acc = mul_rn(acc, a.rowscale[row]);
+    if (a.bias) acc = add_rn(acc, ld_vec(reinterpret_cast<const V *>(a.bias + f0)));
+    V *dst = reinterpret_cast<V *>(a.Y + (int64_t)row * a.ldy + f0);
+    if (a.beta) acc = add_rn(*dst, acc);
+    *dst = acc;
+}
+
+// grid.x = n_item_blocks + n_row_blocks ; grid.y = feature tiles of G*VEC features.
+template <int G, int VEC, int U, int MODE>
+__global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_blocks)
+{
+    constexpr int GROUPS = 256 / G;
+    const int tid = threadIdx.x;
+    const int li = tid % G;         // lane inside the row group
+    int grp = tid / G;              // group inside the block
+    if constexpr (G == 64) grp = __builtin_amdgcn_readfirstlane(grp);
+    const int32_t f0 = (blockIdx.y * G + li) * VEC;
+    const bool active = f0 + VEC <= a.n_feat;
+    const float *xf = a.X + (active ? f0 : 0);  // lanes past n_feat read feature 0 and never store
+
+    if ((int32_t)blockIdx.x < n_item_blocks) {
+        // ---- chunk item of a long row: partial sum into the plan's slab
+        int32_t it = blockIdx.x * GROUPS + grp;
+        if (it >= a.n_items) return;
+        int4 item = a.items[it];
+        if constexpr (G == 64) {
+            item.x = __builtin_amdgcn_readfirstlane(item.x);
+            item.y = __builtin_amdgcn_readfirstlane(item.y);
+            item.z = __builtin_amdgcn_readfirstlane(item.z);
+            item.w = __builtin_amdgcn_readfirstlane(item.w);
+        }
+        auto acc = gather_range<G, VEC, U, MODE>(item.y, item.z, xf, li, a);
+        if (active) *reinterpret_cast<typename Vec<VEC>::type *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
+        return;
+    }
+
+    int32_t row = (blockIdx.x - n_item_blocks) * GROUPS + grp;
+    if (row >= a.n_rows) return;
+    int32_t b = a.rowptr[row], e = a.rowptr[row + 1];
+    if constexpr (G == 64) {
+        b = __builtin_amdgcn_readfirstlane(b);
+        e = __builtin_amdgcn_readfirstlane(e);
+    }
+    if (a.split_threshold > 0 && e - b > a.split_threshold) return;  // handled by chunk items + combine
+    auto acc = gather_range<G, VEC, U, MODE>(b, e, xf, li, a);
+    if (active) epilogue_store<VEC>(acc, row, f0, a);
+}
+
+// Combine the partial slabs of split rows in chunk order (chunk 0 holds the HIGHEST columns), then the
+// same epilogue as the main kernel.  One G-lane group per split row.
+template <int G, int VEC>
+__global__ __launch_bounds__(256) void spmm_combine_kernel(SpmmArgs a, const int4 *rows, int32_t n_split)
+{
+    constexpr int GROUPS = 256 / G;
+    const int li = threadIdx.x % G;
+    const int grp = threadIdx.x / G;
+    const int32_t f0 = (blockIdx.y * G + li) * VEC;
+    int32_t k = blockIdx.x * GROUPS + grp;
+    if (k >= n_split || f0 + VEC > a.n_feat) return;
+    using V = typename Vec<VEC>::type;
+    int4 r = rows[k];
+    V acc = ld_vec(reinterpret_cast<const V *>(a.partial + (int64_t)r.y * a.partial_ld + f0));
+    for (int32_t c = 1; c < r.z; c++)
+        acc = add_rn(acc, ld_vec(reinterpret_cast<const V *>(a.partial + (int64_t)(r.y + c) * a.partial_ld + f0)));
+    epilogue_store<VEC>(acc, r.x, f0, a);
+}
+
+// ---- plan construction -------------------------------------------------------------------------
+__global__ void plan_count_kernel(const int32_t *rowptr, int32_t n_rows, int32_t chunk, int32_t *counters)
+{
+    int32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    int32_t deg = rowptr[row + 1] - rowptr[row];
+    if (deg > chunk) {
+        atomicAdd(&counters[0], 1);
+        atomicAdd(&counters[1], (deg + chunk - 1) / chunk);
+    }
+}
+
+__global__ void plan_fill_kernel(const int32_t *rowptr, int32_t n_rows, int32_t chunk, int32_t *counters, int4 *items,
+                                 int4 *rows)
+{
+    int32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    int32_t b = rowptr[row], e = rowptr[row + 1];
+    int32_t deg = e - b;
+    if (deg <= chunk) return;
+    int32_t nc = (deg + chunk - 1) / chunk;
+    int32_t k = atomicAdd(&counters[2], 1);
+    int32_t slot = atomicAdd(&counters[3], nc);
+    rows[k] = make_int4(row, slot, nc, 0);
+    // chunk 0 = the highest columns, so that chunk order == descending column order
+    int32_t hi = e;
+    for (int32_t c = 0; c < nc; c++) {
+        int32_t lo = hi - chunk < b ? b : hi - chunk;
+        items[slot + c] = make_int4(row, lo, hi, slot + c);
+        hi = lo;
+    }
+}
+
+template <int G, int VEC, int U>
+int launch_mode(const SpmmArgs &a, const gnnx_spmm_plan *plan, hipStream_t st)
+{
+    constexpr int GROUPS = 256 / G;
+    const int feat_per_tile = G * VEC;
+    dim3 grid;
+    int32_t n_item_blocks = (int32_t)ceil_div(a.n_items, GROUPS);
+    int64_t n_row_blocks = ceil_div(a.n_rows, GROUPS);
+    grid.x = (uint32_t)(n_item_blocks + n_row_blocks);
+    grid.y = (uint32_t)ceil_div(a.n_feat, feat_per_tile);
+    if (grid.x == 0) return GNNX_OK;
+    const bool general = a.vals != nullptr;
+    if (general)
+        hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 2>), grid, dim3(256), 0, st, a, n_item_blocks);
+    else if (a.colscale)
+        hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 1>), grid, dim3(256), 0, st, a, n_item_blocks);
+    else
+        hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 0>), grid, dim3(256), 0, st, a, n_item_blocks);
+    GNNX_LAUNCH_CHECK();
+    if (plan && plan->n_split_rows > 0) {
+        dim3 cgrid((uint32_t)ceil_div(plan->n_split_rows, GROUPS), grid.y);
+        hipLaunchKernelGGL((spmm_combine_kernel<G, VEC>), cgrid, dim3(256), 0, st, a, plan->d_rows, plan->n_split_rows);
+        GNNX_LAUNCH_CHECK();
+    }
+    return GNNX_OK;
+}
+
+}  // namespace
+
+GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int32_t chunk, int32_t max_feat,
+                                   gnnx_spmm_plan **plan_out, void *stream)
+{
+    GNNX_REQUIRE(d_rowptr && plan_out, GNNX_ERR_INVALID_ARG, "null pointer");
+    GNNX_REQUIRE(n_rows >= 0 && chunk > 0 && max_feat > 0, GNNX_ERR_INVALID_ARG, "n_rows/chunk/max_feat");
+    hipStream_t st = as_stream(stream);
+    auto *plan = new gnnx_spmm_plan();
+    plan->n_rows = n_rows;
+    plan->chunk = chunk;
+    plan->max_feat = (max_feat + 3) & ~3;
+    *plan_out = plan;
+    GNNX_HIP_CHECK(hipMalloc(&plan->d_counters, 4 * sizeof(int32_t)));
+    GNNX_HIP_CHECK(hipMemsetAsync(plan->d_counters, 0, 4 * sizeof(int32_t), st));
+    if (n_rows == 0) return GNNX_OK;
+    dim3 grid((uint32_t)ceil_div(n_rows, 256));
+    hipLaunchKernelGGL(plan_count_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, chunk, plan->d_counters);
+    GNNX_LAUNCH_CHECK();
+    int32_t h[4];
+    GNNX_HIP_CHECK(hipMemcpyAsync(h, plan->d_counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    plan->n_split_rows = h[0];
+    plan->n_chunks = h[1];
+    if (plan->n_split_rows > 0) {
+        GNNX_HIP_CHECK(hipMalloc(&plan->d_items, sizeof(int4) * (size_t)plan->n_chunks));
+        GNNX_HIP_CHECK(hipMalloc(&plan->d_rows, sizeof(int4) * (size_t)plan->n_split_rows));
+        GNNX_HIP_CHECK(hipMalloc(&plan->d_partial, sizeof(float) * (size_t)plan->n_chunks * plan->max_feat));
+        hipLaunchKernelGGL(plan_fill_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, chunk, plan->d_counters,
+                           plan->d_items, plan->d_rows);
+        GNNX_LAUNCH_CHECK();
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_spmm_plan_destroy(gnnx_spmm_plan *plan)
+{
+    if (!plan) return GNNX_OK;
+    if (plan->d_items) (void)hipFree(plan->d_items);
+    if (plan->d_rows) (void)hipFree(plan->d_rows);
+    if (plan->d_partial) (void)hipFree(plan->d_partial);
+    if (plan->d_counters) (void)hipFree(plan->d_counters);
+    delete plan;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_split_rows, int64_t *n_chunks)
+{
+    GNNX_REQUIRE(plan, GNNX_ERR_INVALID_ARG, "plan is null");
+    if (n_split_rows) *n_split_rows = plan->n_split_rows;
+    if (n_chunks) *n_chunks = plan->n_chunks;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
+                               const int32_t *d_colidx, const float *d_vals, const float *d_colscale,
+                               const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx,
+                               float beta, float *d_Y, int64_t ldy, const gnnx_spmm_plan *plan, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0 || n_feat == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_rowptr && d_X && d_Y, GNNX_ERR_INVALID_ARG, "null pointer");
+    GNNX_REQUIRE(ldx >= n_feat && ldy >= n_feat, GNNX_ERR_SHAPE, "leading dimension smaller than n_feat");
+    GNNX_REQUIRE(beta == 0.f || beta == 1.f, GNNX_ERR_UNSUPPORTED, "beta must be 0 or 1");
+    GNNX_REQUIRE(d_X != d_Y, GNNX_ERR_INVALID_ARG, "X and Y alias");
+    if (plan) {
+        GNNX_REQUIRE(plan->n_rows == n_rows, GNNX_ERR_SHAPE, "plan was built for %d rows, got %d", plan->n_rows, n_rows);
+        GNNX_REQUIRE(plan->n_split_rows == 0 || n_feat <= plan->max_feat, GNNX_ERR_SHAPE,
+                     "plan was built for at most %d features, got %d", plan->max_feat, n_feat);
+    }
+    SpmmArgs a{};
+    a.n_rows = n_rows;
+    a.n_feat = n_feat;
+    a.rowptr = d_rowptr;
+    a.colidx = d_colidx;
+    a.vals = d_vals;
+    a.colscale = d_colscale;
+    a.rowscale = d_rowscale;
+    a.bias = d_bias;
+    a.X = d_X;
+    a.ldx = ldx;
+    a.Y = d_Y;
+    a.ldy = ldy;
+    a.beta = beta != 0.f;
+    if (plan && plan->n_split_rows > 0) {
+        a.split_threshold = plan->chunk;
+        a.items = plan->d_items;
+        a.n_items = plan->n_chunks;
+        a.partial = plan->d_partial;
+        a.partial_ld = plan->max_feat;
+    }
+    hipStream_t st = as_stream(stream);
+    auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const bool vec4 = (n_feat % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(d_X) && aligned16(d_Y) &&
+                      (!d_bias || aligned16(d_bias));
+    if (vec4) {
+        int lanes = n_feat / 4;
+        if (lanes > 32) return launch_mode<64, 4, 8>(a, plan, st);
+        if (lanes > 16) return launch_mode<32, 4, 8>(a, plan, st);
+        if (lanes > 8) return launch_mode<16, 4, 8>(a, plan, st);
+        if (lanes > 4) return launch_mode<8, 4, 8>(a, plan, st);
+        return launch_mode<4, 4, 8>(a, plan, st);
+    }
+    if (n_feat > 32) return launch_mode<64, 1, 8>(a, plan, st);
+    if (n_feat > 16) return launch_mode<32, 1, 8>(a, plan, st);
+    if (n_feat > 8) return launch_mode<16, 1, 8>(a, plan, st);
+    if (n_feat > 4) return launch_mode<8, 1, 8>(a, plan, st);
+    return launch_mode<4, 1, 8>(a, plan, st);
+}

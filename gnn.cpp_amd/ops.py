@@ -1,0 +1,237 @@
+"""Pointer-level Python driver of the GCN hot path (tests / bench / multi-GPU harness).
+
+torch tensors are used only as owners of device memory and for the current stream; every computation is
+a C-ABI call into libgnnx_hip.so (include/gnnx.h).  No CPU fallback exists: a tensor that is not on a
+CUDA (HIP) device is an error.
+
+Mirrors the call structure of the reference's GCNConv (src/graph.cpp:170-212):
+  CsrGraph.from_coo        <- add_self_loops + edge_to_adj_mat            graph.cpp:172,177
+  CsrGraph.s / .norm       <- deg / pow / mm / *=                         graph.cpp:178-185
+  linear_fwd               <- Linear::forward                             nn.cpp:205-211
+  aggregate_fwd            <- aggregate_and_update (+ bias)               graph.cpp:204-212,188
+  aggregate_bwd, colsum,   <- Add/Mul/MatMul/Transpose::_backward         operation.h:114-128,144-167,
+  linear_bwd                                                              504-534,416-433
+"""
+import ctypes as C
+
+import torch
+
+from . import capi
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise capi.GnnxError(-1, "ops", "tensor is not on a HIP device (there is no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D tensor expected"
+    return t.stride(0)
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, tag):
+    """Grow-only device scratch buffer per (device, tag) -- allocated outside the timed/compute calls."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+class SpmmPlan:
+    def __init__(self, rowptr, chunk, max_feat):
+        self.h = C.c_void_p()
+        self._rowptr = rowptr
+        capi.call("gnnx_spmm_plan_create", _ptr(rowptr), rowptr.numel() - 1, int(chunk), int(max_feat),
+                  C.byref(self.h), _stream())
+        a, b = C.c_int64(0), C.c_int64(0)
+        capi.call("gnnx_spmm_plan_info", self.h, C.byref(a), C.byref(b))
+        self.n_split_rows, self.n_chunks = a.value, b.value
+
+    def __del__(self):
+        try:
+            capi.lib().gnnx_spmm_plan_destroy(self.h)
+        except Exception:
+            pass
+
+
+class CsrGraph:
+    """CSR of A (forward) and of A^T (backward) with the reference's adjacency semantics, plus s and norm."""
+
+    def __init__(self, n_nodes, rowptr, colidx, rowptr_t=None, colidx_t=None):
+        self.n = int(n_nodes)
+        self.rowptr, self.colidx = rowptr, colidx
+        self.rowptr_t, self.colidx_t = rowptr_t, colidx_t
+        self.nnz = int(colidx.numel())
+        self.s = self.norm = None
+        self.plan = self.plan_t = None
+
+    @staticmethod
+    def csr_from_coo(src, dst, n_nodes, flags=0):
+        """gnnx_csr_from_coo on device int32 tensors -> (rowptr, colidx)."""
+        E = int(src.numel())
+        dev = src.device
+        rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        colidx = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        ws = _workspace(capi.csr_from_coo_workspace(E, n_nodes), dev, "csr")
+        nnz = C.c_int64(0)
+        capi.call("gnnx_csr_from_coo", _ptr(src), _ptr(dst), E, int(n_nodes), int(flags), _ptr(rowptr), _ptr(colidx),
+                  C.byref(nnz), _ptr(ws), ws.numel(), _stream())
+        return rowptr, colidx[: nnz.value].clone()
+
+    @classmethod
+    def from_coo(cls, src, dst, n_nodes, transpose=True, norm=True):
+        rowptr, colidx = cls.csr_from_coo(src, dst, n_nodes)
+        g = cls(n_nodes, rowptr, colidx)
+        if transpose:
+            g.rowptr_t, g.colidx_t = cls.csr_from_coo(dst, src, n_nodes)
+        if norm:
+            g.compute_norm()
+        return g
+
+    def compute_norm(self):
+        dev = self.rowptr.device
+        self.s = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.norm = torch.empty(self.n, dtype=torch.float32, device=dev)
+        capi.call("gnnx_degree_norm_f32", _ptr(self.rowptr), _ptr(self.colidx), self.n, _ptr(self.s), None,
+                  _ptr(self.norm), _stream())
+        return self.s, self.norm
+
+    def make_plans(self, chunk, max_feat):
+        """Load-balancing plans for power-law rows (forward CSR and transposed CSR)."""
+        self.plan = SpmmPlan(self.rowptr, chunk, max_feat)
+        if self.rowptr_t is not None:
+            self.plan_t = SpmmPlan(self.rowptr_t, chunk, max_feat)
+        return self.plan, self.plan_t
+
+
+def spmm(rowptr, colidx, X, out=None, vals=None, colscale=None, rowscale=None, bias=None, beta=0.0, plan=None,
+         n_rows=None):
+    """gnnx_spmm_csr_f32: Y = beta*Y + rowscale (.) (A . (colscale (.) X)) + bias."""
+    n_rows = int(rowptr.numel() - 1) if n_rows is None else n_rows
+    n_cols, F = X.shape
+    if out is None:
+        out = torch.empty((n_rows, F), dtype=torch.float32, device=X.device)
+    capi.call("gnnx_spmm_csr_f32", n_rows, n_cols, F, _ptr(rowptr), _ptr(colidx), _ptr(vals), _ptr(colscale),
+              _ptr(rowscale), _ptr(bias), _ptr(X), _ld(X), float(beta), _ptr(out), _ld(out),
+              plan.h if plan is not None else None, _stream())
+    return out
+
+
+def gemm(A, B, transA=False, transB=False, out=None, alpha=1.0, beta=0.0):
+    """gnnx_gemm_f32: C = alpha * op(A) . op(B) + beta * C (row-major, no operand is transposed in memory)."""
+    M = A.shape[1] if transA else A.shape[0]
+    K = A.shape[0] if transA else A.shape[1]
+    N = B.shape[0] if transB else B.shape[1]
+    Kb = B.shape[1] if transB else B.shape[0]
+    if K != Kb:
+        raise capi.GnnxError(-2, "gemm", f"inner dimensions differ: {K} vs {Kb}")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    wsb = capi.gemm_workspace(transA, transB, M, N, K)
+    ws = _workspace(wsb, A.device, "gemm") if wsb else None
+    capi.call("gnnx_gemm_f32", int(transA), int(transB), M, N, K, float(alpha), _ptr(A), _ld(A), _ptr(B), _ld(B),
+              float(beta), _ptr(out), _ld(out), _ptr(ws), wsb, _stream())
+    return out
+
+
+def colsum(G, out=None, beta=0.0):
+    N, F = G.shape
+    if out is None:
+        out = torch.empty(F, dtype=torch.float32, device=G.device)
+    wsb = capi.colsum_workspace(N, F)
+    ws = _workspace(wsb, G.device, "colsum")
+    capi.call("gnnx_colsum_f32", _ptr(G), _ld(G), N, F, float(beta), _ptr(out), _ptr(ws), wsb, _stream())
+    return out
+
+
+def gather_rows(X, idx, out=None):
+    n, F = int(idx.numel()), X.shape[1]
+    if out is None:
+        out = torch.empty((n, F), dtype=torch.float32, device=X.device)
+    capi.call("gnnx_gather_rows_f32", _ptr(X), _ld(X), _ptr(idx), n, F, _ptr(out), _ld(out), _stream())
+    return out
+
+
+def scatter_add_rows(inp, idx, Y):
+    n, F = int(idx.numel()), inp.shape[1]
+    capi.call("gnnx_scatter_add_rows_f32", _ptr(inp), _ld(inp), _ptr(idx), n, F, _ptr(Y), _ld(Y), _stream())
+    return Y
+
+
+def rowscale(X, v, out=None):
+    out = torch.empty_like(X) if out is None else out
+    capi.call("gnnx_rowscale_f32", _ptr(X), _ld(X), _ptr(v), X.shape[0], X.shape[1], _ptr(out), _ld(out), _stream())
+    return out
+
+
+def bias_add(X, b, out=None):
+    out = torch.empty_like(X) if out is None else out
+    capi.call("gnnx_bias_add_f32", _ptr(X), _ld(X), _ptr(b), X.shape[0], X.shape[1], _ptr(out), _ld(out), _stream())
+    return out
+
+
+def axpy(a, x, y):
+    capi.call("gnnx_axpy_f32", x.numel(), float(a), _ptr(x), _ptr(y), _stream())
+    return y
+
+
+def rmat_edges(seed, n_nodes, n_edges, a=0.57, b=0.19, c=0.19, device="cuda", first_edge=0):
+    src = torch.empty(n_edges, dtype=torch.int32, device=device)
+    dst = torch.empty(n_edges, dtype=torch.int32, device=device)
+    capi.call("gnnx_rmat_edges", int(seed), int(n_nodes), int(n_edges), int(first_edge), float(a), float(b), float(c),
+              _ptr(src), _ptr(dst), _stream())
+    return src, dst
+
+
+def uniform_pm1(seed, shape, scale=1.0, device="cuda"):
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    capi.call("gnnx_uniform_pm1_f32", int(seed), out.numel(), float(scale), _ptr(out), _stream())
+    return out
+
+
+# ---- the hot path, chained as the reference chains it ------------------------------------------------
+def linear_fwd(X, W, out=None):
+    """H = X . W^T  (nn.cpp:205-211; GCNConv's lin has no bias, graph.cpp:162)."""
+    return gemm(X, W, transB=True, out=out)
+
+
+def aggregate_fwd(g, H, bias=None, out=None, use_plan=True):
+    """out = norm (.) (A . H) (+ bias)  (graph.cpp:204-212, :188)."""
+    return spmm(g.rowptr, g.colidx, H, out=out, rowscale=g.norm, bias=bias, plan=g.plan if use_plan else None)
+
+
+def aggregate_bwd(g, G, out=None, beta=0.0, use_plan=True):
+    """dH = A^T . (norm (.) G)  (operation.h:144-167 then :524-531)."""
+    return spmm(g.rowptr_t, g.colidx_t, G, out=out, colscale=g.norm, beta=beta, plan=g.plan_t if use_plan else None)
+
+
+def linear_bwd(dH, X, W, dX=None, dW=None, beta_dw=0.0):
+    """dX = dH . W ; dW = dH^T . X  (operation.h:516-531, :416-433)."""
+    dX = gemm(dH, W, out=dX)
+    dW = gemm(dH, X, transA=True, out=dW, beta=beta_dw)
+    return dX, dW
+
+
+def gcn_layer_fwd(g, X, W, bias):
+    H = linear_fwd(X, W)
+    out = aggregate_fwd(g, H, bias)
+    return H, out
+
+
+def gcn_layer_bwd(g, X, W, G):
+    dbias = colsum(G)
+    dH = aggregate_bwd(g, G)
+    dX, dW = linear_bwd(dH, X, W)
+    return dict(dbias=dbias, dH=dH, dX=dX, dW=dW)

@@ -1,0 +1,196 @@
+/*
+ * gnnx.h -- C-ABI of the MI355X (gfx950) backend for the walexi/gnn.cpp GCN hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its device hook is
+ * the empty include/device.cuh + the commented call `device::add(out_data, lhs_data, rhs_data)`
+ * (reference include/functional.h:174,180) -- free functions on raw buffers called from
+ * functional::<op>.  These entry points sit exactly there: plain pointers and sizes, int status
+ * returns, an explicit stream, no C++/torch types.  The C++ mirror of the reference API
+ * (gnn.cpp_amd/host/) and the ctypes binding (gnn.cpp_amd/capi.py) are the two callers.
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory (hipMalloc'd, e.g. torch.Tensor.data_ptr() or gnnx_malloc);
+ *   - dense matrices are row-major fp32 with an explicit leading dimension in ELEMENTS (ld >= cols),
+ *     exactly the reference's contiguous std::valarray<float> layout (reference include/tensor.h:825)
+ *     when ld == cols;
+ *   - CSR indices are int32 (rowptr has n_rows+1 entries; nnz < 2^31), columns ASCENDING in a row
+ *     (the row-major scan order of reference src/graph.cpp:52-60);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are asynchronous on
+ *     it unless stated; nothing is allocated or synchronised inside a compute call;
+ *   - return 0 (GNNX_OK) or a negative gnnx_status; gnnx_last_error() gives the message of the
+ *     calling thread's last failure.  The C++ wrapper maps them to std::runtime_error with the
+ *     reference's ERROR_* texts (reference include/utils.h:19-30).
+ *   - one host thread per device, like the (single-threaded) reference.
+ */
+#ifndef GNNX_H
+#define GNNX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNX_VERSION 100
+
+typedef enum gnnx_status {
+    GNNX_OK = 0,
+    GNNX_ERR_INVALID_ARG = -1,  /* null pointer / negative size / ld < cols / misaligned */
+    GNNX_ERR_SHAPE = -2,        /* operand shapes do not agree (reference CHECK_MM_DIMS, utils.cpp:8-78) */
+    GNNX_ERR_INDEX_RANGE = -3,  /* an edge endpoint is outside [0, n_nodes) (reference graph.cpp:89) */
+    GNNX_ERR_WORKSPACE = -4,    /* caller-provided workspace too small */
+    GNNX_ERR_HIP = -5,          /* a HIP runtime call failed (message in gnnx_last_error) */
+    GNNX_ERR_NO_DEVICE = -6,    /* no gfx950 device visible */
+    GNNX_ERR_UNSUPPORTED = -7
+} gnnx_status;
+
+int gnnx_version(void);
+const char *gnnx_status_string(int status);
+const char *gnnx_last_error(void);
+
+/* ------------------------------------------------------------------ runtime plumbing ------------- */
+/* Thin HIP wrappers so that host code above this ABI needs no HIP headers. */
+int gnnx_device_count(int *count);
+int gnnx_set_device(int device);
+int gnnx_device_name(int device, char *buf, size_t buflen);
+int gnnx_malloc(void **d_ptr, size_t bytes);
+int gnnx_free(void *d_ptr);
+int gnnx_memset(void *d_ptr, int value, size_t bytes, void *stream);
+int gnnx_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int gnnx_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream); /* synchronises `stream` */
+int gnnx_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+int gnnx_stream_create(void **stream);
+int gnnx_stream_destroy(void *stream);
+int gnnx_stream_sync(void *stream);
+int gnnx_device_sync(void);
+int gnnx_event_create(void **event);
+int gnnx_event_destroy(void *event);
+int gnnx_event_record(void *event, void *stream);
+int gnnx_event_sync(void *event);
+int gnnx_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* ------------------------------------------------------------------ graph build ------------------ */
+/*
+ * COO [2,E] -> CSR with the reference's adjacency semantics:
+ *   A[src][dst] = 1 by assignment  => duplicate edges collapse   (reference graph.cpp:21-44, line 40)
+ *   diagonal zeroed                => self loops are REMOVED     (graph.cpp:68-75 with fillValue 0, called
+ *                                                                 from GCNConv::forward graph.cpp:172)
+ *   row-major scan                 => entries ordered by (src,dst) (graph.cpp:46-67)
+ * Replaces the dense round trip edge_to_adj_mat -> fill_diagonal_ -> adj_to_edge_list.
+ * Pass (d_dst, d_src) to get the CSR of A^T (what MatMul::_backward's dense transpose,
+ * reference operation.h:524-527, becomes).
+ *
+ * d_rowptr: n_nodes+1 int32.  d_colidx: capacity n_edges int32.  *nnz_out: host int64, valid on return
+ * (this call synchronises `stream`).  Workspace: gnnx_csr_from_coo_workspace() bytes of device memory.
+ * flags: bit0 keep self loops, bit1 keep duplicates (both 0 = reference semantics).
+ * Errors: GNNX_ERR_INDEX_RANGE if any endpoint is outside [0,n_nodes) (the reference would write out
+ * of bounds at graph.cpp:40; its Data ctor throws at graph.cpp:89).
+ */
+#define GNNX_CSR_KEEP_SELF_LOOPS 1u
+#define GNNX_CSR_KEEP_DUPLICATES 2u
+int gnnx_csr_from_coo_workspace(int64_t n_edges, int32_t n_nodes, size_t *bytes);
+int gnnx_csr_from_coo(const int32_t *d_src, const int32_t *d_dst, int64_t n_edges, int32_t n_nodes, uint32_t flags,
+                      int32_t *d_rowptr, int32_t *d_colidx, int64_t *nnz_out, void *d_workspace,
+                      size_t workspace_bytes, void *stream);
+
+/*
+ * Degree / symmetric-normalisation block of GCNConv::forward (reference graph.cpp:177-185):
+ *   deg_i = 1 + sum_j A_ij        (adj_mat->sum(-1,true) + 1;  the "+1" stays although self loops were removed)
+ *   s_i   = deg_i ^ (-1/2)        (deg->pow(-0.5))
+ *   norm_i = s_i * sum_j A_ij s_j (adj_mat->mm(deg); norm *= deg), inner sum in the reference's matmul
+ *            order (descending j, see DESIGN.md "summation order").
+ * d_s and d_norm: n_rows fp32 each (the reference's [N,1] tensors).  Either may be NULL.
+ * For a row block of a sharded graph pass d_s_cols (the s values indexed by COLUMN id, i.e. [local|halo])
+ * and d_s is written for the block's own rows only; with d_s_cols == NULL columns index d_s itself.
+ */
+int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_colidx, int32_t n_rows, float *d_s,
+                         const float *d_s_cols, float *d_norm, void *stream);
+
+/* ------------------------------------------------------------------ hot path: aggregation -------- */
+/*
+ * CSR SpMM with fused prologue/epilogue -- replaces functional::matmul on the dense N x N adjacency
+ * (reference functional.h:399-441 called from graph.cpp:208), the broadcast multiply by norm
+ * (graph.cpp:209 -> functional.h:190-213) and the bias add (graph.cpp:188 -> functional.h:163-187):
+ *
+ *   Y[i,:] = beta * Y[i,:] + rowscale[i] * ( sum_{p in row i, DESCENDING column} vals[p] * colscale[c_p] * X[c_p,:] ) + bias
+ *
+ *   forward  (graph.cpp:204-212,188):  vals=NULL colscale=NULL rowscale=norm bias=bias|NULL  on CSR(A)
+ *   backward (operation.h:144-167 then :524-531):  dH = A^T . (norm (.) G):
+ *                                      vals=NULL colscale=norm rowscale=NULL bias=NULL      on CSR(A^T)
+ *   Mode SYM (textbook D^-1/2 A D^-1/2): colscale=s rowscale=s.
+ * Every product/add is separately rounded fp32 in the reference's order, so with `plan` == NULL (or a
+ * plan that splits no row) the result is bit-identical to the reference CPU path (modulo the sign of 0).
+ * vals, colscale, rowscale, bias may each be NULL.  beta is 0 or 1 (1 = the reference's `_grad +=`,
+ * tensor.h:268-271).  X: [n_cols, F] ld ldx.  Y: [n_rows, F] ld ldy.  X and Y must not alias.
+ *
+ * `plan` (optional, from gnnx_spmm_plan_create) load-balances power-law rows: rows longer than the plan's
+ * chunk are cut into chunks summed by separate wavefronts and combined in chunk order (deterministic,
+ * run-to-run reproducible; differs from the sequential order only in those rows, by O(eps * log)).
+ */
+typedef struct gnnx_spmm_plan gnnx_spmm_plan; /* opaque, device-resident work list */
+int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int32_t chunk, int32_t max_feat,
+                          gnnx_spmm_plan **plan, void *stream);
+int gnnx_spmm_plan_destroy(gnnx_spmm_plan *plan);
+int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_split_rows, int64_t *n_chunks);
+
+int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
+                      const int32_t *d_colidx, const float *d_vals, const float *d_colscale,
+                      const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx, float beta,
+                      float *d_Y, int64_t ldy, const gnnx_spmm_plan *plan, void *stream);
+
+/* ------------------------------------------------------------------ hot path: transform ---------- */
+/*
+ * fp32 GEMM on the MFMA units (v_mfma_f32_32x32x2_f32, exact f32) -- replaces functional::matmul for the
+ * dense products of the path (reference functional.h:399-441):
+ *   C[M,N] = alpha * op(A)[M,K] . op(B)[K,N] + beta * C         row-major, ld in elements
+ *   forward   H  = X . W^T      (nn.cpp:205-211)        transA=0 transB=1  A=X[N,Fin]   B=W[Fout,Fin]
+ *   backward  dX = dH . W       (operation.h:516-523)   transA=0 transB=0  A=dH[N,Fout] B=W[Fout,Fin]
+ *             dW = dH^T . X     (operation.h:524-531 + Transpose::_backward :416-433)
+ *                                                       transA=1 transB=0  A=dH[N,Fout] B=X[N,Fin]
+ * No operand is ever transposed in memory (the reference materialises W^T, nn.cpp:207, and a clone of
+ * each operand's transpose in backward).  transA=1 (reduction over the node dimension) runs split-K over
+ * workgroups into the caller's workspace and reduces slabs in a fixed order (deterministic).
+ * Workspace: gnnx_gemm_workspace() bytes (0 for transA=0).
+ */
+int gnnx_gemm_workspace(int transA, int transB, int64_t M, int64_t N, int64_t K, size_t *bytes);
+int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float *d_A,
+                  int64_t lda, const float *d_B, int64_t ldb, float beta, float *d_C, int64_t ldc,
+                  void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ small ops on the path -------- */
+/* dbias: out[f] = beta*out[f] + sum_i G[i,f]  (Add::_backward -> sum_to_size, reference operation.h:114-128,
+ * tensor.h:618-638).  Two-stage deterministic tree (fixed grid); workspace gnnx_colsum_workspace() bytes. */
+int gnnx_colsum_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes);
+int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out,
+                    void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Unfused forms of the epilogues, for callers that go op by op through the tensor API:
+ *   rowscale: Y[i,:] = X[i,:] * v[i]      ([N,F] (.) [N,1], reference functional.h:190-213 + utils.h:181-228)
+ *   bias    : Y[i,:] = X[i,:] + b[:]      ([N,F] + [F],     reference functional.h:163-187)
+ *   axpy    : y += a * x                  (tensor.h:268-271 `_grad +=`, a = 1)
+ * X and Y may alias. */
+int gnnx_rowscale_f32(const float *d_X, int64_t ldx, const float *d_v, int64_t n_rows, int32_t n_feat, float *d_Y,
+                      int64_t ldy, void *stream);
+int gnnx_bias_add_f32(const float *d_X, int64_t ldx, const float *d_b, int64_t n_rows, int32_t n_feat, float *d_Y,
+                      int64_t ldy, void *stream);
+int gnnx_axpy_f32(int64_t n, float a, const float *d_x, float *d_y, void *stream);
+
+/* ------------------------------------------------------------------ halo (multi-GPU) ------------- */
+/* Pack rows for the all-to-all-v send buffer: out[k,:] = X[idx[k],:]; and the reverse for backward:
+ * Y[idx[k],:] += in[k,:] (idx may repeat across calls but NOT within one call => no atomics, deterministic). */
+int gnnx_gather_rows_f32(const float *d_X, int64_t ldx, const int32_t *d_idx, int64_t n_idx, int32_t n_feat,
+                         float *d_out, int64_t ldo, void *stream);
+int gnnx_scatter_add_rows_f32(const float *d_in, int64_t ldi, const int32_t *d_idx, int64_t n_idx, int32_t n_feat,
+                              float *d_Y, int64_t ldy, void *stream);
+
+/* ------------------------------------------------------------------ synthetic inputs ------------- */
+/* Counter-based SplitMix64 generators, bit-identical to gnn.cpp_amd/synth.py. */
+int gnnx_rmat_edges(uint64_t seed, int32_t n_nodes, int64_t n_edges, int64_t first_edge, double a, double b,
+                    double c, int32_t *d_src, int32_t *d_dst, void *stream);
+int gnnx_uniform_pm1_f32(uint64_t seed, int64_t n, float scale, float *d_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNX_H */

@@ -1,0 +1,91 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a GPU and
+exports every symbol include/gnnx.h declares; argument validation that needs no device works."""
+import ctypes as C
+import importlib
+import re
+import subprocess
+
+import pytest
+
+from tests.helpers import ROOT, pkg  # noqa: F401
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import __graft_entry__ as ge
+    ge.build()
+    return importlib.import_module("gnncpp_amd.capi")
+
+
+def test_library_exports_every_declared_symbol(capi):
+    L = capi.lib()
+    names = capi.declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(L, n), f"libgnnx_hip.so does not export {n}"
+    # and the ctypes table covers every compute entry point of the header
+    for n in names:
+        if n in ("gnnx_version", "gnnx_status_string", "gnnx_last_error"):
+            continue
+        assert n in capi._SIGS, f"capi.py has no signature for {n}"
+
+
+def test_only_c_types_in_the_header():
+    text = open(capi_header()).read()
+    assert 'extern "C"' in text
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)  # declarations only, comments stripped
+    assert "torch" not in code and "std::" not in code and "at::" not in code and "Tensor" not in code
+
+
+def capi_header():
+    import os
+    return os.path.join(ROOT, "include", "gnnx.h")
+
+
+def test_header_cites_reference_lines():
+    text = open(capi_header()).read()
+    cites = re.findall(r"(graph\.cpp|functional\.h|operation\.h|nn\.cpp|tensor\.h|utils\.h):\d+", text)
+    assert len(cites) >= 20
+
+
+def test_version_and_status_strings(capi):
+    L = capi.lib()
+    assert L.gnnx_version() == 100
+    assert L.gnnx_status_string(0) == b"ok"
+    assert b"range" in L.gnnx_status_string(-3)
+
+
+def test_argument_validation_without_device(capi):
+    """Validation happens before any HIP call, so these return statuses even with no GPU."""
+    L = capi.lib()
+    assert L.gnnx_spmm_csr_f32(-1, 0, 0, None, None, None, None, None, None, None, 0, 0.0, None, 0, None, None) == -1
+    assert L.gnnx_spmm_csr_f32(4, 4, 8, None, None, None, None, None, None, None, 8, 0.0, None, 8, None, None) == -1
+    assert b"null" in L.gnnx_last_error()
+    assert L.gnnx_gemm_f32(0, 1, 4, 4, 4, 1.0, None, 4, None, 4, 0.0, None, 4, None, 0, None) == -1
+    b = C.c_size_t(123)
+    assert L.gnnx_gemm_workspace(0, 1, 1000, 128, 128, C.byref(b)) == 0 and b.value == 0
+    assert L.gnnx_gemm_workspace(1, 0, 256, 256, 10_000_000, C.byref(b)) == 0 and b.value > 0
+    assert L.gnnx_colsum_workspace(1000, 16, C.byref(b)) == 0 and b.value >= 16 * 4
+    assert L.gnnx_rmat_edges(1, 0, 10, 0, 0.57, 0.19, 0.19, None, None, None) == -1
+
+
+def test_no_gpu_means_loud_failure(capi):
+    """The product path has no CPU fallback: without a device, calls fail with an error status."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    assert capi.device_count() == 0
+    p = C.c_void_p()
+    st = capi.lib().gnnx_malloc(C.byref(p), 1024)
+    assert st != 0
+    ops = importlib.import_module("gnncpp_amd.ops")
+    with pytest.raises(capi.GnnxError):
+        ops.spmm(torch.zeros(2, dtype=torch.int32), torch.zeros(1, dtype=torch.int32), torch.zeros(1, 4))
+
+
+def test_product_code_never_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    out = subprocess.run(["grep", "-rlE", r"(^|[^_a-zA-Z])oracle", "--include=*.py", "--include=*.hip", "--include=*.h",
+                          "--include=*.cpp", "--include=Makefile", f"{ROOT}/gnn.cpp_amd", f"{ROOT}/include"],
+                         capture_output=True, text=True).stdout.strip()
+    assert out == "", f"product sources mention the oracle: {out}"

@@ -1,0 +1,367 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI
+(include/gnnx.h via gnn.cpp_amd/capi.py), against
+
+  1. the golden vectors produced by the REAL reference (tests/golden/*.npz), and
+  2. the CPU oracle (oracle/gcn_oracle.c, itself pinned bit-exact to the reference) on seeded inputs.
+
+Bars:
+  * integer / index work (CSR build): bit-exact;
+  * aggregation (SpMM fwd/bwd), s, norm: bit-exact (numeric ==) whenever no row is split by a plan -- the
+    kernel adds neighbour rows in the reference's own order with separately rounded fp32 ops;
+  * GEMMs, dbias, split rows: |gpu - ref| <= 1e-5 * max(1, |ref|)  (BASELINE.json north_star tolerance; the
+    MFMA is an fma chain, the reference rounds product and sum separately).
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.golden_util import CASES, load_case, same
+from tests.helpers import synth
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5  # north_star: "within 1e-5 relative fp32"
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: the gpu-marked tests must run on an MI355X")
+    ops = importlib.import_module("gnncpp_amd.ops")
+    capi = importlib.import_module("gnncpp_amd.capi")
+    assert capi.device_count() >= 1
+    return dict(torch=torch, ops=ops, capi=capi, dev=torch.device("cuda:0"))
+
+
+def dev(env, a):
+    return env["torch"].from_numpy(np.ascontiguousarray(a)).to(env["dev"])
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def assert_close(got, ref, what=""):
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64))
+    bound = RTOL * np.maximum(1.0, np.abs(ref.astype(np.float64)))
+    worst = float((err / bound).max()) if err.size else 0.0
+    assert worst <= 1.0, f"{what}: max err/bound = {worst:.3f}"
+
+
+# ------------------------------------------------------------------ golden vectors (real reference)
+@pytest.fixture(scope="module", params=CASES)
+def gcase(request, env):
+    d = load_case(request.param)
+    ops = env["ops"]
+    g = ops.CsrGraph.from_coo(dev(env, d["src"]), dev(env, d["dst"]), d["n"])
+    d["g"] = g
+    return d
+
+
+def test_golden_csr_build_bit_exact(gcase, env):
+    g, ei2 = gcase["g"], gcase["ref_ei2"]
+    rowptr = host(g.rowptr)
+    assert rowptr[0] == 0 and rowptr[-1] == ei2.shape[1] == g.nnz
+    assert np.array_equal(np.repeat(np.arange(gcase["n"], dtype=np.int32), np.diff(rowptr)), ei2[0])
+    assert np.array_equal(host(g.colidx), ei2[1])
+    # transposed CSR == CSR of the swapped edge list (oracle)
+    rp, ci = oracle.coo_to_csr(gcase["dst"], gcase["src"], gcase["n"])
+    assert np.array_equal(host(g.rowptr_t), rp.astype(np.int32)) and np.array_equal(host(g.colidx_t), ci)
+
+
+def test_golden_degree_norm_bit_exact(gcase):
+    assert same(host(gcase["g"].s), gcase["ref_s"])
+    assert same(host(gcase["g"].norm), gcase["ref_norm"])
+
+
+def test_golden_linear_forward(gcase, env):
+    H = env["ops"].linear_fwd(dev(env, gcase["X"]), dev(env, gcase["W"]))
+    assert_close(host(H), gcase["ref_H"], "H = X.W^T")
+
+
+def test_golden_aggregate_forward_bit_exact(gcase, env):
+    """Fed the reference's own H, the SpMM + norm + bias epilogue reproduces the reference bit for bit."""
+    ops, g = env["ops"], gcase["g"]
+    H = dev(env, gcase["ref_H"])
+    agg = ops.aggregate_fwd(g, H, None)
+    out = ops.aggregate_fwd(g, H, dev(env, gcase["bias"]))
+    assert same(host(agg), gcase["ref_agg"])
+    assert same(host(out), gcase["ref_out"])
+    # unfused path (op by op, as the tensor API does it) gives the same bits
+    plain = ops.spmm(g.rowptr, g.colidx, H)
+    un = ops.bias_add(ops.rowscale(plain, g.norm), dev(env, gcase["bias"]))
+    assert same(host(un), gcase["ref_out"])
+
+
+def test_golden_layer_forward_chained(gcase, env):
+    ops = env["ops"]
+    _, out = ops.gcn_layer_fwd(gcase["g"], dev(env, gcase["X"]), dev(env, gcase["W"]), dev(env, gcase["bias"]))
+    assert_close(host(out), gcase["ref_out"], "layer forward")
+
+
+def test_golden_backward(gcase, env):
+    ops = env["ops"]
+    b = ops.gcn_layer_bwd(gcase["g"], dev(env, gcase["X"]), dev(env, gcase["W"]), dev(env, gcase["G"]))
+    assert_close(host(b["dbias"]), gcase["ref_dbias"], "dbias")
+    assert_close(host(b["dW"]), gcase["ref_dW"], "dW")
+    if "ref_dX" in gcase:
+        assert_close(host(b["dX"]), gcase["ref_dX"], "dX")
+    else:
+        assert_close(host(b["dX"])[gcase["ref_dX_rows"]], gcase["ref_dX_sample"], "dX rows")
+    # the aggregation's backward is bit-exact against the oracle (pinned to the reference on dX/dW above)
+    rT, cT = oracle.csr_transpose(*oracle.coo_to_csr(gcase["src"], gcase["dst"], gcase["n"]), gcase["n"])
+    dH_ref = oracle.aggregate_bwd(rT, cT, gcase["G"], gcase["ref_norm"])
+    assert same(host(b["dH"]), dH_ref)
+
+
+# ------------------------------------------------------------------ seeded cases vs the oracle
+def make_graph(env, n, e, seed, kind="rmat"):
+    if kind == "rmat":
+        src, dst = synth.rmat_edges(seed, n, e)
+    else:
+        src, dst = synth.uniform_edges(seed, n, e)
+    rp, ci = oracle.coo_to_csr(src, dst, n)
+    g = env["ops"].CsrGraph.from_coo(dev(env, src), dev(env, dst), n)
+    return src, dst, rp, ci, g
+
+
+@pytest.mark.parametrize("n,e,F", [(20000, 200000, 256), (20000, 200000, 128), (20000, 200000, 100),
+                                   (5000, 60000, 64), (5000, 60000, 16), (3000, 20000, 7), (3000, 20000, 1),
+                                   (2000, 30000, 512), (2000, 30000, 300), (1000, 5000, 33)])
+def test_spmm_forward_backward_bit_exact_vs_oracle(env, n, e, F):
+    ops = env["ops"]
+    src, dst, rp, ci, g = make_graph(env, n, e, seed=7 + F)
+    assert np.array_equal(host(g.rowptr), rp.astype(np.int32)) and np.array_equal(host(g.colidx), ci)
+    s, norm = oracle.degree_norm(rp, ci, n)
+    assert same(host(g.s), s) and same(host(g.norm), norm)
+    H = synth.uniform_pm1(11, (n, F))
+    bias = synth.uniform_pm1(12, (F,))
+    out = ops.aggregate_fwd(g, dev(env, H), dev(env, bias))
+    assert same(host(out), oracle.aggregate_fwd(rp, ci, H, norm, bias))
+    G = synth.uniform_pm1(13, (n, F))
+    rT, cT = oracle.csr_transpose(rp, ci, n)
+    dH = ops.aggregate_bwd(g, dev(env, G))
+    assert same(host(dH), oracle.aggregate_bwd(rT, cT, G, norm))
+
+
+def test_spmm_accumulate_and_strided(env):
+    """beta = 1 (`_grad +=`, tensor.h:268-271) and ld > F (feature blocks inside wider buffers)."""
+    ops, torch = env["ops"], env["torch"]
+    n, F, LD = 4000, 96, 160
+    src, dst, rp, ci, g = make_graph(env, n, 40000, seed=3)
+    H = synth.uniform_pm1(21, (n, F))
+    Y0 = synth.uniform_pm1(22, (n, F))
+    ref = Y0 + oracle.aggregate_fwd(rp, ci, H, g_norm := oracle.degree_norm(rp, ci, n)[1], None)
+    Xw = torch.zeros((n, LD), dtype=torch.float32, device=env["dev"])
+    Xw[:, 32:32 + F] = dev(env, H)
+    Yw = torch.full((n, LD), 7.0, dtype=torch.float32, device=env["dev"])
+    Yw[:, 16:16 + F] = dev(env, Y0)
+    ops.spmm(g.rowptr, g.colidx, Xw[:, 32:32 + F], out=Yw[:, 16:16 + F], rowscale=g.norm, beta=1.0)
+    got = host(Yw)
+    assert same(got[:, 16:16 + F], ref.astype(np.float32))
+    assert np.all(got[:, :16] == 7.0) and np.all(got[:, 16 + F:] == 7.0)  # nothing outside the block is touched
+    del g_norm
+
+
+def test_spmm_split_rows_plan(env):
+    """Power-law rows cut into chunks: deterministic, within tolerance, and bit-exact on unsplit rows."""
+    ops = env["ops"]
+    n, F = 30000, 128
+    src, dst, rp, ci, g = make_graph(env, n, 600000, seed=5)
+    deg = np.diff(rp)
+    assert deg.max() > 2000, "test graph should have hubs"
+    s, norm = oracle.degree_norm(rp, ci, n)
+    H = synth.uniform_pm1(31, (n, F))
+    ref = oracle.aggregate_fwd(rp, ci, H, norm, None)
+    plan, plan_t = g.make_plans(chunk=256, max_feat=F)
+    assert plan.n_split_rows == int((deg > 256).sum()) and plan.n_chunks == int(np.ceil(deg[deg > 256] / 256).sum())
+    out1 = host(ops.aggregate_fwd(g, dev(env, H)))
+    out2 = host(ops.aggregate_fwd(g, dev(env, H)))
+    assert np.array_equal(out1, out2), "split-row combine must be run-to-run deterministic"
+    assert same(out1[deg <= 256], ref[deg <= 256])
+    assert_close(out1, ref, "split rows")
+    G = synth.uniform_pm1(32, (n, F))
+    rT, cT = oracle.csr_transpose(rp, ci, n)
+    dref = oracle.aggregate_bwd(rT, cT, G, norm)
+    dH = host(ops.aggregate_bwd(g, dev(env, G)))
+    degT = np.diff(rT)
+    assert same(dH[degT <= 256], dref[degT <= 256])
+    assert_close(dH, dref, "split rows bwd")
+    # and with the plan disabled the hubs are bit-exact too
+    assert same(host(ops.aggregate_fwd(g, dev(env, H), use_plan=False)), ref)
+
+
+def test_spmm_vals_and_sym_mode(env):
+    """Mode SYM (textbook D^-1/2 A D^-1/2) and per-edge values, vs float64 numpy."""
+    ops = env["ops"]
+    n, F = 3000, 64
+    src, dst, rp, ci, g = make_graph(env, n, 30000, seed=9)
+    H = synth.uniform_pm1(41, (n, F))
+    s = host(g.s)
+    vals = synth.uniform_pm1(42, (len(ci),))
+    got = host(ops.spmm(g.rowptr, g.colidx, dev(env, H), vals=dev(env, vals), colscale=g.s, rowscale=g.s))
+    ref = np.zeros((n, F))
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    np.add.at(ref, rows, (vals.astype(np.float64) * s[ci])[:, None] * H[ci].astype(np.float64))
+    ref *= s[:, None]
+    assert_close(got, ref.astype(np.float32), "SYM + vals")
+
+
+@pytest.mark.parametrize("M,N,K", [(2708, 16, 1433), (2708, 7, 16), (1000, 128, 128), (777, 256, 256),
+                                   (4096, 100, 100), (130, 130, 130), (1, 1, 1), (513, 257, 33)])
+def test_gemm_variants_vs_oracle(env, M, N, K):
+    """All three products of the path on one shape triple: X.W^T, dH.W, dH^T.X."""
+    ops = env["ops"]
+    X = synth.uniform_pm1(51, (M, K))
+    W = synth.uniform_pm1(52, (N, K), scale=1.0 / np.sqrt(K))
+    H = host(ops.linear_fwd(dev(env, X), dev(env, W)))
+    assert_close(H, oracle.linear_fwd(X, W), "X.W^T")
+    dH = synth.uniform_pm1(53, (M, N))
+    dX, dW = ops.linear_bwd(dev(env, dH), dev(env, X), dev(env, W))
+    rdX, rdW = oracle.linear_bwd(dH, X, W)
+    assert_close(host(dX), rdX, "dH.W")
+    assert_close(host(dW), rdW, "dH^T.X")
+
+
+def test_gemm_splitk_long_reduction(env):
+    """dW over many node rows runs split-K + in-order slab reduction: check against float64 and determinism."""
+    ops = env["ops"]
+    n, fo, fi = 200000, 64, 96
+    dH = synth.uniform_pm1(61, (n, fo))
+    X = synth.uniform_pm1(62, (n, fi))
+    a = host(ops.gemm(dev(env, dH), dev(env, X), transA=True))
+    b = host(ops.gemm(dev(env, dH), dev(env, X), transA=True))
+    assert np.array_equal(a, b)
+    ref = dH.astype(np.float64).T @ X.astype(np.float64)
+    # error of an fp32 sum of n terms of magnitude <= 1: bound by 1e-5 * sum|terms| ~ generous vs sqrt(n)*eps
+    assert np.abs(a - ref).max() <= 1e-5 * np.abs(dH).astype(np.float64).T.dot(np.abs(X).astype(np.float64)).max()
+
+
+def test_gemm_beta_accumulate(env):
+    ops = env["ops"]
+    A = synth.uniform_pm1(71, (300, 40))
+    B = synth.uniform_pm1(72, (50, 40))
+    C0 = synth.uniform_pm1(73, (300, 50))
+    out = dev(env, C0.copy())
+    ops.gemm(dev(env, A), dev(env, B), transB=True, out=out, alpha=1.0, beta=1.0)
+    assert_close(host(out), (C0.astype(np.float64) + A.astype(np.float64) @ B.astype(np.float64).T).astype(np.float32))
+
+
+@pytest.mark.parametrize("n,F", [(100000, 256), (50000, 100), (30000, 16), (999, 7), (5, 300)])
+def test_colsum_vs_oracle(env, n, F):
+    G = synth.uniform_pm1(81, (n, F))
+    got = host(env["ops"].colsum(dev(env, G)))
+    ref64 = G.astype(np.float64).sum(0)
+    assert np.abs(got - ref64).max() <= 1e-5 * max(1.0, np.abs(G).astype(np.float64).sum(0).max())
+    if n <= 50000:
+        assert_close(got, oracle.colsum(G), "colsum vs sequential oracle")
+
+
+def test_halo_pack_unpack(env):
+    ops, torch = env["ops"], env["torch"]
+    n, F = 5000, 128
+    X = synth.uniform_pm1(91, (n, F))
+    idx = np.random.default_rng(0).permutation(n)[:1234].astype(np.int32)
+    got = host(ops.gather_rows(dev(env, X), dev(env, idx)))
+    assert np.array_equal(got, X[idx])
+    Y = synth.uniform_pm1(92, (n, F))
+    Yd = dev(env, Y.copy())
+    ops.scatter_add_rows(dev(env, got), dev(env, idx), Yd)
+    ref = Y.copy()
+    ref[idx] += got
+    assert np.array_equal(host(Yd), ref)
+    del torch
+
+
+# ------------------------------------------------------------------ edge cases the domain has
+def test_edge_cases_empty_isolated_and_errors(env):
+    ops, capi, torch = env["ops"], env["capi"], env["torch"]
+    # no edges at all: every row is bias (reference: A = 0 => agg = 0, norm = 0)
+    n, F = 17, 8
+    e0 = torch.empty(0, dtype=torch.int32, device=env["dev"])
+    g = ops.CsrGraph.from_coo(e0, e0, n)
+    assert g.nnz == 0 and host(g.rowptr).tolist() == [0] * (n + 1)
+    assert np.all(host(g.s) == 1.0) and np.all(host(g.norm) == 0.0)
+    bias = synth.uniform_pm1(1, (F,))
+    out = host(ops.aggregate_fwd(g, dev(env, synth.uniform_pm1(2, (n, F))), dev(env, bias)))
+    assert np.array_equal(out, np.tile(bias, (n, 1)))
+    # only self loops + duplicates
+    src = np.array([0, 1, 2, 2, 2, 3, 3], dtype=np.int32)
+    dst = np.array([0, 1, 2, 3, 3, 3, 2], dtype=np.int32)
+    g = ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), 4)
+    assert host(g.rowptr).tolist() == [0, 0, 0, 1, 2] and host(g.colidx).tolist() == [3, 2]
+    # out-of-range endpoint -> the reference's Data ctor message (graph.cpp:89-90)
+    bad = np.array([0, 9], dtype=np.int32)
+    with pytest.raises(capi.GnnxError) as ei:
+        ops.CsrGraph.from_coo(dev(env, bad), dev(env, bad[::-1].copy()), 4)
+    assert ei.value.status == -3 and "max value in edge_index" in str(ei.value)
+    # shape errors surface as statuses, not crashes
+    with pytest.raises(capi.GnnxError):
+        ops.gemm(dev(env, np.zeros((4, 5), np.float32)), dev(env, np.zeros((6, 7), np.float32)))
+    # single node, single feature
+    g1 = ops.CsrGraph.from_coo(e0, e0, 1)
+    assert host(ops.aggregate_fwd(g1, dev(env, np.ones((1, 1), np.float32)))).tolist() == [[0.0]]
+
+
+def test_device_generators_match_numpy(env):
+    ops = env["ops"]
+    s, d = ops.rmat_edges(1, 1_000_000, 300_000)
+    s2, d2 = synth.rmat_edges(1, 1_000_000, 300_000)
+    assert np.array_equal(host(s), s2) and np.array_equal(host(d), d2)
+    s, d = ops.rmat_edges(3, 777, 10_000, a=0.45, b=0.22, c=0.22, first_edge=123)
+    s2, d2 = synth.rmat_edges(3, 777, 10_000, a=0.45, b=0.22, c=0.22, first_edge=123)
+    assert np.array_equal(host(s), s2) and np.array_equal(host(d), d2)
+    u = ops.uniform_pm1(5, (1000, 33), scale=0.125)
+    assert np.array_equal(host(u), synth.uniform_pm1(5, (1000, 33), scale=0.125))
+
+
+# ------------------------------------------------------------------ full-size, size-independent properties
+def test_full_size_properties_rmat_1m_10m(env):
+    """BASELINE configs[2] (RMAT 1M nodes / 10M edges, F = 128): too big for the O(E F) CPU oracle to be
+    quick on every feature, so check (a) the CSR against its own invariants, (b) the aggregation by a
+    checksum of checksums: 1^T (A.H) == indeg^T . H in float64, (c) linearity, (d) sampled rows exactly
+    against the oracle's arithmetic, (e) <A.H, G> == <H, A^T.G> (forward/backward adjointness)."""
+    ops, torch = env["ops"], env["torch"]
+    n, e, F = 1_000_000, 10_000_000, 128
+    src, dst = ops.rmat_edges(1, n, e)
+    g = ops.CsrGraph.from_coo(src, dst, n)
+    g.make_plans(chunk=1024, max_feat=F)
+    rp, ci = host(g.rowptr).astype(np.int64), host(g.colidx)
+    assert rp[0] == 0 and rp[-1] == g.nnz and np.all(np.diff(rp) >= 0)
+    rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+    key = rows * n + ci
+    assert np.all(np.diff(key) > 0), "CSR must be strictly sorted by (row, col): dedupe + order"
+    assert not np.any(rows == ci), "self loops must be stripped"
+    H = ops.uniform_pm1(2, (n, F))
+    Y = ops.spmm(g.rowptr, g.colidx, H, plan=g.plan)
+    indeg = torch.from_numpy(np.bincount(ci, minlength=n).astype(np.float64)).to(env["dev"])
+    lhs = Y.double().sum(0)
+    rhs = indeg @ H.double()
+    scale = (indeg @ H.double().abs()).clamp_min(1.0)
+    assert float(((lhs - rhs).abs() / scale).max()) < 1e-6
+    # sampled rows, exact (rows below the plan's chunk keep the reference order)
+    Hh = host(H)
+    Yh = host(Y)
+    deg = np.diff(rp)
+    rng = np.random.default_rng(1)
+    for r in list(rng.integers(0, n, 200)) + [int(np.argmax(deg))]:
+        acc = np.zeros(F, dtype=np.float32)
+        for p in range(rp[r + 1] - 1, rp[r] - 1, -1):
+            acc = acc + Hh[ci[p]]
+        if deg[r] <= 1024:
+            assert np.array_equal(Yh[r], acc)
+        else:
+            assert np.abs(Yh[r] - acc).max() <= 1e-5 * max(1.0, np.abs(acc).max())
+    # linearity and adjointness
+    H2 = ops.uniform_pm1(3, (n, F))
+    Y2 = ops.spmm(g.rowptr, g.colidx, H2, plan=g.plan)
+    Y12 = ops.spmm(g.rowptr, g.colidx, H + H2, plan=g.plan)
+    assert float((Y12 - (Y + Y2)).abs().max()) <= 1e-5 * float(Y12.abs().max())
+    G = ops.uniform_pm1(4, (n, F))
+    dH = ops.spmm(g.rowptr_t, g.colidx_t, G, plan=g.plan_t)
+    a = float((Y.double() * G.double()).sum())
+    b = float((H.double() * dH.double()).sum())
+    assert abs(a - b) <= 1e-9 * max(abs(a), abs(b), 1.0) * 1e3
