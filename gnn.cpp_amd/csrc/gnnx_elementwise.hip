@@ -3,6 +3,9 @@
 // allows, grid capped at 2048 workgroups with a grid-stride loop.
 #include "gnnx_common.h"
 
+// Parity depends on separately rounded fp32 mul / add (the reference has no FMA): never contract.
+#pragma clang fp contract(off)
+
 using namespace gnnx;
 
 namespace {

@@ -16,6 +16,9 @@
 
 #include "gnnx_common.h"
 
+// Parity depends on separately rounded fp32 mul / add (the reference has no FMA): never contract.
+#pragma clang fp contract(off)
+
 using namespace gnnx;
 
 namespace {

@@ -19,6 +19,9 @@
 //     (deterministic; no float atomics).  Chunk items are placed first in the grid.
 #include "gnnx_common.h"
 
+// Parity depends on separately rounded fp32 mul / add (the reference has no FMA): never contract.
+#pragma clang fp contract(off)
+
 using namespace gnnx;
 
 struct gnnx_spmm_plan {
