@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- GCN-layer edges/sec + achieved HBM GB/s vs roofline on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload NAME]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the synthetic graph: one GCN layer forward
+(H = X.W^T ; Out = norm (.) (A.H) + bias) and its backward (dbias, dH = A^T.(norm (.) G), dX = dH.W,
+dW = dH^T.X) -- SURVEY.md section 8 rows a1-a11.  Graph build (COO->CSR, transpose, norm, plans, halo plan)
+is outside the timed region and reported separately.  value = nnz (edges after dedupe / self-loop strip,
+what the reference semantics sum over) / time per step, whole job.
+
+Workload at N = 1: BASELINE configs[3], the one the metric's target is quoted on (RMAT 10M nodes / 100M
+edges, 256 features); it fits one GPU (~60 GB).  At N > 1 the same graph is sharded by 1-D vertex partition
+with a halo exchange per aggregation (RCCL all-to-all-v) => "scaling": "strong".
+
+Besides the contract fields the JSON line carries
+  roofline     for the dominant kernel (forward SpMM): algorithmic bytes B_gather / HIP-event time
+  cpu_baseline the CPU oracle (the port of the reference arithmetic) timed on this box's host cores on a
+               bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from __graft_entry__ import load_package  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling 6290 GB/s
+
+WORKLOADS = {
+    # name: (n_nodes, n_edges, F, rmat (a,b,c), seed)
+    "rmat10m_100m_f256": (10_000_000, 100_000_000, 256, (0.57, 0.19, 0.19), 2),   # BASELINE configs[3]
+    "rmat1m_10m_f128": (1_000_000, 10_000_000, 128, (0.57, 0.19, 0.19), 1),       # BASELINE configs[2]
+    "products_2p4m_62m_f100": (2_400_000, 62_000_000, 100, (0.45, 0.22, 0.22), 3),  # BASELINE configs[4]
+    "cora_2708_10556": (2708, 10556, 16, None, 42),                                # BASELINE configs[1] (layer 2 width)
+    "tiny": (20_000, 200_000, 64, (0.57, 0.19, 0.19), 5),
+}
+
+
+def spmm_bytes(n_rows, n_cols_rows_written, nnz, F, bias=True):
+    """Algorithmic bytes of one SpMM launch, Mode REF: rowptr + colidx + one neighbour
+    row per edge + rowscale + Y write (+ bias)."""
+    return 4 * (n_rows + 1) + 4 * nnz + 4 * F * nnz + 4 * n_rows + 4 * F * n_cols_rows_written + (4 * F if bias else 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="rmat10m_100m_f256", choices=sorted(WORKLOADS))
+    ap.add_argument("--chunk", type=int, default=1024, help="plan: split rows longer than this (0 = never)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-nodes", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    pkg = load_package()
+    ops = importlib.import_module("gnncpp_amd.ops")
+    capi = importlib.import_module("gnncpp_amd.capi")
+
+    n, e, F, abc, seed = WORKLOADS[args.workload]
+    t_build0 = time.time()
+    if world == 1:
+        runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk)
+    else:
+        shard = importlib.import_module("gnncpp_amd.shard")
+        runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk)
+    torch.cuda.synchronize()
+    t_build = time.time() - t_build0
+
+    for _ in range(args.warmup):
+        runner.step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step(timed=True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    nnz_total = runner.nnz_total
+    roof = runner.roofline()
+    if dist:  # slowest rank's forward SpMM defines the job's roofline line
+        t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        roof["achieved"] = float(t.item())
+        roof["frac"] = roof["achieved"] / roof["peak"]
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(pkg, args, F, abc, seed)
+
+    if rank == 0:
+        line = {
+            "metric": "GCN-layer edges/sec (fwd+bwd: X.W^T + normalized-adjacency SpMM + their gradients)",
+            "value": nnz_total / (ms_per_step * 1e-3),
+            "unit": "edges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": nnz_total,
+                       "features": F, "layer": f"{F}->{F}", "step": "layer fwd+bwd",
+                       "parallelism": "single" if world == 1 else f"1-D vertex shard x{world}, halo all-to-all-v",
+                       "plan_chunk": args.chunk},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels_ms": runner.kernel_times(),
+            "build_s": t_build,
+            "device": torch.cuda.get_device_name(local_rank),
+        }
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+class SingleGpu:
+    """Whole graph on one MI355X.  All buffers are allocated here, outside the timed region."""
+
+    def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk):
+        self.ops, self.capi, self.F, self.n = ops, capi, F, n
+        if abc is None:
+            s, d = pkg.synth.uniform_edges(seed, n, e)
+            src, dst = torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)
+        else:
+            src, dst = ops.rmat_edges(seed, n, e, *abc, device=dev)
+        self.g = g = ops.CsrGraph.from_coo(src, dst, n)
+        del src, dst
+        ops._ws_cache.clear()
+        torch.cuda.empty_cache()
+        if chunk > 0:
+            g.make_plans(chunk, F)
+        self.nnz_total = g.nnz
+        self.X = ops.uniform_pm1(seed + 10, (n, F), device=dev)
+        self.W = ops.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5, device=dev)
+        self.bias = torch.zeros(F, dtype=torch.float32, device=dev)  # graph.cpp:167
+        self.G = ops.uniform_pm1(seed + 12, (n, F), device=dev)
+        self.H = torch.empty((n, F), dtype=torch.float32, device=dev)
+        self.out = torch.empty((n, F), dtype=torch.float32, device=dev)
+        self.dH = torch.empty((n, F), dtype=torch.float32, device=dev)
+        self.dX = torch.empty((n, F), dtype=torch.float32, device=dev)
+        self.dW = torch.empty((F, F), dtype=torch.float32, device=dev)
+        self.dbias = torch.empty(F, dtype=torch.float32, device=dev)
+        self.names = ["gemm_xwT", "spmm_fwd", "colsum", "spmm_bwd", "gemm_dX", "gemm_dW"]
+        self.ev = []  # per timed step: list of (start, stop) HIP events on the launch stream
+
+    def step(self, timed=False):
+        ops, g = self.ops, self.g
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        evs = []
+
+        def run(fn):
+            if timed:
+                a, b = self.capi.Event(), self.capi.Event()
+                a.record(stream)
+                fn()
+                b.record(stream)
+                evs.append((a, b))
+            else:
+                fn()
+
+        run(lambda: ops.linear_fwd(self.X, self.W, out=self.H))
+        run(lambda: ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
+        run(lambda: ops.colsum(self.G, out=self.dbias))
+        run(lambda: ops.aggregate_bwd(g, self.G, out=self.dH))
+        run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
+        run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+        if timed:
+            self.ev.append(evs)
+
+    def kernel_times(self):
+        out = {}
+        for i, nm in enumerate(self.names):
+            out[nm] = float(np.mean([s[i][0].elapsed_ms(s[i][1]) for s in self.ev])) if self.ev else None
+        return out
+
+    def roofline(self):
+        ms = self.kernel_times()["spmm_fwd"]
+        B = spmm_bytes(self.n, self.n, self.g.nnz, self.F, bias=True)
+        achieved = B / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "spmm_kernel<64,4,8,0> (forward aggregation)", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": B, "bytes_per_edge": B / max(1, self.g.nnz), "avg_launch_ms": ms,
+                "frac_of_measured_copy_ceiling_6290": achieved / 6290.0}
+
+
+def cpu_baseline(pkg, args, F, abc, seed):
+    """The CPU oracle (port of the reference arithmetic, OpenMP over rows) on a bounded sample of the same
+    workload: same generator, same average degree and feature width, fewer nodes."""
+    import oracle  # checker / reported baseline only
+    wl_n, wl_e = WORKLOADS[args.workload][:2]
+    n = min(args.cpu_sample_nodes, wl_n)
+    e = int(round(wl_e * (n / wl_n)))
+    if abc is None:
+        src, dst = pkg.synth.uniform_edges(seed, n, e)
+    else:
+        src, dst = pkg.synth.rmat_edges(seed, n, e, *abc)
+    rng = np.random.default_rng(seed)  # same distribution as the device inputs (U[-1,1)), cheaper to draw
+    X = rng.random((n, F), dtype=np.float32) * 2 - 1
+    W = pkg.synth.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5)
+    bias = np.zeros(F, dtype=np.float32)
+    G = rng.random((n, F), dtype=np.float32) * 2 - 1
+    rp, ci = oracle.coo_to_csr(src, dst, n)
+    rT, cT = oracle.csr_transpose(rp, ci, n)
+    s, norm = oracle.degree_norm(rp, ci, n)
+    cores = oracle.max_threads()
+    t0 = time.perf_counter()
+    H = oracle.linear_fwd(X, W)
+    oracle.aggregate_fwd(rp, ci, H, norm, bias)
+    oracle.colsum(G)
+    dH = oracle.aggregate_bwd(rT, cT, G, norm)
+    oracle.linear_bwd(dH, X, W)
+    dt = time.perf_counter() - t0
+    return {"value": len(ci) / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{args.workload} scaled to {n} nodes / {e} generated edges (nnz {len(ci)}), {F} features, "
+                      f"one layer fwd+bwd in {dt:.2f} s, OpenMP over rows on {cores} threads",
+            "seconds": dt}
+
+
+if __name__ == "__main__":
+    main()

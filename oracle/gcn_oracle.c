@@ -115,22 +115,32 @@ API void gcn_oracle_degree_norm(const int64_t *rowptr, const int32_t *colidx, in
     }
 }
 
-/* nn.cpp:205-211 via functional.h:433-439:  H[i,o] = sum_{k desc} fl(X[i,k] * W[o,k]). */
+/* nn.cpp:205-211 via functional.h:433-439:  H[i,o] = sum_{k desc} fl(X[i,k] * W[o,k]).
+ * Loop nest: k outermost-descending per row with W pre-transposed, so the inner loop runs over o contiguously
+ * (vectorisable) while every output element still sees its products in the reference's order. */
 API void gcn_oracle_linear_fwd(const float *X, const float *W, int64_t N, int32_t Fin, int32_t Fout, float *H)
 {
+    float *Wt = (float *)malloc(sizeof(float) * (size_t)(Fin > 0 ? Fin : 1) * (size_t)(Fout > 0 ? Fout : 1));
+    for (int32_t o = 0; o < Fout; o++)
+        for (int32_t k = 0; k < Fin; k++) Wt[(int64_t)k * Fout + o] = W[(int64_t)o * Fin + k];
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; i++) {
         const float *x = X + i * Fin;
-        for (int32_t o = 0; o < Fout; o++) {
-            const float *w = W + (int64_t)o * Fin;
-            float acc = 0.0f;
-            if (Fin > 0) {
-                acc = x[Fin - 1] * w[Fin - 1];
-                for (int32_t k = Fin - 2; k >= 0; k--) acc += x[k] * w[k];
-            }
-            H[i * Fout + o] = acc;
+        float *h = H + i * Fout;
+        if (Fin == 0) {
+            for (int32_t o = 0; o < Fout; o++) h[o] = 0.0f;
+            continue;
+        }
+        const float *w = Wt + (int64_t)(Fin - 1) * Fout;
+        float xv = x[Fin - 1];
+        for (int32_t o = 0; o < Fout; o++) h[o] = xv * w[o];
+        for (int32_t k = Fin - 2; k >= 0; k--) {
+            w = Wt + (int64_t)k * Fout;
+            xv = x[k];
+            for (int32_t o = 0; o < Fout; o++) h[o] += xv * w[o];
         }
     }
+    free(Wt);
 }
 
 /* graph.cpp:208-209 (+ graph.cpp:188 when bias != NULL):
@@ -188,40 +198,59 @@ API void gcn_oracle_colsum(const float *G, int64_t N, int32_t F, float *out)
 {
     for (int32_t f = 0; f < F; f++) out[f] = 0.0f;
     if (N == 0) return;
-    for (int32_t f = 0; f < F; f++) out[f] = G[f];
-    for (int64_t i = 1; i < N; i++)
-        for (int32_t f = 0; f < F; f++) out[f] += G[i * F + f];
+#pragma omp parallel for schedule(static)
+    for (int32_t f0 = 0; f0 < F; f0 += 16) {
+        int32_t f1 = f0 + 16 < F ? f0 + 16 : F;
+        for (int32_t f = f0; f < f1; f++) out[f] = G[f];
+        for (int64_t i = 1; i < N; i++)
+            for (int32_t f = f0; f < f1; f++) out[f] += G[i * F + f];
+    }
 }
 
 /* Backward of the transform (operation.h:516-531, :416-433):
  *   dX[i,k] = sum_{o desc} fl(dH[i,o] * W[o,k])          (G . (W^T)^T)
- *   dW[o,k] = sum_{i desc} fl(X[i,k] * dH[i,o])          (x^T . G, then transposed back) */
+ *   dW[o,k] = sum_{i desc} fl(X[i,k] * dH[i,o])          (x^T . G, then transposed back)
+ * Loop nests keep the reduction index outermost (descending) and a contiguous inner loop; the per-element
+ * order of additions is the reference's. */
 API void gcn_oracle_linear_bwd(const float *dH, const float *X, const float *W, int64_t N, int32_t Fin,
                                int32_t Fout, float *dX, float *dW)
 {
     if (dX) {
 #pragma omp parallel for schedule(static)
-        for (int64_t i = 0; i < N; i++)
-            for (int32_t k = 0; k < Fin; k++) {
-                float acc = 0.0f;
-                if (Fout > 0) {
-                    acc = dH[i * Fout + Fout - 1] * W[(int64_t)(Fout - 1) * Fin + k];
-                    for (int32_t o = Fout - 2; o >= 0; o--) acc += dH[i * Fout + o] * W[(int64_t)o * Fin + k];
-                }
-                dX[i * Fin + k] = acc;
+        for (int64_t i = 0; i < N; i++) {
+            float *d = dX + i * Fin;
+            const float *g = dH + i * Fout;
+            if (Fout == 0) {
+                for (int32_t k = 0; k < Fin; k++) d[k] = 0.0f;
+                continue;
             }
+            const float *w = W + (int64_t)(Fout - 1) * Fin;
+            float gv = g[Fout - 1];
+            for (int32_t k = 0; k < Fin; k++) d[k] = gv * w[k];
+            for (int32_t o = Fout - 2; o >= 0; o--) {
+                w = W + (int64_t)o * Fin;
+                gv = g[o];
+                for (int32_t k = 0; k < Fin; k++) d[k] += gv * w[k];
+            }
+        }
     }
     if (dW) {
 #pragma omp parallel for schedule(static)
-        for (int32_t o = 0; o < Fout; o++)
-            for (int32_t k = 0; k < Fin; k++) {
-                float acc = 0.0f;
-                if (N > 0) {
-                    acc = X[(N - 1) * Fin + k] * dH[(N - 1) * Fout + o];
-                    for (int64_t i = N - 2; i >= 0; i--) acc += X[i * Fin + k] * dH[i * Fout + o];
-                }
-                dW[(int64_t)o * Fin + k] = acc;
+        for (int32_t o = 0; o < Fout; o++) {
+            float *d = dW + (int64_t)o * Fin;
+            if (N == 0) {
+                for (int32_t k = 0; k < Fin; k++) d[k] = 0.0f;
+                continue;
             }
+            float gv = dH[(N - 1) * Fout + o];
+            const float *x = X + (N - 1) * Fin;
+            for (int32_t k = 0; k < Fin; k++) d[k] = x[k] * gv;
+            for (int64_t i = N - 2; i >= 0; i--) {
+                gv = dH[i * Fout + o];
+                x = X + i * Fin;
+                for (int32_t k = 0; k < Fin; k++) d[k] += x[k] * gv;
+            }
+        }
     }
 }
 
