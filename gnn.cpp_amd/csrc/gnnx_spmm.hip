@@ -17,6 +17,11 @@
 //   * power-law rows: an optional plan cuts rows longer than `chunk` into chunks that are gathered by
 //     separate wavefronts into a partial slab and combined in fixed chunk order by a second tiny kernel
 //     (deterministic; no float atomics).  Chunk items are placed first in the grid.
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
 #include "gnnx_common.h"
 
 // Parity depends on separately rounded fp32 mul / add (the reference has no FMA): never contract.
@@ -34,6 +39,10 @@ struct gnnx_spmm_plan {
     int4 *d_rows = nullptr;     // [n_split_rows] {row, first slot, n_chunks, 0}
     float *d_partial = nullptr; // [n_chunks, max_feat]
     int32_t *d_counters = nullptr;
+    // non-zero-balanced row blocks for the streaming kernel: block k owns rows [d_block_starts[k], [k+1])
+    int32_t block_nnz = 0;
+    int32_t n_blocks = 0;
+    int32_t *d_block_starts = nullptr;
 };
 
 namespace {
@@ -58,6 +67,9 @@ struct SpmmArgs {
     int32_t n_items;
     float *partial;
     int32_t partial_ld;
+    // row blocks of the streaming kernel (plan): nullptr => fixed blocks of StreamCfg<G>::R rows
+    const int32_t *block_starts;
+    int32_t n_blocks;
 };
 
 template <int VEC> struct Vec;
@@ -203,6 +215,203 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_bl
     if (active) epilogue_store<VEC>(acc, row, f0, a);
 }
 
+// ---- streaming kernel (the hot one at F > 64) -------------------------------------------------------------
+// One G-lane group owns a BLOCK of R consecutive rows and streams the block's whole non-zero range
+// [rowptr[r0], rowptr[r0+R)) from the top down (so inside every row the columns come in DESCENDING order,
+// the reference's order), B neighbour rows per batch, double-buffered: batch j+1 is in flight from HBM
+// while batch j is added.  Row boundaries are crossed inside the stream (store the finished row, clear the
+// accumulator, go on), so short rows -- most rows of a power-law graph -- cost no pipeline drain, no extra
+// wavefront launch and no dependent rowptr -> colidx -> feature latency chain of their own.
+//   * rowptr of the block: one coalesced load, kept one entry per lane, read back with bcast();
+//   * colidx (+ colscale / vals): one coalesced load per G non-zeros, the next chunk prefetched;
+//   * no load is predicated (see gather_batch): the last batch of a block re-reads an in-range row;
+//   * rows longer than the plan's threshold are skipped here (chunk items + combine kernel own them): the
+//     block is cut into segments of consecutive non-hub rows with a ballot mask.
+// At G == 64 every control decision is wave-uniform (SALU + s_cbranch); at G == 32 the two half-waves
+// stream independent blocks under the EXEC mask.
+template <int G> struct StreamCfg { static constexpr int R = G / 2; };
+
+template <int G, int VEC, int B, int MODE>
+struct Stream {
+    using V = typename Vec<VEC>::type;
+    const SpmmArgs &a;
+    const float *xf;
+    int li, gbase, f0;
+    bool active;
+    int32_t r0;      // first row of the block
+    int32_t rp_l;    // lane l holds rowptr[r0 + min(l, nr)]
+
+    __device__ __forceinline__ int32_t rp(int l) const { return bcast<G>(rp_l, l, gbase); }
+
+    __device__ __forceinline__ void flush(V &acc, int r) const
+    {
+        if (active) epilogue_store<VEC>(acc, r0 + r, f0, a);
+        zero(acc);
+    }
+
+    struct Chunk { int32_t c; float sc; float val; };  // per lane: one non-zero of the current G-chunk
+
+    __device__ __forceinline__ Chunk fetch_chunk(int32_t hi, int32_t lo, int cidx) const
+    {
+        int32_t q = hi - 1 - (cidx * G + li);
+        q = q < lo ? lo : q;  // clamped: still a valid non-zero of this segment
+        Chunk ch;
+        ch.c = a.colidx[q];
+        ch.sc = 1.f;
+        ch.val = 1.f;
+        if constexpr (MODE == 1) ch.sc = a.colscale[ch.c];
+        if constexpr (MODE == 2) {
+            if (a.colscale) ch.sc = a.colscale[ch.c];
+            if (a.vals) ch.val = a.vals[q];
+        }
+        return ch;
+    }
+
+    struct Batch { V v[B]; float sc[B]; float val[B]; };
+
+    __device__ __forceinline__ void issue(Batch &b, const Chunk &ch, int k0) const
+    {
+        int32_t c[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) c[u] = bcast<G>(ch.c, k0 + u, gbase);
+#pragma unroll
+        for (int u = 0; u < B; u++) b.v[u] = ld_vec(reinterpret_cast<const V *>(xf + (int64_t)c[u] * a.ldx));
+        if constexpr (MODE >= 1) {
+#pragma unroll
+            for (int u = 0; u < B; u++) b.sc[u] = __int_as_float(bcast<G>(__float_as_int(ch.sc), k0 + u, gbase));
+        }
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int u = 0; u < B; u++) b.val[u] = __int_as_float(bcast<G>(__float_as_int(ch.val), k0 + u, gbase));
+        }
+    }
+
+    // add entries e .. e+B-1 of the stream (entry e is non-zero hi-1-e), crossing row boundaries as they come
+    __device__ __forceinline__ void consume(const Batch &b, int32_t e, int32_t total, int32_t hi, V &acc, int &r,
+                                            int32_t &rs) const
+    {
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            if (e + u < total) {
+                const int32_t q = hi - 1 - (e + u);
+                while (q < rs) {  // every non-zero of row r (and of the empty rows above q) is in: store them
+                    flush(acc, r);
+                    r--;
+                    rs = rp(r);
+                }
+                V t = b.v[u];
+                if constexpr (MODE >= 1) t = mul_rn(t, b.sc[u]);
+                if constexpr (MODE == 2) t = mul_rn(t, b.val[u]);
+                acc = add_rn(acc, t);
+            }
+        }
+    }
+
+    // rows [sa, sb) of the block (local indices), none of them a hub
+    __device__ __forceinline__ void segment(int sa, int sb) const
+    {
+        const int32_t lo = rp(sa), hi = rp(sb);
+        const int32_t total = hi - lo;
+        int r = sb - 1;
+        int32_t rs = rp(r);
+        V acc;
+        zero(acc);
+        if (total > 0) {
+            Chunk cur = fetch_chunk(hi, lo, 0);
+            Chunk nxt = fetch_chunk(hi, lo, 1);
+            int cidx = 1;
+            Batch ba, bb;
+            issue(ba, cur, 0);
+            int32_t e = 0;
+            while (true) {
+                {   // batch e is in ba; put batch e+B in flight into bb, then add ba
+                    const int kn = (e + B) % G;
+                    if (kn == 0) { cur = nxt; cidx++; nxt = fetch_chunk(hi, lo, cidx); }
+                    issue(bb, cur, kn);
+                    consume(ba, e, total, hi, acc, r, rs);
+                    e += B;
+                    if (e >= total) break;
+                }
+                {
+                    const int kn = (e + B) % G;
+                    if (kn == 0) { cur = nxt; cidx++; nxt = fetch_chunk(hi, lo, cidx); }
+                    issue(ba, cur, kn);
+                    consume(bb, e, total, hi, acc, r, rs);
+                    e += B;
+                    if (e >= total) break;
+                }
+            }
+        }
+        while (r >= sa) {  // the current row and any empty rows below it
+            flush(acc, r);
+            r--;
+        }
+    }
+};
+
+template <int G, int VEC, int B, int MODE, int TPB>
+__global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_item_blocks)
+{
+    constexpr int GROUPS = TPB / G;
+    constexpr int R = StreamCfg<G>::R;
+    const int tid = threadIdx.x;
+    const int li = tid % G;
+    int grp = tid / G;
+    if constexpr (G == 64) grp = __builtin_amdgcn_readfirstlane(grp);
+    const int32_t f0 = (blockIdx.y * G + li) * VEC;
+    const bool active = f0 + VEC <= a.n_feat;
+    const float *xf = a.X + (active ? f0 : 0);
+
+    if ((int32_t)blockIdx.x < n_item_blocks) {  // chunk item of a hub row -> partial slab (same as spmm_kernel)
+        int32_t it = blockIdx.x * GROUPS + grp;
+        if (it >= a.n_items) return;
+        int4 item = a.items[it];
+        if constexpr (G == 64) {
+            item.y = __builtin_amdgcn_readfirstlane(item.y);
+            item.z = __builtin_amdgcn_readfirstlane(item.z);
+            item.w = __builtin_amdgcn_readfirstlane(item.w);
+        }
+        auto acc = gather_range<G, VEC, 8, MODE>(item.y, item.z, xf, li, a);
+        if (active) *reinterpret_cast<typename Vec<VEC>::type *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
+        return;
+    }
+
+    const int32_t blk = (blockIdx.x - n_item_blocks) * GROUPS + grp;
+    int32_t r0, nr;
+    if (a.block_starts) {  // non-zero-balanced blocks of the plan (at most kPlanBlockRows <= R rows each)
+        if (blk >= a.n_blocks) return;
+        r0 = a.block_starts[blk];
+        nr = a.block_starts[blk + 1] - r0;
+        if constexpr (G == 64) {
+            r0 = __builtin_amdgcn_readfirstlane(r0);
+            nr = __builtin_amdgcn_readfirstlane(nr);
+        }
+    } else {
+        const int64_t r0l = (int64_t)blk * R;
+        if (r0l >= a.n_rows) return;
+        r0 = (int32_t)r0l;
+        nr = a.n_rows - r0 < R ? a.n_rows - r0 : R;
+    }
+    const int gbase = (tid & 63) - li;
+    Stream<G, VEC, B, MODE> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)]};
+
+    uint64_t hub = 0;  // bit l: local row l is a hub (left to the chunk items)
+    if (a.split_threshold > 0) {
+        const int32_t nxt = __shfl(st.rp_l, (tid & 63) + 1, 64);  // lane li+1 (li < nr < G: inside the group)
+        const uint64_t m = __ballot(li < nr && nxt - st.rp_l > a.split_threshold);
+        hub = G == 64 ? m : ((m >> gbase) & ((1ull << (G & 63)) - 1));
+    }
+    int sa = 0;
+    while (sa < nr) {
+        const uint64_t rest = hub >> sa;
+        if (rest & 1) { sa++; continue; }
+        int run = rest ? __builtin_ctzll(rest) : 64;
+        int sb = sa + run < nr ? sa + run : nr;
+        st.segment(sa, sb);
+        sa = sb;
+    }
+}
+
 // Combine the partial slabs of split rows in chunk order (chunk 0 holds the HIGHEST columns), then the
 // same epilogue as the main kernel.  One G-lane group per split row.
 template <int G, int VEC>
@@ -255,24 +464,96 @@ __global__ void plan_fill_kernel(const int32_t *rowptr, int32_t n_rows, int32_t 
     }
 }
 
+// GNNX_SPMM_VARIANT=rows forces the one-row-per-group kernel everywhere (A/B measurements); default: the
+// streaming kernel for G >= 32 (F > 64), the row kernel below that (cache-resident widths).
+bool use_stream_kernel(int G)
+{
+    static const int forced = [] {
+        const char *v = getenv("GNNX_SPMM_VARIANT");
+        if (!v) return 0;
+        return strcmp(v, "rows") == 0 ? 1 : (strcmp(v, "stream") == 0 ? 2 : 0);
+    }();
+    if (forced == 1) return false;
+    if (forced == 2) return G >= 8;
+    return G >= 32;
+}
+
+// Row r opens a new block when it starts a new group of kPlanBlockRows rows or when its first non-zero falls
+// into another block_nnz-sized bucket than the previous row's: a block then streams < block_nnz + (its last
+// row's degree) non-zeros, whatever the degree skew, and clustered heavy rows end up in blocks of their own.
+constexpr int kPlanBlockRows = 16;  // <= StreamCfg<G>::R for every G that uses plan blocks (G >= 32)
+
+__global__ void plan_block_flags_kernel(const int32_t *rowptr, int32_t n_rows, int32_t block_nnz, int32_t *flag)
+{
+    int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    bool cut = r % kPlanBlockRows == 0;
+    if (!cut) cut = rowptr[r] / block_nnz != rowptr[r - 1] / block_nnz;
+    flag[r] = cut ? 1 : 0;
+}
+
+__global__ void plan_block_fill_kernel(const int32_t *flag, const int32_t *pos, int32_t n_rows, int32_t n_blocks,
+                                       int32_t *starts)
+{
+    int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r == 0) starts[n_blocks] = n_rows;
+    if (r >= n_rows || !flag[r]) return;
+    starts[pos[r]] = r;
+}
+
 template <int G, int VEC, int U>
-int launch_mode(const SpmmArgs &a, const gnnx_spmm_plan *plan, hipStream_t st)
+int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, hipStream_t st)
 {
     constexpr int GROUPS = 256 / G;
     const int feat_per_tile = G * VEC;
+    SpmmArgs a = a_in;
+    if (G < 2 * kPlanBlockRows) a.block_starts = nullptr;  // plan blocks hold up to kPlanBlockRows rows (< G needed)
     dim3 grid;
     int32_t n_item_blocks = (int32_t)ceil_div(a.n_items, GROUPS);
-    int64_t n_row_blocks = ceil_div(a.n_rows, GROUPS);
-    grid.x = (uint32_t)(n_item_blocks + n_row_blocks);
     grid.y = (uint32_t)ceil_div(a.n_feat, feat_per_tile);
-    if (grid.x == 0) return GNNX_OK;
     const bool general = a.vals != nullptr;
-    if (general)
-        hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 2>), grid, dim3(256), 0, st, a, n_item_blocks);
-    else if (a.colscale)
-        hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 1>), grid, dim3(256), 0, st, a, n_item_blocks);
-    else
-        hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 0>), grid, dim3(256), 0, st, a, n_item_blocks);
+    bool stream = false;
+    if constexpr (G >= 8) stream = use_stream_kernel(G);
+    if (stream) {
+        if constexpr (G >= 8) {
+            constexpr int R = StreamCfg<G>::R;
+            // One wavefront per workgroup: a workgroup's CU slot is held until its slowest wavefront ends, and
+            // blocks of a power-law graph differ a lot in non-zeros, so multi-wave workgroups strand slots.
+            static const int tpb_env = [] { const char *v = getenv("GNNX_SPMM_TPB"); return v ? atoi(v) : 64; }();
+            if (tpb_env == 256) {
+                constexpr int TPB = 256;
+                n_item_blocks = (int32_t)ceil_div(a.n_items, TPB / G);
+                grid.x = (uint32_t)(n_item_blocks + (a.block_starts ? ceil_div(a.n_blocks, TPB / G)
+                                                                    : ceil_div(a.n_rows, (int64_t)(TPB / G) * R)));
+                if (general)
+                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 2, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
+                else if (a.colscale)
+                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 1, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
+                else
+                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 0, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
+            } else {
+                constexpr int TPB = 64;
+                n_item_blocks = (int32_t)ceil_div(a.n_items, TPB / G);
+                grid.x = (uint32_t)(n_item_blocks + (a.block_starts ? ceil_div(a.n_blocks, TPB / G)
+                                                                    : ceil_div(a.n_rows, (int64_t)(TPB / G) * R)));
+                if (general)
+                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 2, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
+                else if (a.colscale)
+                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 1, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
+                else
+                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 0, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
+            }
+        }
+    } else {
+        grid.x = (uint32_t)(n_item_blocks + ceil_div(a.n_rows, GROUPS));
+        if (grid.x == 0) return GNNX_OK;
+        if (general)
+            hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 2>), grid, dim3(256), 0, st, a, n_item_blocks);
+        else if (a.colscale)
+            hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 1>), grid, dim3(256), 0, st, a, n_item_blocks);
+        else
+            hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 0>), grid, dim3(256), 0, st, a, n_item_blocks);
+    }
     GNNX_LAUNCH_CHECK();
     if (plan && plan->n_split_rows > 0) {
         dim3 cgrid((uint32_t)ceil_div(plan->n_split_rows, GROUPS), grid.y);
@@ -315,6 +596,35 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
         GNNX_LAUNCH_CHECK();
         GNNX_HIP_CHECK(hipStreamSynchronize(st));
     }
+    // non-zero-balanced row blocks
+    {
+        static const int env_bn = [] { const char *v = getenv("GNNX_SPMM_BLOCK_NNZ"); return v ? atoi(v) : 0; }();
+        plan->block_nnz = env_bn > 0 ? env_bn : (chunk < 256 ? chunk : 256);
+        int32_t *flag = nullptr, *pos = nullptr;
+        void *tmp = nullptr;
+        size_t tmp_bytes = 0;
+        GNNX_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, (int32_t *)nullptr, (int32_t *)nullptr, 0, (size_t)n_rows,
+                                               rocprim::plus<int32_t>()));
+        GNNX_HIP_CHECK(hipMalloc(&flag, sizeof(int32_t) * (size_t)n_rows));
+        GNNX_HIP_CHECK(hipMalloc(&pos, sizeof(int32_t) * (size_t)n_rows));
+        GNNX_HIP_CHECK(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 4));
+        hipLaunchKernelGGL(plan_block_flags_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, plan->block_nnz, flag);
+        GNNX_LAUNCH_CHECK();
+        GNNX_HIP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, pos, 0, (size_t)n_rows, rocprim::plus<int32_t>(), st));
+        int32_t last[2];
+        GNNX_HIP_CHECK(hipMemcpyAsync(&last[0], pos + (n_rows - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        GNNX_HIP_CHECK(hipMemcpyAsync(&last[1], flag + (n_rows - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));
+        plan->n_blocks = last[0] + last[1];
+        GNNX_HIP_CHECK(hipMalloc(&plan->d_block_starts, sizeof(int32_t) * ((size_t)plan->n_blocks + 1)));
+        hipLaunchKernelGGL(plan_block_fill_kernel, grid, dim3(256), 0, st, flag, pos, n_rows, plan->n_blocks,
+                           plan->d_block_starts);
+        GNNX_LAUNCH_CHECK();
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));
+        (void)hipFree(flag);
+        (void)hipFree(pos);
+        (void)hipFree(tmp);
+    }
     return GNNX_OK;
 }
 
@@ -325,6 +635,7 @@ GNNX_API int gnnx_spmm_plan_destroy(gnnx_spmm_plan *plan)
     if (plan->d_rows) (void)hipFree(plan->d_rows);
     if (plan->d_partial) (void)hipFree(plan->d_partial);
     if (plan->d_counters) (void)hipFree(plan->d_counters);
+    if (plan->d_block_starts) (void)hipFree(plan->d_block_starts);
     delete plan;
     return GNNX_OK;
 }
@@ -367,6 +678,10 @@ GNNX_API int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, c
     a.Y = d_Y;
     a.ldy = ldy;
     a.beta = beta != 0.f;
+    if (plan && plan->d_block_starts) {
+        a.block_starts = plan->d_block_starts;
+        a.n_blocks = plan->n_blocks;
+    }
     if (plan && plan->n_split_rows > 0) {
         a.split_threshold = plan->chunk;
         a.items = plan->d_items;
