@@ -1,0 +1,244 @@
+"""1-D vertex (row) partition of the GCN aggregation over the GPUs of one node + halo exchange.
+
+What shards: rows of A are independent; the only coupling is reading neighbour
+rows of H owned elsewhere.  Rank p owns the contiguous vertex range [cut[p], cut[p+1]) (cuts balance
+out-degree + in-degree), holds
+  * CSR of its rows of A   and CSR of its rows of A^T (built from the edges whose src / dst it owns),
+    columns renumbered to [local rows | halo rows] WITHOUT reordering the entries of a row: the kernel adds
+    neighbours in storage order, which stays the reference's descending-global-column order, so the
+    sharded result is bit-identical to the single-GPU one;
+  * halo lists: the sorted global ids of remote columns it reads (forward: out-neighbours, backward:
+    in-neighbours), grouped by owner because ranges are contiguous;
+  * send lists: for every peer, which of its own rows that peer reads (exchanged once, at plan time).
+Per aggregation there is ONE exchange step: pack rows by send list (gnnx_gather_rows_f32) -> all-to-all-v
+(torch.distributed all_to_all_single with split sizes = grouped ncclSend/ncclRecv on RCCL; every pair of
+GPUs has its own xGMI link) straight into the [halo] tail of the feature buffer -> local SpMM over
+[local | halo].  Backward pulls too (rows of G for in-neighbours through the transposed CSR): no
+scatter-add, no atomics, deterministic.  dW / dbias are summed with a small all-reduce.
+
+This module is host-side index logic (torch tensor ops, device-agnostic so that the gloo/CPU tests drive
+exactly this code) plus the exchange; all arithmetic goes through the C-ABI (ops.py).
+"""
+import torch
+
+
+def balanced_cuts(weight, world):
+    """Cut points [world+1] of contiguous ranges with ~equal total weight (weight: int64 per vertex)."""
+    n = int(weight.numel())
+    csum = torch.cumsum(weight.to(torch.int64), 0)
+    total = int(csum[-1].item()) if n else 0
+    targets = torch.tensor([total * (p + 1) // world for p in range(world - 1)], dtype=torch.int64, device=weight.device)
+    inner = torch.searchsorted(csum, targets, right=False) + 1 if n else targets
+    cuts = [0] + [min(n, int(c)) for c in inner.tolist()] + [n]
+    for i in range(1, len(cuts)):  # monotone
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts
+
+
+class HaloSide:
+    """One direction of the exchange (forward: columns of A; backward: columns of A^T)."""
+
+    def __init__(self, rowptr, colidx_global, lo, hi, cuts):
+        dev = colidx_global.device
+        self.n_local = hi - lo
+        self.rowptr = rowptr
+        remote = (colidx_global < lo) | (colidx_global >= hi)
+        halo = torch.unique(colidx_global[remote])  # sorted ascending => grouped by owner
+        self.halo = halo
+        self.n_halo = int(halo.numel())
+        col = colidx_global.to(torch.int64)
+        local_id = col - lo
+        halo_id = torch.searchsorted(halo.to(torch.int64), col) + self.n_local
+        self.colidx = torch.where(remote, halo_id, local_id).to(torch.int32)  # entry order untouched
+        bounds = torch.tensor(cuts, dtype=halo.dtype, device=dev)
+        pos = torch.searchsorted(halo, bounds)  # halo[pos[q]:pos[q+1]] is owned by rank q
+        self.recv_counts = (pos[1:] - pos[:-1]).tolist()
+        self.send_counts = None
+        self.send_idx = None  # local row ids to pack, peer-major
+
+    def exchange_requests(self, dist, cuts, rank, world):
+        """Tell every owner which of its rows this rank reads; learn which of mine the peers read."""
+        dev = self.halo.device
+        rc = torch.tensor(self.recv_counts, dtype=torch.int64, device=dev)
+        sc = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(sc, rc)
+        self.send_counts = sc.tolist()
+        want = torch.empty(int(sum(self.send_counts)), dtype=self.halo.dtype, device=dev)
+        dist.all_to_all_single(want, self.halo.contiguous(), self.send_counts, self.recv_counts)
+        self.send_idx = (want - cuts[rank]).to(torch.int32)
+        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
+
+
+def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None):
+    """buf: [n_local + n_halo, F]; rows [:n_local] are this rank's; fills rows [n_local:] from the owners.
+    pack(src_rows_view, idx, out) gathers rows (gnnx_gather_rows_f32 on GPU)."""
+    n_send = int(side.send_idx.numel())
+    if send_buf is None or send_buf.shape[0] < n_send:
+        send_buf = torch.empty((max(n_send, 1), n_feat), dtype=buf.dtype, device=buf.device)
+    out = send_buf[:n_send]
+    if n_send:
+        pack(buf[: side.n_local], side.send_idx, out)
+    dist.all_to_all_single(buf[side.n_local: side.n_local + side.n_halo], out, side.recv_counts, side.send_counts)
+    return send_buf
+
+
+class ShardPlan:
+    """Everything rank `rank` needs for sharded forward + backward aggregation.
+
+    csr_builder(src, dst, n_rows, n_cols_hint) -> (rowptr int32 [n_rows+1], colidx int32 [nnz]) must apply the
+    reference's adjacency semantics (dedupe, self-loop strip, (src,dst) order): gnnx_csr_from_coo on the GPU.
+    Rows are LOCAL ids (src - lo), columns stay GLOBAL until HaloSide renumbers them.
+    """
+
+    def __init__(self, src, dst, n_nodes, rank, world, dist, csr_builder, cuts=None):
+        dev = src.device
+        self.rank, self.world, self.n_nodes = rank, world, n_nodes
+        if cuts is None:
+            w = torch.bincount(src.to(torch.int64), minlength=n_nodes) + torch.bincount(dst.to(torch.int64), minlength=n_nodes) + 1
+            cuts = balanced_cuts(w, world)
+        self.cuts = cuts
+        lo, hi = cuts[rank], cuts[rank + 1]
+        self.lo, self.hi, self.n_local = lo, hi, hi - lo
+        # self loops must be dropped on GLOBAL ids (rows are renumbered below), duplicates collapse in the builder
+        keep = src != dst
+        mine = keep & (src >= lo) & (src < hi)
+        rp, ci = csr_builder((src[mine] - lo).to(torch.int32), dst[mine].to(torch.int32), self.n_local, n_nodes)
+        self.fwd = HaloSide(rp, ci, lo, hi, cuts)
+        mine_t = keep & (dst >= lo) & (dst < hi)
+        rpt, cit = csr_builder((dst[mine_t] - lo).to(torch.int32), src[mine_t].to(torch.int32), self.n_local, n_nodes)
+        self.bwd = HaloSide(rpt, cit, lo, hi, cuts)
+        self.nnz_local = int(ci.numel())
+        if world > 1 and dist is not None:
+            self.fwd.exchange_requests(dist, cuts, rank, world)
+            self.bwd.exchange_requests(dist, cuts, rank, world)
+        elif world > 1:
+            pass  # plan without a process group (tests fill the halo rows themselves)
+        else:
+            for s in (self.fwd, self.bwd):
+                s.send_counts = [0]
+                s.send_idx = torch.empty(0, dtype=torch.int32, device=dev)
+        self.s_ext = self.norm = self.norm_ext_bwd = None
+
+    def compute_norm(self, dist, degree_norm, pack):
+        """s for local rows from local degrees, s of halo columns by one exchange, then norm (graph.cpp:177-185);
+        finally norm of the backward halo (colscale of the transposed aggregation)."""
+        f, b = self.fwd, self.bwd
+        dev = f.rowptr.device
+        s_ext = torch.zeros((f.n_local + f.n_halo, 1), dtype=torch.float32, device=dev)
+        degree_norm(f.rowptr, f.colidx, self.n_local, s_out=s_ext[: f.n_local], s_cols=None, norm_out=None)
+        if self.world > 1:
+            exchange_rows(dist, f, s_ext, 1, pack)
+        self.norm = torch.zeros(self.n_local, dtype=torch.float32, device=dev)
+        degree_norm(f.rowptr, f.colidx, self.n_local, s_out=None, s_cols=s_ext, norm_out=self.norm)
+        self.s_ext = s_ext
+        nb = torch.zeros((b.n_local + b.n_halo, 1), dtype=torch.float32, device=dev)
+        nb[: b.n_local, 0] = self.norm
+        if self.world > 1:
+            exchange_rows(dist, b, nb, 1, pack)
+        self.norm_ext_bwd = nb.reshape(-1).contiguous()
+        return self.norm
+
+
+# ---------------------------------------------------------------------------------------------------
+class ShardedBench:
+    """bench.py runner for N > 1 ranks: same synthetic graph as the single-GPU workload, sharded."""
+
+    def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk):
+        import ctypes as C
+        self.C = C
+        self.ops, self.capi, self.dist, self.F = ops, capi, dist, F
+        self.rank, self.world = rank, world
+        if abc is None:
+            s, d = pkg.synth.uniform_edges(seed, n, e)
+            src, dst = torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)
+        else:
+            src, dst = ops.rmat_edges(seed, n, e, *abc, device=dev)
+
+        def builder_once(s_, d_, n_rows, n_cols):
+            rp, ci = ops.CsrGraph.csr_from_coo(s_, d_, max(n_rows, n_cols), flags=1)  # self loops handled on global ids
+            return rp[: n_rows + 1].contiguous(), ci
+
+        self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once)
+        del src, dst
+        ops._ws_cache.clear()
+        torch.cuda.empty_cache()
+
+        def degree_norm(rowptr, colidx, n_rows, s_out, s_cols, norm_out):
+            capi.call("gnnx_degree_norm_f32", ops._ptr(rowptr), ops._ptr(colidx), n_rows, ops._ptr(s_out), ops._ptr(s_cols),
+                      ops._ptr(norm_out), ops._stream())
+
+        self.pack = lambda rows, idx, out: ops.gather_rows(rows, idx, out=out)
+        p.compute_norm(dist, degree_norm, self.pack)
+        t = torch.tensor([p.nnz_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        self.nnz_total = int(t.item())
+        self.plan_f = ops.SpmmPlan(p.fwd.rowptr, chunk, F) if chunk > 0 else None
+        self.plan_b = ops.SpmmPlan(p.bwd.rowptr, chunk, F) if chunk > 0 else None
+        nl = p.n_local
+        self.X = ops.uniform_pm1(seed + 10 + 1000 * rank, (nl, F), device=dev)
+        self.W = ops.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5, device=dev)
+        self.bias = torch.zeros(F, dtype=torch.float32, device=dev)
+        self.Hext = torch.empty((nl + p.fwd.n_halo, F), dtype=torch.float32, device=dev)   # [local | halo]
+        self.Gext = torch.empty((nl + p.bwd.n_halo, F), dtype=torch.float32, device=dev)
+        self.Gext[:nl] = ops.uniform_pm1(seed + 12 + 1000 * rank, (nl, F), device=dev)
+        self.out = torch.empty((nl, F), dtype=torch.float32, device=dev)
+        self.dH = torch.empty((nl, F), dtype=torch.float32, device=dev)
+        self.dX = torch.empty((nl, F), dtype=torch.float32, device=dev)
+        self.dW = torch.empty((F, F), dtype=torch.float32, device=dev)
+        self.dbias = torch.empty(F, dtype=torch.float32, device=dev)
+        n_send = max(int(p.fwd.send_idx.numel()), int(p.bwd.send_idx.numel()), 1)
+        self.send_buf = torch.empty((n_send, F), dtype=torch.float32, device=dev)
+        self.names = ["gemm_xwT", "halo_fwd", "spmm_fwd", "colsum", "halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW", "allreduce"]
+        self.ev = []
+
+    def step(self, timed=False):
+        ops, p, dist, nl = self.ops, self.plan, self.dist, self.plan.n_local
+        stream = self.C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        evs = []
+
+        def run(fn):
+            if timed:
+                a, b = self.capi.Event(), self.capi.Event()
+                a.record(stream)
+                fn()
+                b.record(stream)
+                evs.append((a, b))
+            else:
+                fn()
+
+        Hl, Gl = self.Hext[:nl], self.Gext[:nl]
+        run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
+        run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_buf))
+        run(lambda: ops.spmm(p.fwd.rowptr, p.fwd.colidx, self.Hext, out=self.out, rowscale=p.norm, bias=self.bias,
+                             plan=self.plan_f, n_rows=nl))
+        run(lambda: ops.colsum(Gl, out=self.dbias))
+        run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_buf))
+        run(lambda: ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext, out=self.dH, colscale=p.norm_ext_bwd, plan=self.plan_b,
+                             n_rows=nl))
+        run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
+        run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+
+        def reduce_params():
+            dist.all_reduce(self.dW)
+            dist.all_reduce(self.dbias)
+        run(reduce_params)
+        if timed:
+            self.ev.append(evs)
+
+    def kernel_times(self):
+        import numpy as np
+        out = {}
+        for i, nm in enumerate(self.names):
+            out[nm] = float(np.mean([s[i][0].elapsed_ms(s[i][1]) for s in self.ev])) if self.ev else None
+        return out
+
+    def roofline(self):
+        from bench import HBM_PEAK_GBS, spmm_bytes
+        p = self.plan
+        ms = self.kernel_times()["spmm_fwd"]
+        B = spmm_bytes(p.n_local, p.n_local, p.nnz_local, self.F, bias=True)
+        achieved = B / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "spmm_stream_kernel<64,4,8,0,64> (forward aggregation, slowest rank)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": B, "avg_launch_ms": ms,
+                "halo_rows_fwd": p.fwd.n_halo, "halo_rows_bwd": p.bwd.n_halo, "local_rows": p.n_local}

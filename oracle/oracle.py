@@ -96,11 +96,14 @@ def linear_fwd(X, W):
     return H
 
 
-def aggregate_fwd(rowptr, colidx, H, norm=None, bias=None):
+def aggregate_fwd(rowptr, colidx, H, norm=None, bias=None, n_rows=None):
+    """n_rows: number of output rows when the CSR is a rectangular row block (H has more rows: [local|halo])."""
     rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
     colidx = np.ascontiguousarray(colidx, dtype=np.int32)
     H = _f32(H)
     N, F = H.shape
+    if n_rows is not None:
+        N = n_rows
     out = np.zeros((N, F), dtype=np.float32)
     norm = None if norm is None else _f32(norm)
     bias = None if bias is None else _f32(bias)
@@ -110,11 +113,13 @@ def aggregate_fwd(rowptr, colidx, H, norm=None, bias=None):
     return out
 
 
-def aggregate_bwd(rowptrT, colidxT, G, norm=None):
+def aggregate_bwd(rowptrT, colidxT, G, norm=None, n_rows=None):
     rowptrT = np.ascontiguousarray(rowptrT, dtype=np.int64)
     colidxT = np.ascontiguousarray(colidxT, dtype=np.int32)
     G = _f32(G)
     N, F = G.shape
+    if n_rows is not None:
+        N = n_rows
     dH = np.zeros((N, F), dtype=np.float32)
     norm = None if norm is None else _f32(norm)
     _L().gcn_oracle_aggregate_bwd(_p(rowptrT), _p(colidxT), C.c_int32(N), C.c_int32(F), _p(G),

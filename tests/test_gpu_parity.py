@@ -399,3 +399,43 @@ def test_full_size_properties_rmat_1m_10m(env):
     a = float((Y.double() * G.double()).sum())
     b = float((H.double() * dH.double()).sum())
     assert abs(a - b) <= 1e-5 * max(abs(a), abs(b), 1.0)
+
+
+# ------------------------------------------------------------------ sharded layout on one GPU
+def test_shard_layout_on_gpu_bit_identical(env):
+    """Rank r of a world-3 partition, built by the product planner (gnn.cpp_amd/shard.py) with the device CSR
+    builder; halo rows are filled from the full matrix (what the all-to-all-v delivers -- the exchange itself
+    is covered by the gloo tests).  The [local | halo] SpMM must equal the unsharded rows bit for bit."""
+    ops, torch = env["ops"], env["torch"]
+    shard = importlib.import_module("gnncpp_amd.shard")
+    n, e, F, world = 30000, 400000, 128, 3
+    src, dst = synth.rmat_edges(17, n, e)
+    g = ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), n)
+    H = ops.uniform_pm1(18, (n, F))
+    G = ops.uniform_pm1(19, (n, F))
+    bias = ops.uniform_pm1(20, (F,))
+    out_ref = host(ops.aggregate_fwd(g, H, bias))
+    dH_ref = host(ops.aggregate_bwd(g, G))
+
+    def builder(s_, d_, n_rows, n_cols):
+        rp, ci = ops.CsrGraph.csr_from_coo(s_, d_, max(n_rows, n_cols), flags=1)
+        return rp[: n_rows + 1].contiguous(), ci
+
+    cuts = None
+    for rank in range(world):
+        plan = shard.ShardPlan(dev(env, src), dev(env, dst), n, rank, world, None, builder, cuts=cuts)
+        cuts = plan.cuts
+        lo, hi, nl = plan.lo, plan.hi, plan.n_local
+        f, b = plan.fwd, plan.bwd
+        Hext = torch.cat([H[lo:hi], H[f.halo.long()]])
+        out = ops.spmm(f.rowptr, f.colidx, Hext, rowscale=g.norm[lo:hi].contiguous(), bias=bias, n_rows=nl)
+        assert np.array_equal(host(out), out_ref[lo:hi])
+        Gext = torch.cat([G[lo:hi], G[b.halo.long()]])
+        norm_ext = torch.cat([g.norm[lo:hi], g.norm[b.halo.long()]])
+        dH = ops.spmm(b.rowptr, b.colidx, Gext, colscale=norm_ext, n_rows=nl)
+        assert np.array_equal(host(dH), dH_ref[lo:hi])
+        # with a plan (hub rows chunked) the sharded result equals the unsharded planned result within tolerance
+        pl = ops.SpmmPlan(f.rowptr, 256, F)
+        out_p = ops.spmm(f.rowptr, f.colidx, Hext, rowscale=g.norm[lo:hi].contiguous(), bias=bias, n_rows=nl, plan=pl)
+        assert float((out_p - out).abs().max()) <= 1e-4 * float(out.abs().max())
+    assert cuts[0] == 0 and cuts[-1] == n
