@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--workload", default="rmat10m_100m_f256", choices=sorted(WORKLOADS))
     ap.add_argument("--chunk", type=int, default=4096, help="plan: split rows longer than this (0 = never)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank (rehearsal)")
     ap.add_argument("--cpu-sample-nodes", type=int, default=1_000_000)
     args = ap.parse_args()
 
@@ -77,7 +78,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
@@ -87,7 +92,7 @@ def main():
 
     n, e, F, abc, seed = WORKLOADS[args.workload]
     t_build0 = time.time()
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk)
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
