@@ -48,6 +48,25 @@ WORKLOADS = {
 }
 
 
+def profiled_traffic(workload, kernel_substr):
+    """Per-launch HBM bytes of a kernel from the newest committed rocprofv3 PMC summary of this workload
+    (profiles/*_hbm_traffic.json, made by scripts/summarize_profile.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same bench command, gfx950-corrected); None if there is none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") != workload:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if kernel_substr in k:
+                best = (v["hbm_bytes_corrected"], os.path.relpath(f, ROOT))
+    return best
+
+
 def spmm_bytes(n_rows, n_cols_rows_written, nnz, F, bias=True):
     """Algorithmic bytes of one SpMM launch, Mode REF: rowptr + colidx + one neighbour
     row per edge + rowscale + Y write (+ bias)."""
@@ -94,6 +113,7 @@ def main():
     t_build0 = time.time()
     if world == 1 and not args.force_sharded:
         runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk)
+        runner.workload = args.workload
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
         runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk)
@@ -225,8 +245,10 @@ class SingleGpu:
         ms = self.kernel_times()["spmm_fwd"]
         B = spmm_bytes(self.n, self.n, self.g.nnz, self.F, bias=True)
         achieved = B / (ms * 1e-3) / 1e9
+        tr = profiled_traffic(self.workload, "spmm_stream_kernel<64, 4, 8, 0") if self.F == 256 else None
         return {"bound": "hbm", "kernel": "spmm_stream_kernel<64,4,8,0,64> (forward aggregation)", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+                "traffic_source": tr[1] if tr else None,
                 "algorithmic_bytes_per_launch": B, "bytes_per_edge": B / max(1, self.g.nnz), "avg_launch_ms": ms,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0}
 

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output (gpurun_out/...) into the small summaries committed under profiles/.
+
+    python scripts/summarize_profile.py <tag> <stats_dir> [<fetch_dir> <write_dir>]
+
+Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats summary, names shortened) and, when the two
+--pmc passes are given, profiles/<tag>_hbm_traffic.json with per-kernel per-launch HBM bytes:
+    traffic = 2 * FETCH_SIZE + WRITE_SIZE   (KiB counters -> bytes)
+The factor 2 is the gfx950 correction of MI355X_MICROARCH.md section HBM (FETCH_SIZE tallies 128-B requests at
+64 B); it is calibrated in the same run on colsum_stage1, which reads its [N,F] input exactly once
+(expected 4*N*F bytes).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    m = re.match(r"([A-Za-z0-9_:]+(<[^(]*>)?)", name)
+    return (m.group(1) if m else name)[:110]
+
+
+def one(pattern):
+    f = glob.glob(pattern)
+    if not f:
+        sys.exit(f"no file matches {pattern}")
+    return f[0]
+
+
+def counters(d, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(one(os.path.join(d, "*", "*_counter_collection.csv")))):
+        if r["Counter_Name"] == counter:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) * 1024.0 for k, v in acc.items()}  # KiB -> bytes, mean per launch
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    rows = list(csv.DictReader(open(one(os.path.join(stats_dir, "*", "*_kernel_stats.csv")))))
+    out = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv")
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "pct", "min_ms", "max_ms"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], f"{float(r['TotalDurationNs']) / 1e6:.3f}", f"{float(r['AverageNs']) / 1e6:.4f}",
+                        r["Percentage"], f"{float(r['MinNs']) / 1e6:.4f}", f"{float(r['MaxNs']) / 1e6:.4f}"])
+    print("wrote", out)
+    if len(sys.argv) >= 5:
+        fetch, write = counters(sys.argv[3], "FETCH_SIZE"), counters(sys.argv[4], "WRITE_SIZE")
+        res = {}
+        for k in sorted(set(fetch) | set(write)):
+            if not re.search(r"spmm|gemm_kernel|colsum_stage1|splitk|rows_kernel", k):
+                continue
+            fb, wb = fetch.get(k, 0.0), write.get(k, 0.0)
+            res[k] = {"fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb}
+        out = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
+        json.dump({"workload": os.environ.get("WORKLOAD", "rmat10m_100m_f256"), "command": os.environ.get("PROFILE_CMD", "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"),
+                   "note": "per launch; hbm_bytes_corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
+                           "MI355X_MICROARCH.md section HBM; calibrate on colsum_stage1 = 4*N*F bytes read once)",
+                   "kernels": res}, open(out, "w"), indent=1)
+        print("wrote", out)
+
+
+if __name__ == "__main__":
+    main()
