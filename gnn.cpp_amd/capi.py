@@ -78,6 +78,10 @@ _SIGS = {
     "gnnx_rowscale_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_bias_add_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_axpy_f32": [_i64, _f32, _vp, _vp, _vp],
+    "gnnx_fill_f32": [_vp, _i64, _f32, _vp],
+    "gnnx_pow_f32": [_vp, _i64, _f32, _vp, _vp],
+    "gnnx_csr_rowsum_f32": [_vp, _vp, _i32, _vp, _vp],
+    "gnnx_transpose_f32": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
     "gnnx_gather_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_scatter_add_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_rmat_edges": [_u64, _i32, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp],

@@ -92,6 +92,43 @@ __global__ __launch_bounds__(256) void axpy_kernel(int64_t n, float a, const flo
         y[i] = __fadd_rn(y[i], __fmul_rn(a, x[i]));
 }
 
+__global__ __launch_bounds__(256) void fill_kernel(float *x, int64_t n, float v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = v;
+}
+
+__global__ __launch_bounds__(256) void pow_kernel(const float *x, int64_t n, float e, float *y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = e == -0.5f ? (float)(1.0 / sqrt((double)x[i])) : powf(x[i], e);
+}
+
+__global__ __launch_bounds__(256) void csr_rowsum_kernel(const int32_t *rowptr, const float *vals, int32_t n, float *out)
+{
+    int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t b = rowptr[i], e = rowptr[i + 1];
+    if (!vals) {
+        out[i] = (float)(e - b);  // ascending sum of 1.0f's, exact below 2^24
+    } else {
+        float acc = 0.f;
+        for (int32_t p = b; p < e; p++) acc = __fadd_rn(acc, vals[p]);  // functional::sum walks UP
+        out[i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float *X, int64_t ldx, int64_t R, int64_t Cc, float *Y, int64_t ldy)
+{
+    __shared__ float tile[32][33];
+    int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < Cc) tile[k][tx] = X[(r0 + k) * ldx + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < Cc && r0 + tx < R) Y[(c0 + k) * ldy + r0 + tx] = tile[tx][k];
+}
+
 // ---- halo pack / unpack: one G-lane group per row, 16 B per lane ---------------------------------------
 template <int VEC, bool SCATTER_ADD>
 __global__ __launch_bounds__(256) void rows_kernel(const float *in, int64_t ldi, const int32_t *idx, int64_t n_idx,
@@ -241,4 +278,51 @@ GNNX_API int gnnx_scatter_add_rows_f32(const float *d_in, int64_t ldi, const int
     if (n_idx == 0 || n_feat == 0) return GNNX_OK;
     GNNX_REQUIRE(d_in && d_idx && d_Y && ldi >= n_feat && ldy >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
     return launch_rows<true>(d_in, ldi, d_idx, n_idx, n_feat, d_Y, ldy, as_stream(stream));
+}
+
+GNNX_API int gnnx_fill_f32(float *d_x, int64_t n, float value, void *stream)
+{
+    GNNX_REQUIRE(n >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_x, GNNX_ERR_INVALID_ARG, "null pointer");
+    int64_t blocks = ceil_div(n, 256);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(fill_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_x, n, value);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_pow_f32(const float *d_x, int64_t n, float exponent, float *d_y, void *stream)
+{
+    GNNX_REQUIRE(n >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_x && d_y, GNNX_ERR_INVALID_ARG, "null pointer");
+    int64_t blocks = ceil_div(n, 256);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    hipLaunchKernelGGL(pow_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_x, n, exponent, d_y);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_csr_rowsum_f32(const int32_t *d_rowptr, const float *d_vals, int32_t n_rows, float *d_out, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_rowptr && d_out, GNNX_ERR_INVALID_ARG, "null pointer");
+    hipLaunchKernelGGL(csr_rowsum_kernel, dim3((uint32_t)ceil_div(n_rows, 256)), dim3(256), 0, as_stream(stream), d_rowptr,
+                       d_vals, n_rows, d_out);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_transpose_f32(const float *d_X, int64_t ldx, int64_t n_rows, int64_t n_cols, float *d_Y, int64_t ldy,
+                                void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0 || n_cols == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_X && d_Y && d_X != d_Y && ldx >= n_cols && ldy >= n_rows, GNNX_ERR_INVALID_ARG, "bad pointers or ld");
+    dim3 grid((uint32_t)ceil_div(n_cols, 32), (uint32_t)ceil_div(n_rows, 32));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_cols, d_Y, ldy);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
 }

@@ -1,0 +1,190 @@
+// functional.h -- the "kernels" layer of the API: free functions on tensors, each one call into the C-ABI.
+// This is the seam the reference left open: `// device::add(out_data, lhs_data, rhs_data);`
+// (reference include/functional.h:174,180).  Only the shapes of the GCN hot path are implemented; anything
+// else throws ERROR_BACKEND_UNSUPPORTED (there is no CPU fallback).
+#ifndef GNNCPP_AMD_FUNCTIONAL_H
+#define GNNCPP_AMD_FUNCTIONAL_H
+
+#include "tensor.h"
+
+namespace cyg {
+namespace functional {
+
+namespace impl {
+inline tptr<float> new_out(const std::vector<size_t> &dims, bool req_grad)
+{
+    return std::make_shared<tensor<float>>(tensor<float>::device_tag{}, dims, req_grad);
+}
+inline bool is_col_of(const std::vector<size_t> &big, const std::vector<size_t> &small)  // [N,F] vs [N,1]
+{
+    return big.size() == 2 && small.size() == 2 && small[0] == big[0] && small[1] == 1;
+}
+inline bool is_row_of(const std::vector<size_t> &big, const std::vector<size_t> &small)  // [N,F] vs [F] or [1,F]
+{
+    return big.size() == 2 && ((small.size() == 1 && small[0] == big[1]) || (small.size() == 2 && small[0] == 1 && small[1] == big[1]));
+}
+}  // namespace impl
+
+// [N,F]+[N,F] (same shape: copy + axpy) and [N,F]+[F] (bias broadcast, reference functional.h:163-187)
+template <class T>
+tptr<T> add(const tptr<T> &lhs, const tptr<T> &rhs)
+{
+    if constexpr (!std::is_same_v<T, float>) {
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    } else {
+        const bool req = lhs->requires_grad() || rhs->requires_grad();
+        void *st = detail::current_stream();
+        auto ls = lhs->shape(), rs = rhs->shape();
+        if (ls == rs) {
+            auto out = impl::new_out(ls, req);
+            float *o = out->device_out();
+            detail::gx(gnnx_memcpy_d2d(o, lhs->device_data(), lhs->numel() * sizeof(float), st), "add");
+            detail::gx(gnnx_axpy_f32((int64_t)lhs->numel(), 1.0f, rhs->device_data(), o, st), "add");
+            return out;
+        }
+        if (impl::is_row_of(ls, rs)) {
+            auto out = impl::new_out(ls, req);
+            detail::gx(gnnx_bias_add_f32(lhs->device_data(), (int64_t)ls[1], rhs->device_data(), (int64_t)ls[0], (int32_t)ls[1],
+                                         out->device_out(), (int64_t)ls[1], st), "add");
+            return out;
+        }
+        if (impl::is_row_of(rs, ls)) return add(rhs, lhs);
+        if (!is_broadcastable(ls, rs)) CHECK_EQUAL_SIZES(rs, ls);
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    }
+}
+
+// [N,F]*[N,1] (row scale, reference functional.h:190-213 + utils.h:181-228) and same-shape [N,1]*[N,1]
+template <class T>
+tptr<T> mul(const tptr<T> &lhs, const tptr<T> &rhs)
+{
+    if constexpr (!std::is_same_v<T, float>) {
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    } else {
+        const bool req = lhs->requires_grad() || rhs->requires_grad();
+        void *st = detail::current_stream();
+        auto ls = lhs->shape(), rs = rhs->shape();
+        if (impl::is_col_of(ls, rs)) {
+            auto out = impl::new_out(ls, req);
+            detail::gx(gnnx_rowscale_f32(lhs->device_data(), (int64_t)ls[1], rhs->device_data(), (int64_t)ls[0], (int32_t)ls[1],
+                                         out->device_out(), (int64_t)ls[1], st), "mul");
+            return out;
+        }
+        if (impl::is_col_of(rs, ls)) return mul(rhs, lhs);
+        if (ls == rs) {  // elementwise: one value per "row"
+            auto out = impl::new_out(ls, req);
+            detail::gx(gnnx_rowscale_f32(lhs->device_data(), 1, rhs->device_data(), (int64_t)lhs->numel(), 1, out->device_out(), 1, st),
+                       "mul");
+            return out;
+        }
+        if (!is_broadcastable(ls, rs)) CHECK_EQUAL_SIZES(rs, ls);
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    }
+}
+
+// elementwise power with a scalar exponent (deg->pow(-0.5), reference graph.cpp:183 -> functional.h:242-264)
+template <class T>
+tptr<T> pow(const tptr<T> &base, float exponent)
+{
+    if constexpr (!std::is_same_v<T, float>) {
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    } else {
+        auto out = impl::new_out(base->shape(), false);
+        detail::gx(gnnx_pow_f32(base->device_data(), (int64_t)base->numel(), exponent, out->device_out(), detail::current_stream()),
+                   "pow");
+        return out;
+    }
+}
+
+// sum(-1, keepdim) of a CSR adjacency = out-degrees (reference graph.cpp:178); sum(0) of [N,F] = column sums
+// (sum_to_size in Add::_backward); reference functional.h:267-296
+template <class T>
+tptr<T> sum(const tptr<T> &base, int dim, bool keepdim)
+{
+    if constexpr (!std::is_same_v<T, float>) {
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    } else {
+        void *st = detail::current_stream();
+        auto shp = base->shape();
+        const int rank = (int)shp.size();
+        if (dim != INT_MAX && dim < 0) dim += rank;
+        if (base->is_csr()) {
+            if (dim != 1) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+            auto c = base->csr();
+            std::vector<size_t> od = keepdim ? std::vector<size_t>{(size_t)c->n, 1} : std::vector<size_t>{(size_t)c->n};
+            auto out = impl::new_out(od, false);
+            if (base->csr_transposed()) c->ensure_transpose();
+            detail::gx(gnnx_csr_rowsum_f32((const int32_t *)(base->csr_transposed() ? c->rowptr_t : c->rowptr), nullptr, c->n,
+                                           out->device_out(), st), "sum");
+            return out;
+        }
+        if (rank == 2 && dim == 0) {
+            std::vector<size_t> od = keepdim ? std::vector<size_t>{1, shp[1]} : std::vector<size_t>{shp[1]};
+            auto out = impl::new_out(od, base->requires_grad());
+            size_t wsb = 0;
+            detail::gx(gnnx_colsum_workspace((int64_t)shp[0], (int32_t)shp[1], &wsb), "sum");
+            detail::gx(gnnx_colsum_f32(base->device_data(), (int64_t)shp[1], (int64_t)shp[0], (int32_t)shp[1], 0.0f, out->device_out(),
+                                       detail::workspace(wsb), wsb, st), "sum");
+            return out;
+        }
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    }
+}
+
+// [N,N](CSR) . [N,F] -> CSR SpMM ;  [M,K] . [K,N] -> MFMA GEMM, either operand possibly a transposed view
+// (reference functional.h:399-441)
+template <class T>
+tptr<T> matmul(const tptr<T> &lhs, const tptr<T> &rhs)
+{
+    if constexpr (!std::is_same_v<T, float>) {
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    } else {
+        void *st = detail::current_stream();
+        const bool req = lhs->requires_grad() || rhs->requires_grad();
+        auto ls = lhs->shape(), rs = rhs->shape();
+        if (ls.size() != 2 || rs.size() != 2) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        if (ls[1] != rs[0]) throw std::runtime_error(ERROR_MM_COMPATIBLE);
+        if (rhs->is_csr()) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        if (lhs->is_csr()) {
+            auto c = lhs->csr();
+            const bool tr = lhs->csr_transposed();
+            if (tr) c->ensure_transpose();
+            auto out = impl::new_out({ls[0], rs[1]}, req);
+            detail::gx(gnnx_spmm_csr_f32(c->n, c->n, (int32_t)rs[1], (const int32_t *)(tr ? c->rowptr_t : c->rowptr),
+                                         (const int32_t *)(tr ? c->colidx_t : c->colidx), nullptr, nullptr, nullptr, nullptr,
+                                         rhs->device_data(), (int64_t)rs[1], 0.0f, out->device_out(), (int64_t)rs[1], nullptr, st),
+                       "matmul");
+            return out;
+        }
+        bool ta = false, tb = false;
+        const float *A = lhs->device_storage(ta);
+        const float *B = rhs->device_storage(tb);
+        const int64_t M = (int64_t)ls[0], K = (int64_t)ls[1], N = (int64_t)rs[1];
+        const int64_t lda = ta ? M : K, ldb = tb ? K : N;  // leading dims of the buffers as stored
+        auto out = impl::new_out({ls[0], rs[1]}, req);
+        size_t wsb = 0;
+        detail::gx(gnnx_gemm_workspace(ta, tb, M, N, K, &wsb), "matmul");
+        detail::gx(gnnx_gemm_f32(ta, tb, M, N, K, 1.0f, A, lda, B, ldb, 0.0f, out->device_out(), N, wsb ? detail::workspace(wsb) : nullptr,
+                                 wsb, st), "matmul");
+        return out;
+    }
+}
+
+// global max of an index tensor (edge_index->max(), reference graph.cpp:25,89 -> functional.h:25-71); host side
+template <class T>
+std::tuple<tptr<T>, tptr<int>> max(const tensor<T> &t)
+{
+    auto &self = const_cast<tensor<T> &>(t);
+    auto *h = self.data();
+    size_t arg = 0;
+    for (size_t i = 1; i < h->size(); i++)
+        if ((*h)[i] > (*h)[arg]) arg = i;
+    auto v = std::make_shared<tensor<T>>(std::vector<size_t>{1}, (*h)[arg], false);
+    auto a = std::make_shared<tensor<int>>(std::vector<size_t>{1}, (int)arg, false);
+    return {v, a};
+}
+
+}  // namespace functional
+}  // namespace cyg
+
+#endif

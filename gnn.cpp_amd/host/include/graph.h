@@ -1,0 +1,86 @@
+// graph.h -- the graph layer of the reference API (reference include/graph.h:9-139, src/graph.cpp) on the
+// MI355X backend: COO <-> adjacency helpers, Data, MessagePassing, GCNConv.
+//
+// The adjacency "matrix" is a cyg::tensor<float> of shape [N,N] backed by CSR on the device (never dense):
+//   edge_to_adj_mat   COO -> CSR, duplicates collapse (reference graph.cpp:21-44)
+//   fill_diagonal_(0) strips self loops (graph.cpp:72)
+//   adj_to_edge_list  CSR -> COO in row-major order (graph.cpp:46-67)
+// so GCNConv::forward / aggregate_and_update keep the reference's call sequence (graph.cpp:170-212) while each
+// call lands on a hand-written HIP kernel.
+#ifndef GNNCPP_AMD_GRAPH_H
+#define GNNCPP_AMD_GRAPH_H
+
+#include <memory>
+#include <tuple>
+#include <vector>
+
+#include "nn.h"
+#include "tensor.h"
+
+namespace graph {
+
+typedef enum DataType { TRAIN, VAL, TEST } DataType;
+
+cyg::tptr<int> vec_to_edge_list(std::vector<int> source, std::vector<int> destination);
+// n_nodes == 0 uses max(edge_index)+1 (the reference uses max(edge_index), which overflows its own buffer:
+// graph.cpp:25,40 -- SURVEY appendix A; pass n_nodes explicitly for identical behaviour)
+cyg::tptr<float> edge_to_adj_mat(const cyg::tensor<int> &edge_index, cyg::tensor<float> *edge_attr = nullptr, size_t n_nodes = 0);
+std::tuple<cyg::tptr<int>, cyg::tptr<float>> adj_to_edge_list(cyg::tensor<float> &adj_mat);
+std::tuple<cyg::tptr<int>, cyg::tptr<float>> add_self_loops(const cyg::tensor<int> &edge_index, cyg::tensor<float> *edge_attr = nullptr,
+                                                            const float &fillValue = 0, const int &num_nodes = 0);
+
+class Data {
+public:
+    Data() {}
+    Data(const cyg::tptr<float> &x, cyg::tensor<int> *edge_index = nullptr, cyg::tptr<float> edge_attr = nullptr,
+         cyg::tensor<float> *y = nullptr);
+    cyg::tensor<int> *edge_index();
+    void set_edge_index(cyg::tensor<int> *edge_index, cyg::tptr<float> edge_attr = nullptr);
+    cyg::tptr<float> to_adj();
+    size_t num_nodes() const { return _num_nodes; }
+    size_t num_node_features() const { return _num_node_features; }
+    size_t num_edges() const { return _num_edges; }
+    cyg::tptr<float> x() const { return _x; }
+    cyg::tptr<float> edge_attr() const { return _edge_attr; }
+
+protected:
+    size_t _num_nodes = 0, _num_node_features = 0, _num_edges = 0, _num_edge_features = 0;
+    cyg::tensor<int> *_edge_index = nullptr;
+    cyg::tensor<float> *_y = nullptr;
+    cyg::tptr<float> _x, _edge_attr;
+};
+
+class MessagePassing : public nn::Module {
+public:
+    MessagePassing() {}
+    virtual cyg::tptr<float> message(const cyg::tptr<float> *, const cyg::tptr<float> *x_j, const cyg::tptr<float> * = nullptr) { return *x_j; }
+    virtual cyg::tptr<float> aggregate_and_update(const cyg::tptr<float> &, const cyg::tensor<int> &, const cyg::tptr<float> *)
+    {
+        throw std::runtime_error("not yet implemented");
+    }
+    cyg::tptr<float> operator()(Data &input) { return forward(std::move(input)); }
+    using nn::Module::operator();
+    virtual cyg::tptr<float> forward(Data &&) { throw std::runtime_error("not yet implemented"); }
+    using nn::Module::forward;
+    virtual cyg::tptr<float> propagate(const cyg::tensor<int> &edge_index, const cyg::tptr<float> &x, const cyg::tptr<float> *norm = nullptr);
+};
+
+class GCNConv : public MessagePassing {
+public:
+    GCNConv(size_t in_channels, size_t out_channels, float dropout = 0.0);
+    // transform -> (BatchNorm -> ReLU: next row) -> normalised aggregation -> + bias   (reference graph.cpp:170-191)
+    cyg::tptr<float> forward(Data &&input) override;
+    using MessagePassing::forward;
+    cyg::tptr<float> propagate(const cyg::tensor<int> &edge_index, const cyg::tptr<float> &x, const cyg::tptr<float> *others) override;
+    cyg::tptr<float> aggregate_and_update(const cyg::tptr<float> &x, const cyg::tensor<int> &edge_index, const cyg::tptr<float> *other) override;
+
+    // hot_path_only = true skips the BatchNorm/ReLU pair between transform and aggregation (they are a "next"
+    // row); with false, forward() throws at BatchNorm until that row is built.
+    bool hot_path_only = true;
+    size_t _in_channels, _out_channels;
+    float _dropout;
+};
+
+}  // namespace graph
+
+#endif

@@ -1,0 +1,674 @@
+// tensor.h -- cyg::tensor<T> / tptr<T> / Operation / Context: the reference's autograd tensor API
+// (reference include/tensor.h, include/operation.h, include/functional.h) re-implemented over device memory.
+//
+// What is kept: type names, the shared_ptr ownership model, the op protocol
+// (`forward` saves inputs in a Context, the output owns the op through `grad_fn`, `backward(G)` does
+// `_grad += G` then recurses, reference tensor.h:260-276, operation.h:20-100), constructor signatures
+// (the pointer ctor ADOPTS the valarray, tensor.h:122-130), error texts, and the member functions the GCN
+// hot path uses: mm, t, sum, pow, mul, add, clone, sum_to_size, fill_diagonal_, backward, grad, data,
+// set_data, shape/numel/rank, item, operator()(i,j), max, uniform and the arithmetic operators.
+//
+// What is different (by design, MI355X-first):
+//   * storage lives in HBM; `data()` / `grad()` hand out a host std::valarray synchronised on demand;
+//   * every arithmetic op of the path is one call into the C-ABI (include/gnnx.h): matmul -> MFMA GEMM or CSR
+//     SpMM, mul/add broadcasts -> fused row-scale / bias kernels, sum_to_size -> column sum;
+//   * an adjacency "matrix" (graph::edge_to_adj_mat) is a tensor whose shape() is [N,N] but whose storage is
+//     CSR (+ lazily its transpose): mm, sum(-1,true), fill_diagonal_ dispatch on that, N x N is never built;
+//   * t() of a 2-D tensor is a zero-copy view (a flag the GEMM consumes as transA/transB);
+//   * ops outside the hot path throw ERROR_BACKEND_UNSUPPORTED -- there is no CPU fallback;
+//   * gradients fan-in correctly (the reference drops the 2nd arrival at an op, operation.h:82-86; never
+//     triggered on the hot path itself).
+#ifndef GNNCPP_AMD_TENSOR_H
+#define GNNCPP_AMD_TENSOR_H
+
+#include <cmath>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <random>
+#include <string>
+#include <tuple>
+#include <typeinfo>
+#include <unordered_map>
+#include <valarray>
+#include <vector>
+
+#include "gnnx.h"
+#include "utils.h"
+
+namespace cyg {
+
+template <class T>
+class tensor;
+template <class A>
+using tptr = std::shared_ptr<tensor<A>>;
+
+namespace detail {
+
+// One logical buffer with a host copy and/or a device copy; whichever was written last is authoritative.
+template <class T>
+struct Store {
+    size_t n = 0;
+    std::valarray<T> *host = nullptr;
+    void *dev = nullptr;
+    bool host_ok = false, dev_ok = false;
+
+    explicit Store(size_t n_) : n(n_) {}
+    Store(const Store &) = delete;
+    Store &operator=(const Store &) = delete;
+    ~Store()
+    {
+        delete host;
+        if (dev) gnnx_free(dev);
+    }
+    void adopt_host(std::valarray<T> *h)
+    {
+        delete host;
+        host = h;
+        host_ok = true;
+        dev_ok = false;
+    }
+    // host view, valid contents
+    std::valarray<T> *h()
+    {
+        if (!host) host = new std::valarray<T>(T(), n);
+        if (!host_ok) {
+            if (dev_ok && n) {
+                if constexpr (std::is_same_v<T, bool>) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+                else gx(gnnx_memcpy_d2h(&(*host)[0], dev, n * sizeof(T), current_stream()), "download");
+            }
+            host_ok = true;
+        }
+        return host;
+    }
+    void ensure_dev_alloc()
+    {
+        if (!dev && n) gx(gnnx_malloc(&dev, n * sizeof(T)), "alloc");
+    }
+    // device pointer, valid contents
+    T *d()
+    {
+        if constexpr (std::is_same_v<T, bool>) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        ensure_dev_alloc();
+        if (!dev_ok) {
+            if (host_ok && n) gx(gnnx_memcpy_h2d(dev, &(*host)[0], n * sizeof(T), current_stream()), "upload");
+            else if (n) gx(gnnx_memset(dev, 0, n * sizeof(T), current_stream()), "memset");
+            dev_ok = true;
+        }
+        return static_cast<T *>(dev);
+    }
+    // device pointer about to be fully overwritten by a kernel
+    T *d_out()
+    {
+        ensure_dev_alloc();
+        dev_ok = true;
+        host_ok = false;
+        return static_cast<T *>(dev);
+    }
+    void host_written()
+    {
+        host_ok = true;
+        dev_ok = false;
+    }
+};
+
+// CSR adjacency living on the device (+ the COO it came from, so that A^T can be built on demand).
+struct Csr {
+    int32_t n = 0;
+    int64_t nnz = 0, nnz_t = -1;
+    void *rowptr = nullptr, *colidx = nullptr;      // A
+    void *rowptr_t = nullptr, *colidx_t = nullptr;  // A^T (lazy)
+    void *coo_src = nullptr, *coo_dst = nullptr;    // device copies of the edge list
+    int64_t n_edges = 0;
+    uint32_t flags = GNNX_CSR_KEEP_SELF_LOOPS;       // edge_to_adj_mat keeps the diagonal; fill_diagonal_(0) strips it
+    ~Csr();
+    void build();            // (re)build A from the COO with `flags`
+    void ensure_transpose();
+};
+
+}  // namespace detail
+
+// ---------------------------------------------------------------------------------------------------
+// autograd protocol (reference operation.h:20-100)
+template <class T>
+class Context {
+public:
+    std::vector<std::shared_ptr<T>> cache;
+    std::unordered_map<std::string, int> saved_data;
+    void save_for_backward(std::vector<std::shared_ptr<T>> tensors)
+    {
+        for (const auto &t : tensors) cache.push_back(t);
+    }
+    std::vector<std::shared_ptr<T>> get_variables() { return cache; }
+};
+
+template <class T>
+class Operation {
+public:
+    std::string name = "Operation";
+    std::unique_ptr<Context<T>> context = std::make_unique<Context<T>>();
+    virtual ~Operation() = default;
+    // Unlike the reference (operation.h:80-88) a second arrival is not dropped: every arrival propagates,
+    // which sums gradients correctly on fan-out.  The hot path is a chain, where both behave the same.
+    void backward(std::shared_ptr<tensor<float>> incoming_grad) { _backward(std::move(incoming_grad)); }
+    virtual void _backward(std::shared_ptr<tensor<float>> incoming_grad) = 0;
+};
+
+template <class T>
+void CHECK_BACKWARD(const std::vector<std::shared_ptr<T>> &var, size_t expected = 1)
+{
+    if (var.size() != expected) throw std::runtime_error("cannot backprop without a executing a forward computation first");
+}
+
+namespace functional {
+template <class T>
+tptr<T> add(const tptr<T> &lhs, const tptr<T> &rhs);
+template <class T>
+tptr<T> mul(const tptr<T> &lhs, const tptr<T> &rhs);
+template <class T>
+tptr<T> pow(const tptr<T> &base, float exponent);
+template <class T>
+tptr<T> sum(const tptr<T> &base, int dim, bool keepdim);
+template <class T>
+tptr<T> matmul(const tptr<T> &lhs, const tptr<T> &rhs);
+template <class T>
+std::tuple<tptr<T>, tptr<int>> max(const tensor<T> &t);
+}  // namespace functional
+
+template <class T>
+class Add;
+template <class T>
+class Mul;
+template <class T>
+class MatMul;
+template <class T>
+class Transpose;
+template <class T>
+class Sum;
+
+// ---------------------------------------------------------------------------------------------------
+template <class T>
+class tensor : public std::enable_shared_from_this<tensor<T>> {
+    // arithmetic operators of the API (reference tensor.h:30-95)
+    friend tptr<T> operator+(tptr<T> lhs, const tptr<T> &rhs) { return lhs->add(rhs); }
+    friend tptr<T> operator+(tptr<T> lhs, const float &rhs) { return lhs->add(rhs); }
+    friend tptr<T> operator+(tptr<T> lhs, const int &rhs) { return lhs->add((float)rhs); }
+    friend tptr<T> operator-(tptr<T> lhs, const float &rhs) { return lhs->add(-rhs); }
+    friend tptr<T> operator*(tptr<T> lhs, const tptr<T> &rhs) { return lhs->mul(rhs); }
+    friend tptr<T> operator*(tptr<T> lhs, const float &rhs) { return lhs->mul(rhs); }
+    friend tptr<T> operator*=(tptr<T> lhs, const tptr<T> &rhs)
+    {
+        lhs->check_in_place();
+        auto out = lhs * rhs;
+        lhs->assign_from(*out);
+        return lhs;
+    }
+    friend tptr<T> operator+=(tptr<T> lhs, const tptr<T> &rhs)
+    {
+        lhs->check_in_place();
+        auto out = lhs + rhs;
+        lhs->assign_from(*out);
+        return lhs;
+    }
+
+public:
+    typedef T value_type;
+    std::unique_ptr<Operation<tensor<T>>> grad_fn;
+
+    explicit tensor(std::vector<size_t> dims, T value = 0, bool requires_grad = false)
+        : _dims(dims), _requires_grad(requires_grad)
+    {
+        CHECK_VALID_DIMS(dims);
+        _st = std::make_shared<detail::Store<T>>(numel_of(dims));
+        _st->adopt_host(new std::valarray<T>(value, _st->n));
+        init_grad();
+    }
+    // ADOPTS `data` (reference tensor.h:122-130)
+    explicit tensor(std::vector<size_t> dims, std::valarray<T> *data, bool requires_grad = false)
+        : _dims(dims), _requires_grad(requires_grad)
+    {
+        CHECK_VALID_DIMS(dims);
+        _st = std::make_shared<detail::Store<T>>(numel_of(dims));
+        if (data != nullptr) {
+            CHECK_SIZE(dims, data->size());
+            _st->adopt_host(data);
+        } else {
+            _st->adopt_host(new std::valarray<T>(T(), _st->n));
+        }
+        init_grad();
+    }
+    // backend-side constructors
+    struct device_tag {};
+    tensor(device_tag, std::vector<size_t> dims, bool requires_grad) : _dims(dims), _requires_grad(requires_grad)
+    {
+        CHECK_VALID_DIMS(dims);
+        _st = std::make_shared<detail::Store<T>>(numel_of(dims));
+        init_grad();
+    }
+    tensor(std::shared_ptr<detail::Csr> csr, bool) : _dims({(size_t)csr->n, (size_t)csr->n}), _requires_grad(false), _csr(csr) {}
+
+    // ---- plain accessors
+    std::vector<size_t> shape() const { return _dims; }
+    size_t numel() const { return numel_of(_dims); }
+    int rank() const { return (int)_dims.size(); }
+    bool requires_grad() const { return _requires_grad; }
+    bool is_csr() const { return (bool)_csr; }
+    bool is_transposed_view() const { return _tview; }
+    const std::shared_ptr<detail::Csr> &csr() const { return _csr; }
+
+    // host view of the values; the caller may write through it, so the host copy becomes authoritative
+    std::valarray<T> *data()
+    {
+        materialize();
+        auto *h = _st->h();
+        _st->host_written();
+        return h;
+    }
+    // device pointers for the backend (valid contents / to be overwritten)
+    T *device_data()
+    {
+        materialize();
+        return _st->d();
+    }
+    T *device_out() { return _st->d_out(); }
+    // storage as it is laid out ([rows, cols] of the UNtransposed buffer) + whether this tensor views it transposed
+    T *device_storage(bool &transposed)
+    {
+        transposed = _tview;
+        return _st->d();
+    }
+
+    template <class A>
+    void set_data(std::valarray<A> *data)
+    {
+        if (data->size() != numel()) throw std::runtime_error(ERROR_SIZE_MISMATCH);
+        require_dense();
+        _tview = false;
+        auto *h = new std::valarray<T>(numel());
+        for (size_t i = 0; i < numel(); i++) (*h)[i] = static_cast<T>((*data)[i]);
+        _st = std::make_shared<detail::Store<T>>(numel());
+        _st->adopt_host(h);
+        if (_requires_grad) zero_grad();
+    }
+
+    std::valarray<float> *grad()
+    {
+        if (grad_fn != nullptr) throw std::runtime_error(WARNING_GRAD_NOT_LEAF);
+        if (!_grad) throw std::runtime_error("invalid op, pls enable grad on this tensor");
+        auto *h = _grad->h();
+        _grad->host_written();
+        return h;
+    }
+    float *device_grad() { return _grad ? _grad->d() : nullptr; }
+
+    void requires_grad_(bool requires_grad)
+    {
+        _requires_grad = requires_grad;
+        if (requires_grad) zero_grad();
+        else _grad.reset();
+    }
+    void zero_grad()
+    {
+        if (typeid(T) != typeid(float)) throw std::runtime_error(ERROR_GRAD_DTYPE);
+        _grad = std::make_shared<detail::Store<float>>(numel());
+        _grad->adopt_host(new std::valarray<float>(0.0f, numel()));
+    }
+
+    // ---- autograd entry (reference tensor.h:260-276)
+    void backward(std::shared_ptr<tensor<float>> incoming_gradient = nullptr)
+    {
+        if (incoming_gradient == nullptr && numel() != 1) throw std::runtime_error(ERROR_NON_SCALAR_BACKPROP);
+        if (incoming_gradient == nullptr) incoming_gradient = std::make_shared<tensor<float>>(_dims, 1.0f, false);
+        if (incoming_gradient->numel() != numel()) throw std::runtime_error(ERROR_GRAD_MISMATCH);
+        if (_grad && !grad_fn)  // `_grad += G`; only leaves keep it (a non-leaf's grad() is refused anyway)
+            detail::gx(gnnx_axpy_f32((int64_t)numel(), 1.0f, incoming_gradient->device_data(), _grad->d(),
+                                     detail::current_stream()), "grad accumulate");
+        if (_grad && !grad_fn) _grad->host_ok = false;
+        if (grad_fn) grad_fn->backward(incoming_gradient);
+    }
+
+    // ---- ops of the hot path (each builds the reference's op object and records it)
+    tptr<T> add(const tptr<T> &other)
+    {
+        CHECK_ARGS_OPS_BROADCAST(shape(), other->shape());
+        auto op = std::make_unique<Add<tensor<T>>>();
+        auto out = op->forward(this->shared_from_this(), other);
+        if (out->requires_grad()) out->grad_fn = std::move(op);
+        return out;
+    }
+    tptr<T> add(const float &other) { return add(std::make_shared<tensor<T>>(_dims, static_cast<T>(other), false)); }
+    tptr<T> mul(const tptr<T> &other)
+    {
+        CHECK_ARGS_OPS_BROADCAST(shape(), other->shape());
+        auto op = std::make_unique<Mul<tensor<T>>>();
+        auto out = op->forward(this->shared_from_this(), other);
+        if (out->requires_grad()) out->grad_fn = std::move(op);
+        return out;
+    }
+    tptr<T> mul(const float &other) { return mul(std::make_shared<tensor<T>>(_dims, static_cast<T>(other), false)); }
+    tptr<T> mm(const tptr<T> &other)
+    {
+        CHECK_MM_DIMS(shape(), other->shape());
+        auto op = std::make_unique<MatMul<tensor<T>>>();
+        auto out = op->forward(this->shared_from_this(), other);
+        if (out->requires_grad()) out->grad_fn = std::move(op);
+        return out;
+    }
+    template <class A>
+    tptr<T> pow(const A &exponent)
+    {
+        if (_requires_grad) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);  // only the (grad-free) degree scaling is on the path
+        return functional::pow(this->shared_from_this(), (float)exponent);
+    }
+    tptr<T> sum(int dim = INT_MAX, const bool &keepdim = false, const bool &inplace = false)
+    {
+        CHECK_VALID_RANGE(dim, rank(), -rank());
+        auto op = std::make_unique<Sum<tensor<T>>>();
+        auto out = op->forward(this->shared_from_this(), dim, keepdim);
+        if (inplace) {
+            assign_from(*out);
+            return this->shared_from_this();
+        }
+        if (out->requires_grad()) out->grad_fn = std::move(op);
+        return out;
+    }
+    // transpose of two adjacent dims; for 2-D tensors a zero-copy view (the GEMM takes it as a flag)
+    tptr<T> t(int d1 = -1, int d2 = -2, const bool &inplace = false)
+    {
+        CHECK_TRANSPOSE(shape(), d1, d2);
+        if (rank() != 2) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        if (inplace) {
+            check_in_place();
+            require_dense();
+            std::swap(_dims[0], _dims[1]);
+            _tview = !_tview;
+            return this->shared_from_this();
+        }
+        auto op = std::make_unique<Transpose<tensor<T>>>();
+        auto out = op->forward(this->shared_from_this(), d1, d2);
+        if (out->requires_grad()) out->grad_fn = std::move(op);
+        return out;
+    }
+    tptr<T> clone(const bool &require_grad = false, const T fillValue = INT_MAX) const
+    {
+        auto self = const_cast<tensor<T> *>(this);
+        self->require_dense();
+        if (fillValue != static_cast<T>(INT_MAX)) return std::make_shared<tensor<T>>(_dims, fillValue, require_grad);
+        auto out = std::make_shared<tensor<T>>(device_tag{}, _dims, require_grad);
+        if constexpr (std::is_same_v<T, bool>) {
+            *out->_st->h() = *self->_st->h();
+            out->_st->host_written();
+        } else {
+            detail::gx(gnnx_memcpy_d2d(out->device_out(), self->device_data(), numel() * sizeof(T), detail::current_stream()),
+                       "clone");
+        }
+        return out;
+    }
+    // reduce (in place) to `dims` by summing the broadcast dimensions (reference tensor.h:618-638)
+    void sum_to_size(std::vector<size_t> dims)
+    {
+        if ((size_t)rank() < dims.size()) throw std::runtime_error("not expandable");
+        if (!is_broadcastable(_dims, dims)) throw std::runtime_error("dims is not broacastable to this tensor's size");
+        for (int i = -1; i >= -rank(); i--) {
+            if ((size_t)std::abs(i) > dims.size()) {
+                this->sum(0, false, true);
+            } else {
+                size_t mine = _dims[_dims.size() + i], want = dims[dims.size() + i];
+                if (mine < want) throw std::runtime_error(" not expandable");
+                if (mine != want) this->sum(i, true, true);
+            }
+        }
+    }
+    template <class A>
+    void fill_diagonal_(const A &value = 0)
+    {
+        if (rank() != 2 || _dims[0] != _dims[1]) throw std::runtime_error("all dimensions must be of same length and tensor must be 2D");
+        if (_csr) {
+            // only the two values the path uses: 0 strips self loops (graph.cpp:72); anything else is off-path
+            if ((float)value != 0.0f) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+            _csr->flags &= ~GNNX_CSR_KEEP_SELF_LOOPS;
+            _csr->build();
+            return;
+        }
+        auto *h = data();
+        for (size_t i = 0; i < _dims[0]; i++) (*h)[i * _dims[1] + i] = static_cast<T>(value);
+    }
+    T item()
+    {
+        if (numel() != 1) throw std::runtime_error("invalid op, item() is only valid for tensors with one element");
+        return (*const_cast<tensor<T> *>(this)->_st->h())[0];
+    }
+    // element access (scalar tensor, as the reference returns: tensor.h:282-293)
+    tptr<T> operator()(size_t i, size_t j)
+    {
+        if (rank() != 2) throw std::runtime_error(ERROR_RANK_MISMATCH);
+        if (i >= _dims[0] || j >= _dims[1]) throw std::runtime_error(ERROR_OUT_OF_RANGE);
+        materialize();
+        return std::make_shared<tensor<T>>(std::vector<size_t>{1}, (*_st->h())[i * _dims[1] + j], false);
+    }
+    T operator[](size_t i)
+    {
+        if (i >= numel()) throw std::runtime_error(ERROR_OUT_OF_RANGE);
+        materialize();
+        return (*_st->h())[i];
+    }
+    std::tuple<tptr<T>, tptr<int>> max() { return functional::max<T>(*this); }
+    // U(low, high) initialisation (reference tensor.h:693-705; the reference seeds from time(), utils.cpp:6 --
+    // here the engine is seedable through cyg::manual_seed for reproducible runs)
+    tptr<T> uniform(const float &low, const float &high);
+
+    // ---- backend helpers
+    void assign_from(tensor<T> &other)
+    {
+        _st = other._st;
+        _dims = other._dims;
+        _tview = other._tview;
+        _csr = other._csr;
+        _csr_t = other._csr_t;
+    }
+    void check_in_place() const
+    {
+        if (_requires_grad && grad_fn == nullptr) throw std::runtime_error(ERROR_IN_PLACE_OP_LEAF);
+    }
+    void require_dense() const
+    {
+        if (_csr) throw std::runtime_error("this tensor is a CSR adjacency (graph::edge_to_adj_mat); it has no dense data");
+    }
+    // turn a transposed view into real row-major storage
+    void materialize()
+    {
+        require_dense();
+        if (!_tview) return;
+        if constexpr (std::is_same_v<T, float>) {
+            auto fresh = std::make_shared<detail::Store<T>>(numel());
+            // stored buffer is [dims1, dims0]; this tensor is its transpose [dims0, dims1]
+            detail::gx(gnnx_transpose_f32(_st->d(), (int64_t)_dims[0], (int64_t)_dims[1], (int64_t)_dims[0], fresh->d_out(),
+                                          (int64_t)_dims[1], detail::current_stream()), "transpose");
+            _st = fresh;
+            _tview = false;
+        } else {
+            throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        }
+    }
+    // grad-free transposed alias of this tensor: no copy (dense: flips the view flag; CSR: selects A^T)
+    tptr<T> clone_view_t()
+    {
+        if (rank() != 2) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        if (_csr) {
+            auto out = std::make_shared<tensor<T>>(_csr, false);
+            out->_csr_t = !_csr_t;
+            return out;
+        }
+        auto out = std::make_shared<tensor<T>>(device_tag{}, std::vector<size_t>{_dims[1], _dims[0]}, false);
+        out->set_storage(_st, !_tview);
+        return out;
+    }
+    bool csr_transposed() const { return _csr_t; }
+    std::shared_ptr<detail::Store<T>> storage() const { return _st; }
+    void set_storage(std::shared_ptr<detail::Store<T>> st, bool tview)
+    {
+        _st = std::move(st);
+        _tview = tview;
+    }
+
+private:
+    void init_grad()
+    {
+        if (_requires_grad) {
+            if (typeid(T) != typeid(float)) throw std::runtime_error(ERROR_GRAD_DTYPE);
+            zero_grad();
+        }
+    }
+    std::vector<size_t> _dims;
+    bool _requires_grad = false;
+    bool _tview = false;
+    bool _csr_t = false;
+    std::shared_ptr<detail::Store<T>> _st;
+    std::shared_ptr<detail::Store<float>> _grad;
+    std::shared_ptr<detail::Csr> _csr;
+};
+
+void manual_seed(unsigned long long seed);
+float generate_random(const float &low, const float &high);
+tptr<float> randn(std::vector<size_t> dims, int low = -1, int high = 1, bool requires_grad = false);
+
+template <class T>
+tptr<T> tensor<T>::uniform(const float &low, const float &high)
+{
+    auto *h = data();
+    for (size_t i = 0; i < numel(); i++) (*h)[i] = static_cast<T>(generate_random(low, high));
+    return this->shared_from_this();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// op classes (reference operation.h:103-168, 256-292, 399-434, 490-535): same protocol, device arithmetic
+template <class T>
+class Add : public Operation<T> {
+public:
+    Add() { this->name = "Add"; }
+    std::shared_ptr<T> forward(const std::shared_ptr<T> &lhs, const std::shared_ptr<T> &rhs)
+    {
+        auto output = functional::add(lhs, rhs);
+        if (output->requires_grad()) this->context->save_for_backward({lhs, rhs});
+        return output;
+    }
+    void _backward(std::shared_ptr<tensor<float>> incoming_gradient) override
+    {
+        auto var = this->context->get_variables();
+        CHECK_BACKWARD<T>(var, 2);
+        for (const auto &t : var)
+            if (t->requires_grad()) {
+                auto g = incoming_gradient->clone(false);
+                g->sum_to_size(t->shape());  // [N,F] -> [F] for the bias: column sum on the device
+                t->backward(g);
+            }
+    }
+};
+
+template <class T>
+class Mul : public Operation<T> {
+public:
+    Mul() { this->name = "Mul"; }
+    std::shared_ptr<T> forward(const std::shared_ptr<T> &lhs, const std::shared_ptr<T> &rhs)
+    {
+        auto output = functional::mul(lhs, rhs);
+        if (output->requires_grad()) this->context->save_for_backward({lhs, rhs});
+        return output;
+    }
+    void _backward(std::shared_ptr<tensor<float>> incoming_grad) override
+    {
+        auto var = this->context->get_variables();
+        CHECK_BACKWARD<T>(var, 2);
+        auto lhs = var[0], rhs = var[1];
+        if (rhs->requires_grad()) {
+            auto g = functional::mul(incoming_grad, lhs);
+            g->sum_to_size(rhs->shape());
+            rhs->backward(g);
+        }
+        if (lhs->requires_grad()) {
+            auto g = functional::mul(incoming_grad, rhs);
+            g->sum_to_size(lhs->shape());
+            lhs->backward(g);
+        }
+    }
+};
+
+template <class T>
+class Sum : public Operation<T> {
+public:
+    Sum() { this->name = "Sum"; }
+    std::shared_ptr<T> forward(const std::shared_ptr<T> &base, int dim, bool keepdim)
+    {
+        auto output = functional::sum(base, dim, keepdim);
+        if (output->requires_grad()) this->context->save_for_backward({base});
+        return output;
+    }
+    void _backward(std::shared_ptr<tensor<float>>) override { throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED); }
+};
+
+template <class T>
+class Transpose : public Operation<T> {
+public:
+    Transpose() { this->name = "Transpose"; }
+    std::shared_ptr<T> forward(const std::shared_ptr<T> &lhs, int d1 = -1, int d2 = -2)
+    {
+        lhs->require_dense();
+        auto dims = lhs->shape();
+        std::swap(dims[0], dims[1]);
+        auto output = std::make_shared<T>(typename T::device_tag{}, dims, lhs->requires_grad());
+        output->set_storage(lhs->storage(), !lhs->is_transposed_view());  // zero-copy view
+        if (output->requires_grad()) {
+            this->context->save_for_backward({lhs});
+            this->context->saved_data["d1"] = d1;
+            this->context->saved_data["d2"] = d2;
+        }
+        return output;
+    }
+    void _backward(std::shared_ptr<tensor<float>> incoming_grad) override
+    {
+        auto var = this->context->get_variables();
+        CHECK_BACKWARD<T>(var, 1);
+        auto base = var[0];
+        if (base->requires_grad()) {
+            auto g = incoming_grad->clone(false);
+            g->t(this->context->saved_data["d1"], this->context->saved_data["d2"], true);
+            base->backward(g);
+        }
+    }
+};
+
+template <class T>
+class MatMul : public Operation<T> {
+public:
+    MatMul() { this->name = "MatMul"; }
+    std::shared_ptr<T> forward(const std::shared_ptr<T> &lhs, const std::shared_ptr<T> &rhs)
+    {
+        auto output = functional::matmul(lhs, rhs);
+        if (output->requires_grad()) this->context->save_for_backward({lhs, rhs});
+        return output;
+    }
+    // dL = G . R^T ; dR = L^T . G  (reference operation.h:504-534) -- transposes are views, and for a CSR
+    // lhs (the adjacency) L^T . G runs on the transposed CSR instead of a dense N x N transpose.
+    void _backward(std::shared_ptr<tensor<float>> incoming_grad) override
+    {
+        auto var = this->context->get_variables();
+        CHECK_BACKWARD<T>(var, 2);
+        auto lhs = var[0], rhs = var[1];
+        if (lhs->requires_grad()) {
+            auto g = functional::matmul(incoming_grad, rhs->clone_view_t());
+            g->sum_to_size(lhs->shape());
+            lhs->backward(g);
+        }
+        if (rhs->requires_grad()) {
+            auto g = functional::matmul(lhs->clone_view_t(), incoming_grad);
+            g->sum_to_size(rhs->shape());
+            rhs->backward(g);
+        }
+    }
+};
+
+}  // namespace cyg
+
+#include "functional.h"
+
+#endif

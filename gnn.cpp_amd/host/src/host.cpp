@@ -1,0 +1,369 @@
+// Backend glue of the cyg / nn / graph API: C-ABI status -> exception, stream + workspace, CSR storage,
+// the module registry, Linear, and the graph layer (reference src/utils.cpp, src/tensor.cpp, src/nn.cpp:12-211,
+// src/graph.cpp re-implemented over include/gnnx.h).
+#include <algorithm>
+#include <cmath>
+#include <random>
+
+#include "graph.h"
+#include "nn.h"
+#include "tensor.h"
+
+using namespace cyg;
+
+// ---------------------------------------------------------------------------------------------------- detail
+namespace cyg {
+namespace detail {
+
+static thread_local void *g_stream = nullptr;
+static void *g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+
+void gx(int status, const char *where)
+{
+    if (status == GNNX_OK) return;
+    std::string msg;
+    switch (status) {
+    case GNNX_ERR_SHAPE: msg = ERROR_MM_COMPATIBLE; break;
+    case GNNX_ERR_INDEX_RANGE:
+        msg = "invalid input, max value in edge_index should be less than the number of nodes from x";  // graph.cpp:90
+        break;
+    default: msg = std::string(where) + ": " + gnnx_last_error() + " [" + gnnx_status_string(status) + "]";
+    }
+    throw std::runtime_error(msg);
+}
+
+void *current_stream() { return g_stream; }
+void set_current_stream(void *stream) { g_stream = stream; }
+
+void *workspace(size_t bytes)
+{
+    if (bytes == 0) return nullptr;
+    if (bytes > g_ws_bytes) {
+        if (g_ws) {
+            gx(gnnx_stream_sync(g_stream), "workspace");
+            gnnx_free(g_ws);
+        }
+        g_ws = nullptr;
+        gx(gnnx_malloc(&g_ws, bytes), "workspace");
+        g_ws_bytes = bytes;
+    }
+    return g_ws;
+}
+
+Csr::~Csr()
+{
+    for (void *p : {rowptr, colidx, rowptr_t, colidx_t, coo_src, coo_dst})
+        if (p) gnnx_free(p);
+}
+
+static void build_one(const void *src, const void *dst, int64_t n_edges, int32_t n, uint32_t flags, void **rowptr, void **colidx,
+                      int64_t *nnz)
+{
+    if (*rowptr) gnnx_free(*rowptr);
+    if (*colidx) gnnx_free(*colidx);
+    *rowptr = *colidx = nullptr;
+    gx(gnnx_malloc(rowptr, sizeof(int32_t) * ((size_t)n + 1)), "csr");
+    gx(gnnx_malloc(colidx, sizeof(int32_t) * (size_t)std::max<int64_t>(n_edges, 1)), "csr");
+    size_t wsb = 0;
+    gx(gnnx_csr_from_coo_workspace(n_edges, n, &wsb), "csr");
+    gx(gnnx_csr_from_coo((const int32_t *)src, (const int32_t *)dst, n_edges, n, flags, (int32_t *)*rowptr, (int32_t *)*colidx, nnz,
+                         workspace(wsb), wsb, current_stream()), "csr");
+}
+
+void Csr::build()
+{
+    build_one(coo_src, coo_dst, n_edges, n, flags, &rowptr, &colidx, &nnz);
+    nnz_t = -1;  // transpose is stale
+}
+
+void Csr::ensure_transpose()
+{
+    if (nnz_t >= 0) return;
+    build_one(coo_dst, coo_src, n_edges, n, flags, &rowptr_t, &colidx_t, &nnz_t);
+}
+
+}  // namespace detail
+
+static std::mt19937_64 &engine()
+{
+    static std::mt19937_64 e(0x5eed5eedull);
+    return e;
+}
+void manual_seed(unsigned long long seed) { engine().seed(seed); }
+float generate_random(const float &low, const float &high)
+{
+    return std::uniform_real_distribution<float>(low, high)(engine());
+}
+tptr<float> randn(std::vector<size_t> dims, int low, int high, bool requires_grad)
+{
+    if (low >= high) throw std::runtime_error("pls check input params, low must be lower than high");
+    auto t = std::make_shared<tensor<float>>(dims, 0.0f, requires_grad);
+    t->uniform((float)low, (float)high);
+    return t;
+}
+}  // namespace cyg
+
+// ---------------------------------------------------------------------------------------------------- nn
+namespace nn {
+
+void Module::register_module(std::string n, Module *module)
+{
+    module->name = n;
+    _modules.push_back({n, std::shared_ptr<Module>(module)});
+}
+void Module::register_parameter(std::string n, tptr<float> p) { _parameters[n] = std::move(p); }
+void Module::register_buffer(std::string n, tptr<float> p) { _buffers[n] = std::move(p); }
+
+void Module::zero_grad()
+{
+    for (auto &p : parameters()) p->zero_grad();
+}
+void Module::train(const bool &isTrain)
+{
+    training = isTrain;
+    for (auto &[n, m] : _modules) m->train(isTrain);
+}
+std::vector<std::shared_ptr<Module>> Module::modules(const bool &recurse)
+{
+    std::vector<std::shared_ptr<Module>> out;
+    for (auto &[n, m] : _modules) {
+        out.push_back(m);
+        if (recurse)
+            for (auto &c : m->modules(true)) out.push_back(c);
+    }
+    return out;
+}
+std::unordered_map<std::string, tptr<float>> Module::named_parameters(const bool &recurse)
+{
+    auto out = _parameters;
+    if (recurse)
+        for (auto &[cname, m] : _modules)
+            for (auto &[k, v] : m->named_parameters(true)) out[out.count(k) ? cname + "_" + k : k] = v;
+    return out;
+}
+std::unordered_map<std::string, tptr<float>> Module::named_buffers(const bool &recurse)
+{
+    auto out = _buffers;
+    if (recurse)
+        for (auto &[cname, m] : _modules)
+            for (auto &[k, v] : m->named_buffers(true)) out[out.count(k) ? cname + "_" + k : k] = v;
+    return out;
+}
+std::vector<tptr<float>> Module::parameters(const bool &recurse)
+{
+    std::vector<tptr<float>> out;
+    for (auto &[k, v] : named_parameters(recurse)) out.push_back(v);
+    return out;
+}
+tptr<float> Module::get_parameter(std::string n)
+{
+    auto all = named_parameters();
+    auto it = all.find(n);
+    if (it == all.end()) throw std::runtime_error("no parameter named " + n);
+    return it->second;
+}
+tptr<float> Module::get_buffer(std::string n)
+{
+    auto all = named_buffers();
+    auto it = all.find(n);
+    if (it == all.end()) throw std::runtime_error("no buffer named " + n);
+    return it->second;
+}
+std::shared_ptr<Module> Module::get_module(std::string n)
+{
+    for (auto &[k, m] : _modules)
+        if (k == n) return m;
+    for (auto &[k, m] : _modules) {
+        try {
+            return m->get_module(n);
+        } catch (const std::runtime_error &) {
+        }
+    }
+    throw std::runtime_error("no module named " + n);
+}
+
+Linear::Linear(const size_t &in_features, const size_t &out_features, const bool &bias, const std::string &n)
+    : Module(n), _bias(bias), _in_features(in_features), _out_features(out_features)
+{
+    register_parameter("weight", std::make_shared<tensor<float>>(std::vector<size_t>{out_features, in_features}, 1.0f, true));
+    if (_bias) register_parameter("bias", std::make_shared<tensor<float>>(std::vector<size_t>{out_features}, 1.0f, true));
+    reset_parameters();
+}
+void Linear::reset_parameters()
+{
+    const float bound = 1.0f / std::sqrt((float)_in_features);
+    _parameters["weight"]->uniform(-bound, bound);
+    if (_bias) _parameters["bias"]->uniform(-bound, bound);
+}
+// the dense feature transform of the hot path: x.mm(W.t(-1,-2)) (+ b) -- reference nn.cpp:205-211; t() is a view,
+// so this is ONE MFMA GEMM with transB = 1
+tptr<float> Linear::forward(const tptr<float> &input_tensor)
+{
+    auto output = input_tensor->mm(get_parameter("weight")->t(-1, -2));
+    if (_bias) return output + get_parameter("bias");
+    return output;
+}
+
+}  // namespace nn
+
+// ---------------------------------------------------------------------------------------------------- graph
+namespace graph {
+
+tptr<int> vec_to_edge_list(std::vector<int> source, std::vector<int> destination)
+{
+    if (source.size() != destination.size()) throw std::runtime_error("input vectors must be of same length");
+    const size_t e = source.size();
+    auto *v = new std::valarray<int>(2 * e);
+    for (size_t i = 0; i < e; i++) {
+        (*v)[i] = source[i];
+        (*v)[e + i] = destination[i];
+    }
+    if (e == 0) throw std::runtime_error(ERROR_INVALID_DIMS);
+    return std::make_shared<tensor<int>>(std::vector<size_t>{2, e}, v, false);
+}
+
+// COO -> CSR on the device; the returned tensor says shape [N,N] but holds no dense data
+tptr<float> edge_to_adj_mat(const tensor<int> &edge_index, tensor<float> *edge_attr, size_t n_nodes)
+{
+    auto &ei = const_cast<tensor<int> &>(edge_index);
+    if (ei.rank() != 2 || ei.shape()[0] != 2) throw std::runtime_error("invalid input for x, must be of 2D");
+    const size_t e = ei.shape()[1];
+    if (edge_attr != nullptr) {
+        if (e != edge_attr->shape()[0])
+            throw std::runtime_error("invalid inputs, number of edges in edge_index must be equal to size of edge_attr");
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);  // weighted adjacency: SURVEY 8(f) rank 4 (kernel supports vals; API row pending)
+    }
+    size_t n = n_nodes;
+    if (n == 0) n = (size_t)std::get<0>(ei.max())->item() + 1;
+    auto c = std::make_shared<detail::Csr>();
+    c->n = (int32_t)n;
+    c->n_edges = (int64_t)e;
+    const int32_t *d = ei.device_data();  // rows 0 (sources) and 1 (destinations), contiguous
+    detail::gx(gnnx_malloc(&c->coo_src, e * sizeof(int32_t)), "adj");
+    detail::gx(gnnx_malloc(&c->coo_dst, e * sizeof(int32_t)), "adj");
+    detail::gx(gnnx_memcpy_d2d(c->coo_src, d, e * sizeof(int32_t), detail::current_stream()), "adj");
+    detail::gx(gnnx_memcpy_d2d(c->coo_dst, d + e, e * sizeof(int32_t), detail::current_stream()), "adj");
+    c->build();
+    return std::make_shared<tensor<float>>(c, false);
+}
+
+// CSR -> COO, row-major order (what the reference's scan of the dense matrix yields, graph.cpp:46-67)
+std::tuple<tptr<int>, tptr<float>> adj_to_edge_list(tensor<float> &adj_mat)
+{
+    if (!adj_mat.is_csr()) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    auto c = adj_mat.csr();
+    const size_t nnz = (size_t)c->nnz;
+    std::vector<int32_t> rp((size_t)c->n + 1), ci(std::max<size_t>(nnz, 1));
+    detail::gx(gnnx_memcpy_d2h(rp.data(), c->rowptr, rp.size() * sizeof(int32_t), detail::current_stream()), "edge list");
+    if (nnz) detail::gx(gnnx_memcpy_d2h(ci.data(), c->colidx, nnz * sizeof(int32_t), detail::current_stream()), "edge list");
+    if (nnz == 0) throw std::runtime_error(ERROR_INVALID_DIMS);  // the reference cannot represent an empty [2,0] tensor either
+    auto *v = new std::valarray<int>(2 * nnz);
+    for (int32_t r = 0; r < c->n; r++)
+        for (int32_t p = rp[r]; p < rp[r + 1]; p++) {
+            (*v)[p] = r;
+            (*v)[nnz + p] = ci[p];
+        }
+    auto edge_index = std::make_shared<tensor<int>>(std::vector<size_t>{2, nnz}, v, false);
+    auto edge_attr = std::make_shared<tensor<float>>(std::vector<size_t>{nnz}, 1.0f, false);
+    return {edge_index, edge_attr};
+}
+
+std::tuple<tptr<int>, tptr<float>> add_self_loops(const tensor<int> &edge_index, tensor<float> *edge_attr, const float &fillValue,
+                                                  const int &num_nodes)
+{
+    auto mat = edge_to_adj_mat(edge_index, edge_attr, (size_t)num_nodes);
+    mat->fill_diagonal_(fillValue);
+    return adj_to_edge_list(*mat);
+}
+
+Data::Data(const tptr<float> &x, tensor<int> *edge_index, tptr<float> edge_attr, tensor<float> *y)
+    : _num_nodes(x->shape()[0]), _num_node_features(x->rank() > 1 ? x->shape()[1] : 0), _edge_index(edge_index), _y(y), _x(x),
+      _edge_attr(edge_attr)
+{
+    if (x->rank() != 2) throw std::runtime_error("invalid input for x, must be 2D");
+    if (edge_index != nullptr) {
+        if (edge_index->rank() != 2 || edge_index->shape()[0] != 2) throw std::runtime_error("invalid input for x, must be of 2D");
+        _num_edges = edge_index->shape()[1];
+        if ((int)x->shape()[0] <= std::get<0>(edge_index->max())->item())
+            throw std::runtime_error("invalid input, max value in edge_index should be less than the number of nodes from x");
+        if (edge_attr != nullptr) {
+            if (edge_attr->rank() != 2) throw std::runtime_error("pls check input tensors, must of 2D for x, edge_index and edge_attr");
+            if (edge_index->shape()[1] != edge_attr->shape()[0])
+                throw std::runtime_error("invalid edge_index and/or edge_attr input, edge_index should of [2, num_edges] and edge_attr "
+                                         "should be of [num_edges, num_edge_feature]");
+            _num_edge_features = edge_attr->shape()[1];
+        }
+    }
+}
+tensor<int> *Data::edge_index()
+{
+    if (_edge_index == nullptr) throw std::runtime_error("pls provide adj matr or edge");
+    return _edge_index;
+}
+void Data::set_edge_index(tensor<int> *edge_index, tptr<float> edge_attr)
+{
+    _edge_index = edge_index;  // not owned (the reference deletes the previous one, graph.cpp:114; callers own theirs here)
+    _edge_attr = std::move(edge_attr);
+}
+tptr<float> Data::to_adj()
+{
+    if (_edge_index == nullptr) throw std::runtime_error("pls provide adj matr or edge");
+    return edge_to_adj_mat(*_edge_index, _edge_attr.get(), _num_nodes);
+}
+
+tptr<float> MessagePassing::propagate(const tensor<int> &edge_index, const tptr<float> &x, const tptr<float> *)
+{
+    return aggregate_and_update(x, edge_index, nullptr);
+}
+
+GCNConv::GCNConv(size_t in_channels, size_t out_channels, float dropout)
+    : MessagePassing(), _in_channels(in_channels), _out_channels(out_channels), _dropout(dropout)
+{
+    register_module("lin", new nn::Linear(in_channels, out_channels, false));
+    register_module("bnorm", new nn::BatchNorm(out_channels));
+    register_module("drop", new nn::Dropout(dropout));
+    register_module("relu", new nn::ReLU());
+    register_parameter("bias", std::make_shared<tensor<float>>(std::vector<size_t>{out_channels}, 0.0f, true));
+}
+
+// Same sequence of API calls as the reference layer (graph.cpp:170-191); each lands on the device:
+//   add_self_loops          -> CSR build (dedupe, diagonal stripped), never a dense N x N
+//   lin                     -> MFMA GEMM, W^T as a view
+//   sum(-1,true) + 1, pow   -> degrees from rowptr, correctly rounded rsqrt
+//   adj.mm(deg), norm *= deg-> CSR SpMV in the reference's summation order + elementwise
+//   propagate, + bias       -> CSR SpMM, row scale, bias broadcast
+tptr<float> GCNConv::forward(Data &&input)
+{
+    auto [edge_index, _] = add_self_loops(*input.edge_index(), nullptr, 0, (int)input.num_nodes());
+    auto out = (*get_module("lin"))(input.x());
+    if (!hot_path_only) {
+        out = (*get_module("bnorm"))(out);
+        out = (*get_module("relu"))(out);
+    }
+    auto adj_mat = edge_to_adj_mat(*edge_index, nullptr, input.num_nodes());
+    auto deg = adj_mat->sum(-1, true) + 1;
+    deg = deg->pow(-0.5);
+    auto norm = adj_mat->mm(deg);
+    norm *= deg;
+    out = propagate(*edge_index, out, &norm);
+    out = out + get_parameter("bias");
+    return out;
+}
+
+tptr<float> GCNConv::propagate(const tensor<int> &edge_index, const tptr<float> &x, const tptr<float> *norm)
+{
+    return aggregate_and_update(x, edge_index, norm);
+}
+
+// norm (.) (A . x): SpMM then row scale, recorded as MatMul + Mul so that backward is A^T . (norm (.) G)
+// (reference graph.cpp:204-212)
+tptr<float> GCNConv::aggregate_and_update(const tptr<float> &x, const tensor<int> &edge_index, const tptr<float> *norm)
+{
+    auto adj_mat = edge_to_adj_mat(edge_index, nullptr, x->shape()[0]);
+    auto agg_x = adj_mat->mm(x);
+    agg_x = agg_x * *norm;
+    return agg_x;
+}
+
+}  // namespace graph

@@ -176,6 +176,19 @@ int gnnx_bias_add_f32(const float *d_X, int64_t ldx, const float *d_b, int64_t n
                       int64_t ldy, void *stream);
 int gnnx_axpy_f32(int64_t n, float a, const float *d_x, float *d_y, void *stream);
 
+/* Elementwise helpers behind the tensor API mirror (gnn.cpp_amd/host/):
+ *   fill      : x[i] = value                                   (tensor(dims, value) ctor, reference tensor.h:106)
+ *   pow       : y[i] = pow(x[i], e); e == -0.5 is the correctly rounded 1/sqrt (the GCN degree scaling,
+ *               reference graph.cpp:183 -> functional.h:253), other exponents use powf
+ *   csr_rowsum: out[i] = sum_j A_ij = rowptr[i+1]-rowptr[i] (vals == NULL) -- adj_mat->sum(-1,true), reference
+ *               graph.cpp:178 -> functional.h:267-296, without the dense N x N matrix
+ *   transpose : Y[c,r] = X[r,c]  (materialises a 2-D transpose only when a caller insists on the data;
+ *               the GEMM never needs it).  X and Y must not alias. */
+int gnnx_fill_f32(float *d_x, int64_t n, float value, void *stream);
+int gnnx_pow_f32(const float *d_x, int64_t n, float exponent, float *d_y, void *stream);
+int gnnx_csr_rowsum_f32(const int32_t *d_rowptr, const float *d_vals, int32_t n_rows, float *d_out, void *stream);
+int gnnx_transpose_f32(const float *d_X, int64_t ldx, int64_t n_rows, int64_t n_cols, float *d_Y, int64_t ldy, void *stream);
+
 /* ------------------------------------------------------------------ halo (multi-GPU) ------------- */
 /* Pack rows for the all-to-all-v send buffer: out[k,:] = X[idx[k],:]; and the reverse for backward:
  * Y[idx[k],:] += in[k,:] (idx may repeat across calls but NOT within one call => no atomics, deterministic). */
