@@ -95,7 +95,7 @@ def test_reference_driver_compiles_unchanged_against_the_host_api(capi):
     """oracle/ref_driver.cpp (written against the reference's headers) builds as-is against gnn.cpp_amd/host."""
     import os
     assert os.path.exists(os.path.join(ROOT, "gnn.cpp_amd", "libgnncpp_host.so"))
-    drv = os.path.join(ROOT, "gnn.cpp_amd", "host", "dropin_driver")
+    drv = os.path.join(ROOT, "tests", "cpp", "dropin_driver")
     assert os.path.exists(drv)
     r = subprocess.run([drv], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr  # loads (links libgnnx_hip.so) and parses args without a GPU

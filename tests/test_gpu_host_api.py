@@ -1,6 +1,6 @@
 """Drop-in boundary on the GPU: oracle/ref_driver.cpp -- the driver that is compiled against the REAL reference
 to produce the golden vectors -- is compiled UNCHANGED against gnn.cpp_amd/host/include (cyg::tensor, nn::Module,
-graph::GCNConv ... over the C-ABI) into gnn.cpp_amd/host/dropin_driver, run on the golden inputs, and its dumps
+graph::GCNConv ... over the C-ABI) into tests/cpp/dropin_driver, run on the golden inputs, and its dumps
 are compared with what the reference produced for the same calls."""
 import os
 import subprocess
@@ -15,7 +15,7 @@ from tests.helpers import ROOT
 from tests.test_gpu_parity import assert_close
 
 pytestmark = pytest.mark.gpu
-DRIVER = os.path.join(ROOT, "gnn.cpp_amd", "host", "dropin_driver")
+DRIVER = os.path.join(ROOT, "tests", "cpp", "dropin_driver")
 
 
 def run_driver(d):
