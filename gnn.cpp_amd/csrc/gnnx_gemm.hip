@@ -14,6 +14,9 @@
 // flight from HBM while tile t is multiplied.
 // transA = 1 reduces over the node dimension (K = millions, M x N = F_out x F_in tiny): split-K over
 // workgroups into fp32 slabs + an in-order slab reduction (deterministic; no float atomics).
+#include <cstdlib>
+#include <cstring>
+
 #include "gnnx_common.h"
 
 using namespace gnnx;
@@ -21,9 +24,6 @@ using namespace gnnx;
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDS_LD = 130;  // words; 4*130 % 32 == 8 keeps the transposing writes at <= 2-way conflicts
 
 struct GemmArgs {
     int64_t M, N, K;
@@ -38,144 +38,173 @@ struct GemmArgs {
     float *slab;          // split-K partials [splits][M][N] (nullptr => write C directly)
 };
 
-// Global -> registers for one operand tile [128 rows(m or n)] x [32 k].
+// Tile configuration: BM x BN output tile, BK K-step, WM x WN wavefronts (each (BM/WM) x (BN/WN), made of 32x32 MFMA tiles).
+template <int BM_, int BN_, int BK_, int WM_, int WN_>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+    static constexpr int NT = 64 * WM * WN;                     // threads
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wavefront
+    static constexpr int LDA = BM + 2, LDB = BN + 2;  // LDS row strides (words): 4*LD % 32 == 8 => <= 2-way write conflicts
+    static constexpr int A_VECS = BM * BK / 4 / NT;   // float4 per thread per tile
+    static constexpr int B_VECS = BN * BK / 4 / NT;
+    static_assert(A_VECS >= 1 && B_VECS >= 1, "tile too small for the thread count");
+};
+
+// Global -> registers for one operand tile [ROWS (m or n)] x [BK k].
 // KC (K-contiguous): element (r, k) at base[r*ld + k]  (X, W^T-as-W).   !KC (k-major): base[k*ld + r].
-// VEC: 16-byte loads are legal (ld % 4 == 0, base 16-B aligned, and for KC also K % 4 == 0).
-// Out-of-range elements are zero.  Loads are never predicated (see gnnx_spmm.hip): addresses are clamped
-// into the matrix and the value is zeroed by a select.
-template <bool KC, bool VEC>
-__device__ __forceinline__ void load_tile(float (&reg)[16], const float *base, int64_t ld, int64_t r0, int64_t rmax,
+// VEC: 16-byte loads are legal (ld % 4 == 0, base 16-B aligned, and the contiguous extent % 4 == 0).
+// Loads are never predicated (see gnnx_spmm.hip) and their results are NOT touched here: addresses are clamped
+// into the matrix and out-of-range elements are zeroed later, in store_tile -- a select right after the load
+// would make the compiler wait for HBM before the MFMA loop instead of after it.
+template <bool KC, bool VEC, int ROWS, int BK, int NT, int NV>
+__device__ __forceinline__ void load_tile(float (&reg)[NV * 4], const float *base, int64_t ld, int64_t r0, int64_t rmax,
                                           int64_t k0, int64_t kmax, int tid)
 {
-    if constexpr (KC) {
-        // thread -> (row = tid/8 + 32*i, kq = tid%8): 8 lanes cover one 128-B row segment
-        const int kq = tid & 7;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int64_t r = r0 + (tid >> 3) + 32 * i;
-            int64_t k = k0 + kq * 4;
-            bool rok = r < rmax;
-            int64_t rc = rok ? r : rmax - 1;
+    for (int i = 0; i < NV; i++) {
+        const int idx = tid + i * NT;
+        int64_t r, k;  // first of 4 consecutive elements along the contiguous axis
+        if constexpr (KC) {
+            r = r0 + idx / (BK / 4);
+            k = k0 + (idx % (BK / 4)) * 4;
+            const int64_t rc = r < rmax ? r : rmax - 1;
             if constexpr (VEC) {
-                bool ok = rok && k < kmax;  // K % 4 == 0 => whole float4 in or out
-                int64_t kc = k < kmax ? k : 0;
-                float4 v = *reinterpret_cast<const float4 *>(base + rc * ld + kc);
-                reg[4 * i + 0] = ok ? v.x : 0.f;
-                reg[4 * i + 1] = ok ? v.y : 0.f;
-                reg[4 * i + 2] = ok ? v.z : 0.f;
-                reg[4 * i + 3] = ok ? v.w : 0.f;
+                const float4 v = *reinterpret_cast<const float4 *>(base + rc * ld + (k < kmax ? k : 0));
+                reg[4 * i + 0] = v.x;
+                reg[4 * i + 1] = v.y;
+                reg[4 * i + 2] = v.z;
+                reg[4 * i + 3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    bool ok = rok && (k + j) < kmax;
-                    int64_t kc = (k + j) < kmax ? (k + j) : 0;
-                    float v = base[rc * ld + kc];
-                    reg[4 * i + j] = ok ? v : 0.f;
-                }
+                for (int j = 0; j < 4; j++) reg[4 * i + j] = base[rc * ld + ((k + j) < kmax ? (k + j) : 0)];
             }
-        }
-    } else {
-        // thread -> (k = tid/32 + 8*i, rq = tid%32): 32 lanes cover 512 B of one k-row
-        const int rq = tid & 31;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int64_t k = k0 + (tid >> 5) + 8 * i;
-            int64_t r = r0 + rq * 4;
-            bool kok = k < kmax;
-            int64_t kc = kok ? k : kmax - 1;
+        } else {
+            k = k0 + idx / (ROWS / 4);
+            r = r0 + (idx % (ROWS / 4)) * 4;
+            const int64_t kc = k < kmax ? k : kmax - 1;
             if constexpr (VEC) {
-                bool ok = kok && r < rmax;  // rmax % 4 == 0 on this path
-                int64_t rc = r < rmax ? r : 0;
-                float4 v = *reinterpret_cast<const float4 *>(base + kc * ld + rc);
-                reg[4 * i + 0] = ok ? v.x : 0.f;
-                reg[4 * i + 1] = ok ? v.y : 0.f;
-                reg[4 * i + 2] = ok ? v.z : 0.f;
-                reg[4 * i + 3] = ok ? v.w : 0.f;
+                const float4 v = *reinterpret_cast<const float4 *>(base + kc * ld + (r < rmax ? r : 0));
+                reg[4 * i + 0] = v.x;
+                reg[4 * i + 1] = v.y;
+                reg[4 * i + 2] = v.z;
+                reg[4 * i + 3] = v.w;
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    bool ok = kok && (r + j) < rmax;
-                    int64_t rc = (r + j) < rmax ? (r + j) : 0;
-                    float v = base[kc * ld + rc];
-                    reg[4 * i + j] = ok ? v : 0.f;
-                }
+                for (int j = 0; j < 4; j++) reg[4 * i + j] = base[kc * ld + ((r + j) < rmax ? (r + j) : 0)];
             }
         }
     }
 }
 
-// registers -> LDS tile [32 k][LDS_LD]
-template <bool KC>
-__device__ __forceinline__ void store_tile(float *lds, const float (&reg)[16], int tid)
+// registers -> LDS tile [BK k][LD] (k-major).  MASK = false: the whole tile is inside the matrix (the hot case, no
+// selects); MASK = true: out-of-range elements are written as zero.
+template <bool KC, bool MASK, int ROWS, int BK, int NT, int NV, int LD>
+__device__ __forceinline__ void store_tile_impl(float *lds, const float (&reg)[NV * 4], int tid, int64_t r0, int64_t rmax,
+                                                int64_t k0, int64_t kmax)
 {
-    if constexpr (KC) {
-        const int kq = tid & 7;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int r = (tid >> 3) + 32 * i;
+    for (int i = 0; i < NV; i++) {
+        const int idx = tid + i * NT;
+        if constexpr (KC) {
+            const int r = idx / (BK / 4), k = (idx % (BK / 4)) * 4;
 #pragma unroll
-            for (int j = 0; j < 4; j++) lds[(kq * 4 + j) * LDS_LD + r] = reg[4 * i + j];
-        }
-    } else {
-        const int rq = tid & 31;
+            for (int j = 0; j < 4; j++) {
+                float v = reg[4 * i + j];
+                if constexpr (MASK) v = (r0 + r < rmax && k0 + k + j < kmax) ? v : 0.f;
+                lds[(k + j) * LD + r] = v;
+            }
+        } else {
+            const int k = idx / (ROWS / 4), r = (idx % (ROWS / 4)) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int k = (tid >> 5) + 8 * i;
-#pragma unroll
-            for (int j = 0; j < 4; j++) lds[k * LDS_LD + rq * 4 + j] = reg[4 * i + j];
+            for (int j = 0; j < 4; j++) {
+                float v = reg[4 * i + j];
+                if constexpr (MASK) v = (k0 + k < kmax && r0 + r + j < rmax) ? v : 0.f;
+                lds[k * LD + r + j] = v;
+            }
         }
     }
 }
 
-template <bool A_KC, bool B_KC, bool VEC_A, bool VEC_B>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g)
+template <bool KC, int ROWS, int BK, int NT, int NV, int LD>
+__device__ __forceinline__ void store_tile(float *lds, const float (&reg)[NV * 4], int tid, bool full, int64_t r0, int64_t rmax,
+                                           int64_t k0, int64_t kmax)
 {
-    __shared__ float lds[2][2][BK * LDS_LD];  // [buffer][A|B]
+    if (full) store_tile_impl<KC, false, ROWS, BK, NT, NV, LD>(lds, reg, tid, r0, rmax, k0, kmax);
+    else store_tile_impl<KC, true, ROWS, BK, NT, NV, LD>(lds, reg, tid, r0, rmax, k0, kmax);
+}
+
+template <class C, bool A_KC, bool B_KC, bool VEC_A, bool VEC_B>
+__global__ __launch_bounds__(C::NT) void gemm_kernel(GemmArgs g)
+{
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NT = C::NT, TM = C::TM, TN = C::TN, LDA = C::LDA, LDB = C::LDB;
+    extern __shared__ float lds_raw[];  // [2][BK*LDA] A tiles, then [2][BK*LDB] B tiles
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;  // 2 x 2 wavefronts
+    const int wm = wave / C::WN, wn = wave % C::WN;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
     const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+    const bool full_mn = m0 + BM <= g.M && n0 + BN <= g.N;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+        for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-    float ra[16], rb[16];
+    constexpr int STORE_AT = (BK * 3 / 4) & ~1;  // k-step after which the next tile is written to LDS
+    float ra[C::A_VECS * 4], rb[C::B_VECS * 4];
     int buf = 0;
     if (kbeg < kend) {
-        load_tile<A_KC, VEC_A>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid);
-        load_tile<B_KC, VEC_B>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
-        store_tile<A_KC>(lds[0][0], ra, tid);
-        store_tile<B_KC>(lds[0][1], rb, tid);
+        const bool full = full_mn && kbeg + BK <= kend;
+        load_tile<A_KC, VEC_A, BM, BK, NT, C::A_VECS>(ra, g.A, g.lda, m0, g.M, kbeg, kend, tid);
+        load_tile<B_KC, VEC_B, BN, BK, NT, C::B_VECS>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+        store_tile<A_KC, BM, BK, NT, C::A_VECS, LDA>(lds_raw, ra, tid, full, m0, g.M, kbeg, kend);
+        store_tile<B_KC, BN, BK, NT, C::B_VECS, LDB>(lds_raw + 2 * BK * LDA, rb, tid, full, n0, g.N, kbeg, kend);
     }
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {  // next tile: HBM -> registers, in flight during the MFMAs below
-            load_tile<A_KC, VEC_A>(ra, g.A, g.lda, m0, g.M, k0 + BK, kend, tid);
-            load_tile<B_KC, VEC_B>(rb, g.B, g.ldb, n0, g.N, k0 + BK, kend, tid);
+            load_tile<A_KC, VEC_A, BM, BK, NT, C::A_VECS>(ra, g.A, g.lda, m0, g.M, k0 + BK, kend, tid);
+            load_tile<B_KC, VEC_B, BN, BK, NT, C::B_VECS>(rb, g.B, g.ldb, n0, g.N, k0 + BK, kend, tid);
         }
-        const float *As = lds[buf][0] + wm * 64 + (lane & 31);
-        const float *Bs = lds[buf][1] + wn * 64 + (lane & 31);
-        const int kh = lane >> 5;
+        const float *As = lds_raw + buf * BK * LDA + wm * (BM / C::WM) + (lane & 31) + (lane >> 5) * LDA;
+        const float *Bs = lds_raw + 2 * BK * LDA + buf * BK * LDB + wn * (BN / C::WN) + (lane & 31) + (lane >> 5) * LDB;
+        // MFMA operand fragments are read one k-step ahead of their use (two register sets, static indices)
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) a[0][i] = As[32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; j++) b[0][j] = Bs[32 * j];
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            float a0 = As[(kk + kh) * LDS_LD], a1 = As[(kk + kh) * LDS_LD + 32];
-            float b0 = Bs[(kk + kh) * LDS_LD], b1 = Bs[(kk + kh) * LDS_LD + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (more) {
-            store_tile<A_KC>(lds[buf ^ 1][0], ra, tid);
-            store_tile<B_KC>(lds[buf ^ 1][1], rb, tid);
+            const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+            if (kk + 2 < BK) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) a[nxt][i] = As[(kk + 2) * LDA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; j++) b[nxt][j] = Bs[(kk + 2) * LDB + 32 * j];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the fragment reads of step kk+2 AHEAD of the MFMAs of step kk
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk == STORE_AT && more) {
+                // tile t+1: registers -> the OTHER LDS buffer, three quarters into the MFMAs of tile t: the HBM loads
+                // issued at the top have landed by now and the ds_writes hide under the remaining MFMAs, so only the
+                // barrier itself sits between two tiles
+                const bool full = full_mn && k0 + 2 * BK <= kend;
+                store_tile<A_KC, BM, BK, NT, C::A_VECS, LDA>(lds_raw + (buf ^ 1) * BK * LDA, ra, tid, full, m0, g.M, k0 + BK, kend);
+                store_tile<B_KC, BN, BK, NT, C::B_VECS, LDB>(lds_raw + 2 * BK * LDA + (buf ^ 1) * BK * LDB, rb, tid, full, n0, g.N,
+                                                             k0 + BK, kend);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();
         buf ^= 1;
@@ -184,23 +213,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g)
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float *out = g.slab ? g.slab + (int64_t)blockIdx.z * g.M * g.N : g.C;
     const int64_t ldo = g.slab ? g.N : g.ldc;
+    const float alpha = g.slab ? 1.f : g.alpha;
+    const float beta = g.slab ? 0.f : g.beta;
+    float *obase = out + (m0 + wm * (BM / C::WM) + 4 * (lane >> 5)) * ldo + n0 + wn * (BN / C::WN) + (lane & 31);
+    if (full_mn && beta == 0.f) {  // hot case: no bounds checks, no read-modify-write, no branches between stores
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            int64_t col = n0 + wn * 64 + j * 32 + (lane & 31);
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    obase[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32] = alpha * acc[i][j][r];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int64_t col = n0 + wn * (BN / C::WN) + j * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int64_t row = m0 + wm * (BM / C::WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < g.M && col < g.N) {
-                    float v = acc[i][j][r];
-                    if (g.slab) {
-                        out[row * ldo + col] = v;
-                    } else {
-                        v *= g.alpha;
-                        if (g.beta != 0.f) v += g.beta * out[row * ldo + col];
-                        out[row * ldo + col] = v;
-                    }
+                    float v = alpha * acc[i][j][r];
+                    if (beta != 0.f) v += beta * out[row * ldo + col];
+                    out[row * ldo + col] = v;
                 }
             }
         }
@@ -222,10 +259,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *slab, i
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+using CfgDefault = Cfg<128, 128, 32, 2, 2>;  // 256 threads, 66 KB LDS, 2 workgroups per CU
+using CfgWide = Cfg<128, 256, 16, 2, 4>;     // 512 threads, 49 KB LDS: one pass over A for 256-wide outputs
+using CfgK16 = Cfg<128, 128, 16, 2, 2>;      // 33 KB LDS: 3 workgroups per CU
+
+// Default: the 128 x 256 tile whenever the output is wider than 128 columns (A is then streamed once for a 256-wide
+// output: 115 vs 111 TFLOP/s at the bench shape), else 128 x 128.  GNNX_GEMM_TILE=square|wide|k16 forces one (A/B runs).
+int tile_variant()
+{
+    static const int v = [] {
+        const char *e = getenv("GNNX_GEMM_TILE");
+        if (!e) return 1;
+        return !strcmp(e, "wide") ? 1 : (!strcmp(e, "k16") ? 2 : 0);
+    }();
+    return v;
+}
+
+struct TileDims { int bm, bn, bk; };
+TileDims tile_dims(int64_t N)
+{
+    int v = tile_variant();
+    if (v == 1 && N > 128) return {CfgWide::BM, CfgWide::BN, CfgWide::BK};
+    if (v == 2) return {CfgK16::BM, CfgK16::BN, CfgK16::BK};
+    return {CfgDefault::BM, CfgDefault::BN, CfgDefault::BK};
+}
+
 int choose_splits(int64_t M, int64_t N, int64_t K)
 {
-    int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
-    int64_t ksteps = ceil_div(K, BK);
+    TileDims t = tile_dims(N);
+    int64_t tiles = ceil_div(M, t.bm) * ceil_div(N, t.bn);
+    int64_t ksteps = ceil_div(K, t.bk);
     int64_t want = ceil_div(4 * kNumCU, tiles);  // ~4 workgroups per CU
     if (want > ksteps / 8) want = ksteps / 8;    // keep >= 8 K-steps per split
     if (want < 1) want = 1;
@@ -233,16 +296,38 @@ int choose_splits(int64_t M, int64_t N, int64_t K)
     return (int)want;
 }
 
+template <class C, bool A_KC, bool B_KC, bool VA, bool VB>
+int launch_one(const GemmArgs &g, int splits, hipStream_t st)
+{
+    dim3 grid((uint32_t)ceil_div(g.N, C::BN), (uint32_t)ceil_div(g.M, C::BM), (uint32_t)splits);
+    constexpr size_t lds = sizeof(float) * 2 * C::BK * (C::LDA + C::LDB);
+    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in, once per kernel instantiation
+    if (!attr_set) {
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<C, A_KC, B_KC, VA, VB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<C, A_KC, B_KC, VA, VB>), grid, dim3(C::NT), lds, st, g);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+template <class C, bool A_KC, bool B_KC>
+int launch_cfg(const GemmArgs &g, int splits, bool va, bool vb, hipStream_t st)
+{
+    if (va && vb) return launch_one<C, A_KC, B_KC, true, true>(g, splits, st);
+    if (va) return launch_one<C, A_KC, B_KC, true, false>(g, splits, st);
+    if (vb) return launch_one<C, A_KC, B_KC, false, true>(g, splits, st);
+    return launch_one<C, A_KC, B_KC, false, false>(g, splits, st);
+}
+
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs &g, int splits, bool va, bool vb, hipStream_t st)
 {
-    dim3 grid((uint32_t)ceil_div(g.N, BN), (uint32_t)ceil_div(g.M, BM), (uint32_t)splits);
-    if (va && vb) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true, true>), grid, dim3(256), 0, st, g);
-    else if (va) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, true, false>), grid, dim3(256), 0, st, g);
-    else if (vb) hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, false, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_kernel<A_KC, B_KC, false, false>), grid, dim3(256), 0, st, g);
-    GNNX_LAUNCH_CHECK();
-    return GNNX_OK;
+    int v = tile_variant();
+    if (v == 1 && g.N > 128) return launch_cfg<CfgWide, A_KC, B_KC>(g, splits, va, vb, st);
+    if (v == 2) return launch_cfg<CfgK16, A_KC, B_KC>(g, splits, va, vb, st);
+    return launch_cfg<CfgDefault, A_KC, B_KC>(g, splits, va, vb, st);
 }
 
 }  // namespace
@@ -280,8 +365,9 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     const bool vb = aligned16(d_B) && ldb % 4 == 0 && (b_kc ? K % 4 == 0 : N % 4 == 0);
     int splits = 1;
     if (transA && K > 0) splits = choose_splits(M, N, K);
-    int64_t ksteps = ceil_div(K > 0 ? K : 1, BK);
-    g.k_per_split = ceil_div(ksteps, splits) * BK;
+    const int bk = tile_dims(N).bk;
+    int64_t ksteps = ceil_div(K > 0 ? K : 1, bk);
+    g.k_per_split = ceil_div(ksteps, splits) * bk;
     if (splits > 1) {
         size_t need = sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
         GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu",
