@@ -15,8 +15,58 @@ constexpr int kMaxBlocks = 2048;  // 256 CUs x 8 blocks/CU
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- colsum: stage 1 -- each workgroup reduces a contiguous slab of rows to one partial row ---------
-// Thread t owns feature columns {t, t+256, ...} (coalesced along the row), walks its slab's rows
-// sequentially; stage 2 adds the partial rows in slab order.  Fixed grid => deterministic.
+// Vector form (F % 4 == 0, 16-B aligned): a row is covered by L = F/4 lanes (16 B each, coalesced); the 256
+// threads form 256/L row groups that walk the slab interleaved, 4 rows in flight per thread; the groups'
+// partials are combined through LDS in group order.  Fixed grid and fixed order => deterministic.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void colsum_stage1_vec(const float *G, int64_t ldg, int64_t n_rows, int32_t n_feat,
+                                                          int64_t rows_per_block, float *partial)
+{
+    __shared__ float4 red[256];
+    const int L = n_feat / 4;            // lanes per row (<= 256)
+    const int groups = 256 / L;          // row groups per pass
+    const int li = threadIdx.x % L, grp = threadIdx.x / L;
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+    for (int f0 = 0; f0 < n_feat; f0 += 4 * L) {  // one iteration unless F > 1024
+        float4 acc[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp < groups && f0 + 4 * li < n_feat) {
+            const float *base = G + f0 + 4 * li;
+            int64_t r = r0 + grp;
+            for (; r + (int64_t)(UNROLL - 1) * groups < r1; r += (int64_t)UNROLL * groups) {
+                float4 v[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) v[u] = *reinterpret_cast<const float4 *>(base + (r + (int64_t)u * groups) * ldg);
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
+                }
+            }
+            for (; r < r1; r += groups) {
+                float4 v = *reinterpret_cast<const float4 *>(base + r * ldg);
+                acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+            }
+        }
+        float4 t = acc[0];
+#pragma unroll
+        for (int u = 1; u < UNROLL; u++) { t.x += acc[u].x; t.y += acc[u].y; t.z += acc[u].z; t.w += acc[u].w; }
+        red[threadIdx.x] = t;
+        __syncthreads();
+        if (grp == 0 && f0 + 4 * li < n_feat) {
+            float4 s4 = red[li];
+            for (int k = 1; k < groups; k++) {
+                float4 o = red[k * L + li];
+                s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+            }
+            *reinterpret_cast<float4 *>(partial + (int64_t)blockIdx.x * n_feat + f0 + 4 * li) = s4;
+        }
+        __syncthreads();
+    }
+}
+
+// Scalar form: thread t owns feature columns {t, t+256, ...}
 __global__ __launch_bounds__(256) void colsum_stage1(const float *G, int64_t ldg, int64_t n_rows, int32_t n_feat,
                                                       int64_t rows_per_block, float *partial)
 {
@@ -69,7 +119,7 @@ __global__ void colsum_stage2(const float *partial, int32_t n_blocks, int32_t n_
 int colsum_blocks(int64_t n_rows)
 {
     int64_t b = ceil_div(n_rows, 64);
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
 // ---- row-wise elementwise -------------------------------------------------------------------------
@@ -208,7 +258,11 @@ GNNX_API int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int3
     GNNX_REQUIRE(n_rows == 0 || (d_G && ldg >= n_feat), GNNX_ERR_INVALID_ARG, "G null or ld < n_feat");
     float *partial = static_cast<float *>(d_workspace);
     int64_t rpb = ceil_div(n_rows > 0 ? n_rows : 1, nb);
-    if (n_feat >= 128) {
+    const bool vec = n_feat % 4 == 0 && ldg % 4 == 0 && aligned16(d_G) && aligned16(partial) && n_feat / 4 <= 256 &&
+                     256 % (n_feat / 4) == 0;
+    if (vec) {
+        hipLaunchKernelGGL(colsum_stage1_vec<4>, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial);
+    } else if (n_feat >= 128) {
         hipLaunchKernelGGL(colsum_stage1, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial);
     } else {
         int fw = 1;

@@ -210,6 +210,13 @@ class tensor : public std::enable_shared_from_this<tensor<T>> {
         lhs->assign_from(*out);
         return lhs;
     }
+    friend tptr<T> operator+=(tptr<T> lhs, const float &rhs)
+    {
+        lhs->check_in_place();
+        auto out = lhs + rhs;
+        lhs->assign_from(*out);
+        return lhs;
+    }
 
 public:
     typedef T value_type;
@@ -312,6 +319,21 @@ public:
         if (typeid(T) != typeid(float)) throw std::runtime_error(ERROR_GRAD_DTYPE);
         _grad = std::make_shared<detail::Store<float>>(numel());
         _grad->adopt_host(new std::valarray<float>(0.0f, numel()));
+    }
+
+    // drop / insert size-1 dimensions (reference tensor.h:232-252); metadata only
+    void squeeze()
+    {
+        require_dense();
+        _dims.erase(std::remove(_dims.begin(), _dims.end(), (size_t)1), _dims.end());
+        if (_dims.empty()) _dims.push_back(1);
+    }
+    tptr<T> unsqueeze(int dim)
+    {
+        require_dense();
+        CHECK_VALID_RANGE(dim, rank() + 1, -rank() - 1);
+        _dims.insert(_dims.begin() + (dim < 0 ? dim + rank() + 1 : dim), 1);
+        return this->shared_from_this();
     }
 
     // ---- autograd entry (reference tensor.h:260-276)

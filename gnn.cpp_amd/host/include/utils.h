@@ -15,6 +15,7 @@
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <valarray>
 #include <vector>
 
 // message texts: part of the API contract (compared verbatim by callers)
@@ -92,6 +93,14 @@ inline void CHECK_TRANSPOSE(const std::vector<size_t> &s, int a, int b)
 {
     const int n = (int)s.size();
     if (a < -n || a >= n || b < -n || b >= n || std::abs(a - b) != 1) throw std::runtime_error(ERROR_TRANSPOSE);
+}
+
+// new std::valarray<T>(value, prod(dims)) -- the buffer a tensor constructor adopts (reference utils.h:150-158)
+template <class T>
+std::valarray<T> *initialize(const std::vector<size_t> &dims, T value = 0)
+{
+    CHECK_VALID_DIMS(dims);
+    return new std::valarray<T>(value, numel_of(dims));
 }
 
 namespace cyg {

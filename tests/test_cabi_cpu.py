@@ -99,3 +99,11 @@ def test_reference_driver_compiles_unchanged_against_the_host_api(capi):
     assert os.path.exists(drv)
     r = subprocess.run([drv], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr  # loads (links libgnnx_hip.so) and parses args without a GPU
+
+
+def test_host_api_conventions_cpu(capi):
+    """tests/cpp/test_host_api_cpu.cpp: the reference's own tensor / module assertions, against the mirror API."""
+    import os
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_api_cpu")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "HOST_API_CPU_OK" in r.stdout, r.stdout + r.stderr
