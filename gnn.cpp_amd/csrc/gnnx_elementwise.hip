@@ -107,13 +107,30 @@ __global__ __launch_bounds__(256) void colsum_stage1_narrow(const float *G, int6
     }
 }
 
-__global__ void colsum_stage2(const float *partial, int32_t n_blocks, int32_t n_feat, float beta, float *out)
+// stage 2: out[f] = beta*out[f] + sum_b partial[b][f].  64 columns per workgroup, 4 interleaved row parts per column
+// (each walks every 4th partial row with 4 loads in flight), combined in part order through LDS: deterministic.
+__global__ __launch_bounds__(256) void colsum_stage2(const float *partial, int32_t n_blocks, int32_t n_feat, float beta, float *out)
 {
-    int32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_feat) return;
-    float acc = 0.f;
-    for (int32_t b = 0; b < n_blocks; b++) acc += partial[(int64_t)b * n_feat + f];
-    out[f] = beta != 0.f ? out[f] + acc : acc;
+    __shared__ float red[256];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int32_t f = blockIdx.x * 64 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (f < n_feat) {
+        int32_t b = part;
+        for (; b + 12 < n_blocks; b += 16) {
+            a0 += partial[(int64_t)b * n_feat + f];
+            a1 += partial[(int64_t)(b + 4) * n_feat + f];
+            a2 += partial[(int64_t)(b + 8) * n_feat + f];
+            a3 += partial[(int64_t)(b + 12) * n_feat + f];
+        }
+        for (; b < n_blocks; b += 4) a0 += partial[(int64_t)b * n_feat + f];
+    }
+    red[threadIdx.x] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (part == 0 && f < n_feat) {
+        float acc = ((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c];
+        out[f] = beta != 0.f ? out[f] + acc : acc;
+    }
 }
 
 int colsum_blocks(int64_t n_rows)
@@ -270,7 +287,7 @@ GNNX_API int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int3
         hipLaunchKernelGGL(colsum_stage1_narrow, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, fw, rpb, partial);
     }
     GNNX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 256)), dim3(256), 0, st, partial, nb, n_feat, beta,
+    hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta,
                        d_out);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
