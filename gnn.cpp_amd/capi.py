@@ -82,6 +82,11 @@ _SIGS = {
     "gnnx_pow_f32": [_vp, _i64, _f32, _vp, _vp],
     "gnnx_csr_rowsum_f32": [_vp, _vp, _i32, _vp, _vp],
     "gnnx_transpose_f32": [_vp, _i64, _i64, _i64, _vp, _i64, _vp],
+    "gnnx_bn_workspace": [_i64, _i32, C.POINTER(_sz)],
+    "gnnx_bn_stats_f32": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
+    "gnnx_bn_relu_fwd_f32": [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp],
+    "gnnx_bn_relu_bwd_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp, _sz,
+                             _vp],
     "gnnx_gather_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_scatter_add_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_rmat_edges": [_u64, _i32, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp],

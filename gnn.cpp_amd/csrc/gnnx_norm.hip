@@ -1,0 +1,256 @@
+// BatchNorm (training-mode batch statistics) + ReLU between the transform and the aggregation of GCNConv::forward
+// (reference graph.cpp:174-175 -> nn.cpp:285-330 BatchNorm::forward, nn.cpp:229-237 ReLU::forward) -- the first
+// "next" row of SURVEY.md section 8(f).  HBM-bound streaming kernels:
+//   stats    mean_f = (1/N) sum_i x_if ;  var_f = (1/N) sum_i (x_if - mean_f)^2   (x->mean(-2), x->var(-2, correction 0))
+//   forward  y = relu( ((x - mean) / (var + eps)^0.5) * gamma + beta )             each op separately rounded, in the
+//            reference's order (sub, div, mul, add); relu = where(x > 0, x, 0)
+//   backward (mathematically correct; the reference's own is fan-in-dropping, operation.h:82-86):
+//            g = dY * (y > 0);  dbeta = sum g;  dgamma = sum g * xhat;  dx = (gamma / sigma) * (g - dbeta/N - xhat * dgamma/N)
+// Column reductions use a fixed grid + fixed combine order (deterministic).
+#include "gnnx_common.h"
+
+#pragma clang fp contract(off)
+
+using namespace gnnx;
+
+namespace {
+
+constexpr int kBlocks = 1024;
+
+// Generic column reduction of up to two per-element terms.  Thread -> (row slot rr, column f) with fw columns per
+// pass; rows of the workgroup's slab are walked by the slots interleaved, 4 in flight; slots combined through LDS.
+template <class OP>
+__global__ __launch_bounds__(256) void colreduce_stage1(OP op, int64_t n_rows, int32_t n_feat, int32_t fw, int64_t rows_per_block,
+                                                         float *partial0, float *partial1)
+{
+    __shared__ float red0[256], red1[256];
+    const int rpp = 256 / fw;
+    const int c = threadIdx.x % fw, rr = threadIdx.x / fw;
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+    for (int32_t f0 = 0; f0 < n_feat; f0 += fw) {
+        const int32_t f = f0 + c;
+        float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+        if (f < n_feat && rr < rpp) {
+            int64_t r = r0 + rr;
+            for (; r + 3 * (int64_t)rpp < r1; r += 4 * (int64_t)rpp) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) op.term(r + u * (int64_t)rpp, f, a0[u], a1[u]);
+            }
+            for (; r < r1; r += rpp) op.term(r, f, a0[0], a1[0]);
+        }
+        red0[threadIdx.x] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+        if (OP::kTwo) red1[threadIdx.x] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+        __syncthreads();
+        if (rr == 0 && f < n_feat) {
+            float s0 = 0.f, s1 = 0.f;
+            for (int k = 0; k < rpp; k++) {
+                s0 += red0[k * fw + c];
+                if (OP::kTwo) s1 += red1[k * fw + c];
+            }
+            partial0[(int64_t)blockIdx.x * n_feat + f] = s0;
+            if (OP::kTwo) partial1[(int64_t)blockIdx.x * n_feat + f] = s1;
+        }
+        __syncthreads();
+    }
+}
+
+// out[f] = scale * sum_b partial[b][f]
+__global__ __launch_bounds__(256) void colreduce_stage2(const float *partial, int32_t n_blocks, int32_t n_feat, float scale, float *out)
+{
+    __shared__ float red[256];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int32_t f = blockIdx.x * 64 + c;
+    float acc = 0.f;
+    if (f < n_feat)
+        for (int32_t b = part; b < n_blocks; b += 4) acc += partial[(int64_t)b * n_feat + f];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (part == 0 && f < n_feat) out[f] = (((red[c] + red[64 + c]) + red[128 + c]) + red[192 + c]) * scale;
+}
+
+struct OpIdent {
+    static constexpr bool kTwo = false;
+    const float *X;
+    int64_t ldx;
+    __device__ __forceinline__ void term(int64_t r, int32_t f, float &a0, float &) const { a0 += X[r * ldx + f]; }
+};
+struct OpSqDev {
+    static constexpr bool kTwo = false;
+    const float *X;
+    int64_t ldx;
+    const float *mean;
+    __device__ __forceinline__ void term(int64_t r, int32_t f, float &a0, float &) const
+    {
+        float d = X[r * ldx + f] - mean[f];
+        a0 += d * d;
+    }
+};
+// g = dY * (Y > 0 or no relu);  sums of g and of g * xhat
+struct OpBnBwd {
+    static constexpr bool kTwo = true;
+    const float *X, *Y, *dY, *mean, *rstd;
+    int64_t ldx, ldy, ldd;
+    int relu;
+    __device__ __forceinline__ void term(int64_t r, int32_t f, float &a0, float &a1) const
+    {
+        float g = dY[r * ldd + f];
+        if (relu && !(Y[r * ldy + f] > 0.f)) g = 0.f;
+        float xhat = (X[r * ldx + f] - mean[f]) * rstd[f];
+        a0 += g;
+        a1 += g * xhat;
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float *X, int64_t ldx, int64_t n_rows, int32_t n_feat, const float *mean,
+                                                      const float *var, float eps, const float *gamma, const float *beta, int relu,
+                                                      float *Y, int64_t ldy)
+{
+    int64_t total = n_rows * n_feat;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i / n_feat;
+        int32_t f = (int32_t)(i - r * n_feat);
+        float v = X[r * ldx + f];
+        if (mean) {
+            float sd = sqrtf(__fadd_rn(var[f], eps));           // (var + eps)->pow(0.5)
+            v = __fdiv_rn(__fsub_rn(v, mean[f]), sd);             // (x - mean) / sd
+            if (gamma) v = __fmul_rn(v, gamma[f]);                // * gammas
+            if (beta) v = __fadd_rn(v, beta[f]);                  // + betas
+        }
+        if (relu) v = v > 0.f ? v : 0.f;                          // where(x > 0, x, 0)
+        Y[r * ldy + f] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void rstd_kernel(const float *var, float eps, int32_t n_feat, float *rstd)
+{
+    int32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f < n_feat) rstd[f] = 1.0f / sqrtf(var[f] + eps);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t ldd,
+                                                      int64_t n_rows, int32_t n_feat, const float *mean, const float *rstd,
+                                                      const float *gamma, const float *dbeta, const float *dgamma, int relu, float *dX,
+                                                      int64_t ldo)
+{
+    int64_t total = n_rows * n_feat;
+    const float inv_n = 1.0f / (float)n_rows;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i / n_feat;
+        int32_t f = (int32_t)(i - r * n_feat);
+        float g = dY[r * ldd + f];
+        if (relu && !(Y[r * ldy + f] > 0.f)) g = 0.f;
+        if (mean) {
+            float xhat = (X[r * ldx + f] - mean[f]) * rstd[f];
+            float gm = gamma ? gamma[f] : 1.f;
+            g = gm * rstd[f] * (g - dbeta[f] * inv_n - xhat * dgamma[f] * inv_n);
+        }
+        dX[r * ldo + f] = g;
+    }
+}
+
+int pick_fw(int32_t n_feat)
+{
+    int fw = 1;
+    while (fw < n_feat && fw < 256) fw <<= 1;
+    return fw;
+}
+int n_blocks_for(int64_t n_rows)
+{
+    int64_t b = ceil_div(n_rows, 64);
+    return (int)(b < 1 ? 1 : (b > kBlocks ? kBlocks : b));
+}
+
+template <class OP>
+int reduce(OP op, int64_t n_rows, int32_t n_feat, float scale, float *out0, float *out1, float *ws, hipStream_t st)
+{
+    int nb = n_blocks_for(n_rows);
+    int64_t rpb = ceil_div(n_rows > 0 ? n_rows : 1, nb);
+    float *p0 = ws, *p1 = ws + (size_t)nb * n_feat;
+    hipLaunchKernelGGL(colreduce_stage1<OP>, dim3(nb), dim3(256), 0, st, op, n_rows, n_feat, pick_fw(n_feat), rpb, p0, p1);
+    GNNX_LAUNCH_CHECK();
+    dim3 g2((uint32_t)ceil_div(n_feat, 64));
+    hipLaunchKernelGGL(colreduce_stage2, g2, dim3(256), 0, st, p0, nb, n_feat, scale, out0);
+    GNNX_LAUNCH_CHECK();
+    if (OP::kTwo) {
+        hipLaunchKernelGGL(colreduce_stage2, g2, dim3(256), 0, st, p1, nb, n_feat, scale, out1);
+        GNNX_LAUNCH_CHECK();
+    }
+    return GNNX_OK;
+}
+
+}  // namespace
+
+GNNX_API int gnnx_bn_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes)
+{
+    GNNX_REQUIRE(bytes && n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    *bytes = sizeof(float) * ((size_t)2 * n_blocks_for(n_rows) + 1) * (size_t)(n_feat > 0 ? n_feat : 1);
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_bn_stats_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, float *d_mean, float *d_var,
+                               void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(n_rows > 0 && n_feat > 0, GNNX_ERR_INVALID_ARG, "empty batch");
+    GNNX_REQUIRE(d_X && d_mean && d_var && ldx >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    size_t need = 0;
+    gnnx_bn_workspace(n_rows, n_feat, &need);
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    float *ws = static_cast<float *>(d_workspace);
+    const float inv_n = 1.0f / (float)n_rows;
+    int rc = reduce(OpIdent{d_X, ldx}, n_rows, n_feat, inv_n, d_mean, nullptr, ws, st);
+    if (rc) return rc;
+    return reduce(OpSqDev{d_X, ldx, d_mean}, n_rows, n_feat, inv_n, d_var, nullptr, ws, st);
+}
+
+GNNX_API int gnnx_bn_relu_fwd_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const float *d_mean,
+                                  const float *d_var, float eps, const float *d_gamma, const float *d_beta, int relu, float *d_Y,
+                                  int64_t ldy, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0 || n_feat == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_X && d_Y && ldx >= n_feat && ldy >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    GNNX_REQUIRE((d_mean == nullptr) == (d_var == nullptr), GNNX_ERR_INVALID_ARG, "mean and var go together");
+    int64_t blocks = ceil_div(n_rows * n_feat, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_feat, d_mean, d_var,
+                       eps, d_gamma, d_beta, relu, d_Y, ldy);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
+                                  int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps,
+                                  const float *d_gamma, int relu, float *d_dX, int64_t ldo, float *d_dgamma, float *d_dbeta,
+                                  void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(n_rows > 0 && n_feat > 0, GNNX_ERR_INVALID_ARG, "empty batch");
+    GNNX_REQUIRE(d_X && d_dY && d_dX && ldx >= n_feat && ldd >= n_feat && ldo >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld");
+    GNNX_REQUIRE(!relu || (d_Y && ldy >= n_feat), GNNX_ERR_INVALID_ARG, "relu backward needs the forward output");
+    GNNX_REQUIRE((d_mean == nullptr) == (d_var == nullptr), GNNX_ERR_INVALID_ARG, "mean and var go together");
+    hipStream_t st = as_stream(stream);
+    int64_t blocks = ceil_div(n_rows * n_feat, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (!d_mean) {  // ReLU only
+        hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat,
+                           (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
+                           (const float *)nullptr, relu, d_dX, ldo);
+        GNNX_LAUNCH_CHECK();
+        return GNNX_OK;
+    }
+    GNNX_REQUIRE(d_dgamma && d_dbeta, GNNX_ERR_INVALID_ARG, "dgamma / dbeta outputs are required");
+    size_t need = 0;
+    gnnx_bn_workspace(n_rows, n_feat, &need);
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+    float *ws = static_cast<float *>(d_workspace);
+    float *rstd = ws + (size_t)2 * n_blocks_for(n_rows) * n_feat;
+    hipLaunchKernelGGL(rstd_kernel, dim3((uint32_t)ceil_div(n_feat, 256)), dim3(256), 0, st, d_var, eps, n_feat, rstd);
+    GNNX_LAUNCH_CHECK();
+    int rc = reduce(OpBnBwd{d_X, d_Y, d_dY, d_mean, rstd, ldx, ldy, ldd, relu}, n_rows, n_feat, 1.0f, d_dbeta, d_dgamma, ws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean,
+                       (const float *)rstd, d_gamma, (const float *)d_dbeta, (const float *)d_dgamma, relu, d_dX, ldo);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}

@@ -68,15 +68,15 @@ public:
 class GCNConv : public MessagePassing {
 public:
     GCNConv(size_t in_channels, size_t out_channels, float dropout = 0.0);
-    // transform -> (BatchNorm -> ReLU: next row) -> normalised aggregation -> + bias   (reference graph.cpp:170-191)
+    // transform -> BatchNorm -> ReLU -> normalised aggregation -> + bias   (reference graph.cpp:170-191)
     cyg::tptr<float> forward(Data &&input) override;
     using MessagePassing::forward;
     cyg::tptr<float> propagate(const cyg::tensor<int> &edge_index, const cyg::tptr<float> &x, const cyg::tptr<float> *others) override;
     cyg::tptr<float> aggregate_and_update(const cyg::tptr<float> &x, const cyg::tensor<int> &edge_index, const cyg::tptr<float> *other) override;
 
-    // hot_path_only = true skips the BatchNorm/ReLU pair between transform and aggregation (they are a "next"
-    // row); with false, forward() throws at BatchNorm until that row is built.
-    bool hot_path_only = true;
+    // false (default): the reference's full layer, transform -> BatchNorm -> ReLU -> aggregation -> bias.
+    // true: only the hot path of BASELINE.json (transform -> aggregation -> bias).
+    bool hot_path_only = false;
     size_t _in_channels, _out_channels;
     float _dropout;
 };

@@ -1,8 +1,7 @@
-// nn.h -- nn::Module registry and nn::Linear of the reference API (reference include/nn.h:28-73,
-// src/nn.cpp:12-211) over the MI355X tensor backend.  Only what the GCN hot path touches is implemented:
-// the module / parameter registry GCNConv relies on (`get_module("lin")`, `get_parameter("bias")`,
-// reference graph.cpp:173,188) and Linear (the dense X.W^T step).  BatchNorm / ReLU / Dropout are registered by
-// GCNConv like in the reference but are "next" rows of SURVEY.md section 8(f): their forward throws here.
+// nn.h -- nn::Module registry, nn::Linear, nn::BatchNorm and nn::ReLU of the reference API (reference
+// include/nn.h:28-123, src/nn.cpp:12-330) over the MI355X tensor backend.  Only what GCNConv touches is implemented:
+// the module / parameter registry (`get_module("lin")`, `get_parameter("bias")`, reference graph.cpp:173,188),
+// Linear (the dense X.W^T step) and the BatchNorm + ReLU pair between transform and aggregation (graph.cpp:174-175).
 #ifndef GNNCPP_AMD_NN_H
 #define GNNCPP_AMD_NN_H
 
@@ -59,27 +58,36 @@ public:
     size_t _in_features, _out_features;
 };
 
-// Registered by GCNConv exactly like the reference does (graph.cpp:163-165); not on the hot path.
-class NotOnHotPath : public Module {
+// BatchNorm over the node dimension with batch statistics, y = ((x - mean) / (var + eps)^0.5) * gammas + betas
+// (reference nn.cpp:285-330).  Like the reference, the running statistics are registered but never updated by
+// forward (the reference assigns them to temporaries, nn.cpp:323-324); in eval mode they are what normalises.
+// Backward is the mathematically correct one (the reference's own drops fan-in gradients, operation.h:82-86).
+class BatchNorm : public Module {
 public:
-    explicit NotOnHotPath(const std::string &n) : Module(n) {}
+    explicit BatchNorm(const size_t &num_features, const float &eps = 1e-05, const float &momentum = 0.1, const bool &affine = true,
+                       const bool &track_running_stats = true, const std::string &n = "BatchNorm");
+    cyg::tptr<float> forward(const cyg::tptr<float> &x) override;
+
+    size_t _num_features;
+    float _eps, _momentum;
+    bool _affine, _tracking_running_stats;
+};
+
+// max(0, x) as a select (reference nn.cpp:229-237 -> functional.h:443-470)
+class ReLU : public Module {
+public:
+    explicit ReLU(const std::string &n = "ReLU") : Module(n) {}
+    cyg::tptr<float> forward(const cyg::tptr<float> &input_tensor) override;
+};
+
+// Registered by GCNConv like in the reference (graph.cpp:164) and, like there, never applied (graph.cpp:170-191).
+class Dropout : public Module {
+public:
+    explicit Dropout(float p = 0.2f, const std::string &n = "Dropout") : Module(n), _p(p) {}
     cyg::tptr<float> forward(const cyg::tptr<float> &) override
     {
-        throw std::runtime_error(name + ": not implemented by the MI355X backend yet (SURVEY.md section 8(f) 'next' row)");
+        throw std::runtime_error("Dropout: not implemented by the MI355X backend (never applied on the GCN path)");
     }
-};
-class BatchNorm : public NotOnHotPath {
-public:
-    explicit BatchNorm(size_t num_features, float = 1e-5f, float = 0.1f) : NotOnHotPath("BatchNorm"), _num_features(num_features) {}
-    size_t _num_features;
-};
-class ReLU : public NotOnHotPath {
-public:
-    ReLU() : NotOnHotPath("ReLU") {}
-};
-class Dropout : public NotOnHotPath {
-public:
-    explicit Dropout(float p = 0.2f) : NotOnHotPath("Dropout"), _p(p) {}
     float _p;
 };
 

@@ -205,6 +205,129 @@ tptr<float> Linear::forward(const tptr<float> &input_tensor)
     return output;
 }
 
+// ---- BatchNorm / ReLU as autograd ops over the fused device kernels
+namespace {
+class BatchNormOp : public cyg::Operation<tensor<float>> {
+public:
+    float eps = 1e-5f;
+    bool batch_stats = true;
+    tptr<float> mean, var;
+    BatchNormOp() { name = "BatchNorm"; }
+    tptr<float> forward(const tptr<float> &x, const tptr<float> &gamma, const tptr<float> &beta)
+    {
+        const auto shp = x->shape();
+        if (shp.size() != 2) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        const int64_t n = (int64_t)shp[0];
+        const int32_t f = (int32_t)shp[1];
+        void *st = detail::current_stream();
+        size_t wsb = 0;
+        detail::gx(gnnx_bn_workspace(n, f, &wsb), "BatchNorm");
+        if (batch_stats) {
+            mean = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
+            var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
+            detail::gx(gnnx_bn_stats_f32(x->device_data(), f, n, f, mean->device_out(), var->device_out(), detail::workspace(wsb), wsb, st),
+                       "BatchNorm");
+        }
+        const bool req = x->requires_grad() || gamma->requires_grad() || (beta && beta->requires_grad());
+        auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, req);
+        detail::gx(gnnx_bn_relu_fwd_f32(x->device_data(), f, n, f, mean->device_data(), var->device_data(), eps, gamma->device_data(),
+                                        beta ? beta->device_data() : nullptr, 0, out->device_out(), f, st), "BatchNorm");
+        if (req) context->save_for_backward({x, gamma, beta ? beta : gamma});
+        has_beta = (bool)beta;
+        return out;
+    }
+    void _backward(std::shared_ptr<tensor<float>> g) override
+    {
+        if (!batch_stats) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);  // eval-mode backward is not on any path
+        auto var_ = context->get_variables();
+        CHECK_BACKWARD<tensor<float>>(var_, 3);
+        auto x = var_[0], gamma = var_[1], beta = var_[2];
+        const auto shp = x->shape();
+        const int64_t n = (int64_t)shp[0];
+        const int32_t f = (int32_t)shp[1];
+        size_t wsb = 0;
+        detail::gx(gnnx_bn_workspace(n, f, &wsb), "BatchNorm");
+        auto dx = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
+        auto dgamma = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
+        auto dbeta = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
+        detail::gx(gnnx_bn_relu_bwd_f32(x->device_data(), f, nullptr, 0, g->device_data(), f, n, f, mean->device_data(), var->device_data(),
+                                        eps, gamma->device_data(), 0, dx->device_out(), f, dgamma->device_out(), dbeta->device_out(),
+                                        detail::workspace(wsb), wsb, detail::current_stream()), "BatchNorm");
+        if (x->requires_grad()) x->backward(dx);
+        if (gamma->requires_grad()) gamma->backward(dgamma);
+        if (has_beta && beta->requires_grad()) beta->backward(dbeta);
+    }
+    bool has_beta = true;
+};
+
+class ReluOp : public cyg::Operation<tensor<float>> {
+public:
+    ReluOp() { name = "ReLU"; }
+    tptr<float> forward(const tptr<float> &x)
+    {
+        const auto shp = x->shape();
+        if (shp.size() != 2) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, x->requires_grad());
+        detail::gx(gnnx_bn_relu_fwd_f32(x->device_data(), (int64_t)shp[1], (int64_t)shp[0], (int32_t)shp[1], nullptr, nullptr, 0.f, nullptr,
+                                        nullptr, 1, out->device_out(), (int64_t)shp[1], detail::current_stream()), "ReLU");
+        if (out->requires_grad()) {
+            context->save_for_backward({x});
+            y = out.get();  // the output owns this op (grad_fn), so a raw back-pointer cannot dangle
+        }
+        return out;
+    }
+    void _backward(std::shared_ptr<tensor<float>> g) override
+    {
+        auto var_ = context->get_variables();
+        CHECK_BACKWARD<tensor<float>>(var_, 1);
+        auto x = var_[0];
+        const auto shp = x->shape();
+        auto dx = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
+        detail::gx(gnnx_bn_relu_bwd_f32(x->device_data(), (int64_t)shp[1], y->device_data(), (int64_t)shp[1], g->device_data(),
+                                        (int64_t)shp[1], (int64_t)shp[0], (int32_t)shp[1], nullptr, nullptr, 0.f, nullptr, 1,
+                                        dx->device_out(), (int64_t)shp[1], nullptr, nullptr, nullptr, 0, detail::current_stream()), "ReLU");
+        if (x->requires_grad()) x->backward(dx);
+    }
+    tensor<float> *y = nullptr;
+};
+}  // namespace
+
+BatchNorm::BatchNorm(const size_t &num_features, const float &eps, const float &momentum, const bool &affine,
+                     const bool &track_running_stats, const std::string &n)
+    : Module(n), _num_features(num_features), _eps(eps), _momentum(momentum), _affine(affine), _tracking_running_stats(track_running_stats)
+{
+    std::vector<size_t> dims = {1, num_features};
+    register_parameter("gammas", std::make_shared<tensor<float>>(dims, 1.0f, true));
+    if (affine) register_parameter("betas", std::make_shared<tensor<float>>(dims, 0.0f, true));
+    if (_tracking_running_stats) {
+        register_buffer("running_mean", std::make_shared<tensor<float>>(dims, 0.0f, false));
+        register_buffer("running_var", std::make_shared<tensor<float>>(dims, 0.0f, false));
+    }
+    training = true;
+}
+
+tptr<float> BatchNorm::forward(const tptr<float> &x)
+{
+    auto op = std::make_unique<BatchNormOp>();
+    op->eps = _eps;
+    op->batch_stats = training || !_tracking_running_stats;
+    if (!op->batch_stats) {
+        op->mean = get_buffer("running_mean");
+        op->var = get_buffer("running_var");
+    }
+    auto out = op->forward(x, _parameters["gammas"], _affine ? _parameters["betas"] : nullptr);
+    if (out->requires_grad()) out->grad_fn = std::move(op);
+    return out;
+}
+
+tptr<float> ReLU::forward(const tptr<float> &input_tensor)
+{
+    auto op = std::make_unique<ReluOp>();
+    auto out = op->forward(input_tensor);
+    if (out->requires_grad()) out->grad_fn = std::move(op);
+    return out;
+}
+
 }  // namespace nn
 
 // ---------------------------------------------------------------------------------------------------- graph
@@ -322,7 +445,7 @@ GCNConv::GCNConv(size_t in_channels, size_t out_channels, float dropout)
 {
     register_module("lin", new nn::Linear(in_channels, out_channels, false));
     register_module("bnorm", new nn::BatchNorm(out_channels));
-    register_module("drop", new nn::Dropout(dropout));
+    register_module("drop", new nn::Dropout(dropout));  // registered, never applied: as in the reference
     register_module("relu", new nn::ReLU());
     register_parameter("bias", std::make_shared<tensor<float>>(std::vector<size_t>{out_channels}, 0.0f, true));
 }

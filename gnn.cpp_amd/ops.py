@@ -187,6 +187,39 @@ def axpy(a, x, y):
     return y
 
 
+def bn_stats(X):
+    """Batch mean / biased variance per feature (x->mean(-2), x->var(-2, 0); reference nn.cpp:303,312)."""
+    N, F = X.shape
+    mean = torch.empty(F, dtype=torch.float32, device=X.device)
+    var = torch.empty(F, dtype=torch.float32, device=X.device)
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_bn_workspace", N, F, C.byref(wsb))
+    ws = _workspace(wsb.value, X.device, "bn")
+    capi.call("gnnx_bn_stats_f32", _ptr(X), _ld(X), N, F, _ptr(mean), _ptr(var), _ptr(ws), wsb.value, _stream())
+    return mean, var
+
+
+def bn_relu_fwd(X, mean=None, var=None, gamma=None, beta=None, eps=1e-5, relu=True, out=None):
+    out = torch.empty_like(X) if out is None else out
+    capi.call("gnnx_bn_relu_fwd_f32", _ptr(X), _ld(X), X.shape[0], X.shape[1], _ptr(mean), _ptr(var), float(eps), _ptr(gamma),
+              _ptr(beta), int(relu), _ptr(out), _ld(out), _stream())
+    return out
+
+
+def bn_relu_bwd(X, Y, dY, mean=None, var=None, gamma=None, eps=1e-5, relu=True):
+    N, F = X.shape
+    dX = torch.empty_like(X)
+    dgamma = torch.empty(F, dtype=torch.float32, device=X.device) if mean is not None else None
+    dbeta = torch.empty(F, dtype=torch.float32, device=X.device) if mean is not None else None
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_bn_workspace", N, F, C.byref(wsb))
+    ws = _workspace(wsb.value, X.device, "bn")
+    capi.call("gnnx_bn_relu_bwd_f32", _ptr(X), _ld(X), _ptr(Y), _ld(Y) if Y is not None else 0, _ptr(dY), _ld(dY), N, F, _ptr(mean),
+              _ptr(var), float(eps), _ptr(gamma), int(relu), _ptr(dX), _ld(dX), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb.value,
+              _stream())
+    return dX, dgamma, dbeta
+
+
 def rmat_edges(seed, n_nodes, n_edges, a=0.57, b=0.19, c=0.19, device="cuda", first_edge=0):
     src = torch.empty(n_edges, dtype=torch.int32, device=device)
     dst = torch.empty(n_edges, dtype=torch.int32, device=device)

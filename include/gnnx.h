@@ -189,6 +189,28 @@ int gnnx_pow_f32(const float *d_x, int64_t n, float exponent, float *d_y, void *
 int gnnx_csr_rowsum_f32(const int32_t *d_rowptr, const float *d_vals, int32_t n_rows, float *d_out, void *stream);
 int gnnx_transpose_f32(const float *d_X, int64_t ldx, int64_t n_rows, int64_t n_cols, float *d_Y, int64_t ldy, void *stream);
 
+/* ------------------------------------------------------------------ next row: BatchNorm + ReLU ---- */
+/*
+ * The pair that sits between transform and aggregation inside GCNConv::forward (reference graph.cpp:174-175):
+ *   BatchNorm::forward (nn.cpp:301-330, training mode): mean = x->mean(-2,true); var = x->var(-2, 0, true);
+ *       y = ((x - mean) / (var + eps)->pow(0.5)) * gammas + betas     (running stats are never really updated in the
+ *       reference: they are assigned to temporaries, nn.cpp:323-324)
+ *   ReLU::forward (nn.cpp:229-237): where(x > 0, x, 0)
+ * stats : d_mean[F], d_var[F] (biased variance).   fwd: d_mean/d_var may both be NULL (ReLU only); gamma / beta may be NULL.
+ * bwd   : mathematically correct gradients (the reference's own drop fan-in contributions, operation.h:82-86):
+ *         g = dY (.) (Y > 0);  dbeta = colsum g;  dgamma = colsum g (.) xhat;  dX = gamma/sigma (.) (g - dbeta/N - xhat (.) dgamma/N).
+ *         d_Y (the forward output) is only read when relu != 0.  Workspace: gnnx_bn_workspace() bytes.
+ */
+int gnnx_bn_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes);
+int gnnx_bn_stats_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, float *d_mean, float *d_var,
+                      void *d_workspace, size_t workspace_bytes, void *stream);
+int gnnx_bn_relu_fwd_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var,
+                         float eps, const float *d_gamma, const float *d_beta, int relu, float *d_Y, int64_t ldy, void *stream);
+int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd, int64_t n_rows,
+                         int32_t n_feat, const float *d_mean, const float *d_var, float eps, const float *d_gamma, int relu,
+                         float *d_dX, int64_t ldo, float *d_dgamma, float *d_dbeta, void *d_workspace, size_t workspace_bytes,
+                         void *stream);
+
 /* ------------------------------------------------------------------ halo (multi-GPU) ------------- */
 /* Pack rows for the all-to-all-v send buffer: out[k,:] = X[idx[k],:]; and the reverse for backward:
  * Y[idx[k],:] += in[k,:] (idx may repeat across calls but NOT within one call => no atomics, deterministic). */

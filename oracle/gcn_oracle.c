@@ -274,6 +274,55 @@ API void gcn_oracle_dense_aggregate(const int32_t *src, const int32_t *dst, int6
     free(A);
 }
 
+/*
+ * BatchNorm (training mode) + ReLU as GCNConv::forward applies them between transform and aggregation
+ * (graph.cpp:174-175).  Restates nn.cpp:301-330 and nn.cpp:229-237 with their arithmetic order:
+ *   mean_f = (sum_{i ASC} x_if) / (float)N                         functional.h:299-307 (sum materialises => ascending)
+ *   var_f  = (sum_{i DESC} powf(x_if - fl(sum_asc/N), 2)) / max(0,N) functional.h:380-388: std::pow(valarray,2) is an
+ *            expression template, its .sum() walks DOWN; correction = 0 (nn.cpp:312)
+ *   y = ((x - mean) / powf(var + eps, 0.5f)) * gamma + beta          nn.cpp:313-316, each op rounded
+ *   relu: x > 0 ? x : 0                                              functional.h:459-460 (a select)
+ * mean_out / var_out may be NULL.  do_bn = 0 applies only the ReLU.
+ */
+API void gcn_oracle_bn_relu_fwd(const float *X, int64_t N, int32_t F, const float *gamma, const float *beta, float eps, int do_bn,
+                                int do_relu, float *Y, float *mean_out, float *var_out)
+{
+    float *mean = (float *)malloc(sizeof(float) * (size_t)(F > 0 ? F : 1));
+    float *sd = (float *)malloc(sizeof(float) * (size_t)(F > 0 ? F : 1));
+    if (do_bn) {
+        for (int32_t f = 0; f < F; f++) {
+            float s = X[f];
+            for (int64_t i = 1; i < N; i++) s += X[i * F + f];
+            float m = s / (float)(int)N;
+            float d = X[(N - 1) * F + f] - m;
+            float v = powf(d, 2.0f);
+            for (int64_t i = N - 2; i >= 0; i--) {
+                d = X[i * F + f] - m;
+                v += powf(d, 2.0f);
+            }
+            v = v / (float)(int)N;
+            mean[f] = m;
+            sd[f] = powf(v + eps, 0.5f);
+            if (mean_out) mean_out[f] = m;
+            if (var_out) var_out[f] = v;
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < N; i++)
+        for (int32_t f = 0; f < F; f++) {
+            float v = X[i * F + f];
+            if (do_bn) {
+                v = (v - mean[f]) / sd[f];
+                v = v * gamma[f];
+                v = v + beta[f];
+            }
+            if (do_relu) v = v > 0.0f ? v : 0.0f;
+            Y[i * F + f] = v;
+        }
+    free(mean);
+    free(sd);
+}
+
 /* out[d] = powf((float)d, -0.5f) for d in [0,n): the libm call behind functional.h:253 (std::pow on valarrays),
  * exposed so the tests can measure where a device-side (float)(1/sqrt((double)d)) differs from it. */
 API void gcn_oracle_powf_table(int32_t n, float *out)

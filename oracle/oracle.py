@@ -15,7 +15,7 @@ _lib = None
 
 __all__ = ["build", "coo_to_csr", "csr_transpose", "degree_norm", "linear_fwd", "aggregate_fwd",
            "aggregate_bwd", "colsum", "linear_bwd", "dense_aggregate", "set_threads", "max_threads",
-           "powf_table", "gcn_layer_fwd", "gcn_layer_bwd", "ref_driver_path"]
+           "powf_table", "bn_relu_fwd", "gcn_layer_fwd", "gcn_layer_bwd", "ref_driver_path"]
 
 
 def build():
@@ -156,6 +156,20 @@ def dense_aggregate(src, dst, n_nodes, H, norm=None):
     _L().gcn_oracle_dense_aggregate(_p(src), _p(dst), C.c_int64(src.shape[0]), C.c_int32(n_nodes), C.c_int32(F),
                                     _p(H), _p(norm) if norm is not None else None, _p(out))
     return out
+
+
+def bn_relu_fwd(X, gamma=None, beta=None, eps=1e-5, do_bn=True, do_relu=True):
+    """BatchNorm (batch statistics) then ReLU, the reference's arithmetic (nn.cpp:301-330, 229-237)."""
+    X = _f32(X)
+    N, F = X.shape
+    gamma = _f32(np.ones(F) if gamma is None else gamma).reshape(-1)
+    beta = _f32(np.zeros(F) if beta is None else beta).reshape(-1)
+    Y = np.zeros((N, F), dtype=np.float32)
+    mean = np.zeros(F, dtype=np.float32)
+    var = np.zeros(F, dtype=np.float32)
+    _L().gcn_oracle_bn_relu_fwd(_p(X), C.c_int64(N), C.c_int32(F), _p(gamma), _p(beta), C.c_float(eps), C.c_int(int(do_bn)),
+                                C.c_int(int(do_relu)), _p(Y), _p(mean), _p(var))
+    return Y, mean, var
 
 
 def powf_table(n):

@@ -28,14 +28,15 @@ def run_driver(d):
                 np.ascontiguousarray(d[k], dtype=np.int32).tofile(f)
             for k in ("X", "W", "bias", "G"):
                 np.ascontiguousarray(d[k], dtype=np.float32).tofile(f)
-        r = subprocess.run([DRIVER, cpath, td], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([DRIVER, cpath, td, "full"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         n, fin, fout = d["n"], d["fin"], d["fout"]
         rd = lambda nm, dt: np.fromfile(os.path.join(td, nm), dtype=dt)  # noqa: E731
         return dict(ei2=rd("ei2.i32", np.int32).reshape(2, -1), s=rd("s.f32", np.float32), norm=rd("norm.f32", np.float32),
                     H=rd("H.f32", np.float32).reshape(n, fout), agg=rd("agg.f32", np.float32).reshape(n, fout),
                     out=rd("out.f32", np.float32).reshape(n, fout), dX=rd("dX.f32", np.float32).reshape(n, fin),
-                    dW=rd("dW.f32", np.float32).reshape(fout, fin), dbias=rd("dbias.f32", np.float32))
+                    dW=rd("dW.f32", np.float32).reshape(fout, fin), dbias=rd("dbias.f32", np.float32),
+                    out_full=rd("out_full.f32", np.float32).reshape(n, fout))
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -53,6 +54,8 @@ def test_reference_call_sites_run_on_the_hip_backend(name):
     assert same(got["agg"], oracle.aggregate_fwd(rp, ci, got["H"], d["ref_norm"], None))
     assert same(got["out"], oracle.aggregate_fwd(rp, ci, got["H"], d["ref_norm"], d["bias"]))
     assert_close(got["out"], d["ref_out"], "out")
+    # the whole layer as the reference runs it: layer(data) = transform -> BatchNorm -> ReLU -> aggregate -> + bias
+    assert_close(got["out_full"], d["ref_out_full"], "GCNConv::forward (full layer)")
     # autograd: out->backward(G) through Add -> Mul -> MatMul(CSR) -> MatMul -> Transpose
     G64, X64 = d["G"].astype(np.float64), d["X"].astype(np.float64)
     rT, cT = oracle.csr_transpose(rp, ci, d["n"])

@@ -439,3 +439,60 @@ def test_shard_layout_on_gpu_bit_identical(env):
         out_p = ops.spmm(f.rowptr, f.colidx, Hext, rowscale=g.norm[lo:hi].contiguous(), bias=bias, n_rows=nl, plan=pl)
         assert float((out_p - out).abs().max()) <= 1e-4 * float(out.abs().max())
     assert cuts[0] == 0 and cuts[-1] == n
+
+
+# ------------------------------------------------------------------ next row: BatchNorm + ReLU
+def test_golden_full_layer_with_batchnorm_relu(gcase, env):
+    """transform -> BatchNorm -> ReLU -> aggregate -> + bias == the reference's GCNConv::forward output."""
+    ops, g = env["ops"], gcase["g"]
+    H = dev(env, gcase["ref_H"])
+    mean, var = ops.bn_stats(H)
+    Hn = ops.bn_relu_fwd(H, mean, var, relu=True)
+    ref_Hn, ref_mean, ref_var = oracle.bn_relu_fwd(gcase["ref_H"])
+    assert_close(host(mean), ref_mean, "batch mean")
+    assert_close(host(var), ref_var, "batch var")
+    assert_close(host(Hn), ref_Hn, "BatchNorm+ReLU")
+    out = ops.aggregate_fwd(g, Hn, dev(env, gcase["bias"]))
+    assert_close(host(out), gcase["ref_out_full"], "full layer", absum=None)
+    # the normalise/affine/ReLU pass itself is bit-exact when fed the reference-order statistics
+    Hn2 = ops.bn_relu_fwd(H, dev(env, ref_mean), dev(env, ref_var), relu=True)
+    sd_ok = np.power(ref_var + np.float32(1e-5), np.float32(0.5), dtype=np.float32) == np.sqrt(ref_var + np.float32(1e-5), dtype=np.float32)
+    got, ref = host(Hn2), ref_Hn
+    assert np.array_equal(got[:, sd_ok], ref[:, sd_ok])
+
+
+@pytest.mark.parametrize("n,F,relu,bn", [(5000, 64, True, True), (3000, 100, True, True), (2000, 7, False, True), (4000, 256, True, False)])
+def test_batchnorm_relu_backward_vs_float64(env, n, F, relu, bn):
+    """Gradients of y = relu(bn(x)) against a float64 evaluation of the textbook formulas."""
+    ops = env["ops"]
+    X = synth.uniform_pm1(201, (n, F)) * 2.0 + 0.3
+    gamma = synth.uniform_pm1(202, (F,)) + 1.5
+    beta = synth.uniform_pm1(203, (F,), scale=0.3)
+    dY = synth.uniform_pm1(204, (n, F))
+    Xd, gd, bd, dYd = dev(env, X), dev(env, gamma), dev(env, beta), dev(env, dY)
+    if bn:
+        mean, var = ops.bn_stats(Xd)
+        Y = ops.bn_relu_fwd(Xd, mean, var, gd, bd, relu=relu)
+        dX, dgamma, dbeta = ops.bn_relu_bwd(Xd, Y, dYd, mean, var, gd, relu=relu)
+    else:
+        Y = ops.bn_relu_fwd(Xd, relu=True)
+        dX, dgamma, dbeta = ops.bn_relu_bwd(Xd, Y, dYd, relu=True)
+    x = X.astype(np.float64)
+    if bn:
+        mu, v = x.mean(0), x.var(0)
+        rstd = 1.0 / np.sqrt(v + 1e-5)
+        xhat = (x - mu) * rstd
+        y = xhat * gamma + beta
+    else:
+        y = x
+    g = dY.astype(np.float64) * ((y > 0) if relu else 1.0)
+    assert_close(host(Y), (np.maximum(y, 0) if relu else y).astype(np.float32), "forward")
+    if bn:
+        dbeta_ref, dgamma_ref = g.sum(0), (g * xhat).sum(0)
+        dx_ref = gamma * rstd * (g - dbeta_ref / n - xhat * dgamma_ref / n)
+        scale = np.abs(g).sum(0)
+        assert np.abs(host(dbeta) - dbeta_ref).max() <= 1e-5 * max(1.0, scale.max())
+        assert np.abs(host(dgamma) - dgamma_ref).max() <= 1e-5 * max(1.0, (np.abs(g * xhat)).sum(0).max())
+        assert np.abs(host(dX) - dx_ref).max() <= 1e-4 * max(1.0, np.abs(dx_ref).max())
+    else:
+        assert np.array_equal(host(dX), g.astype(np.float32))
