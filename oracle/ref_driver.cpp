@@ -140,6 +140,11 @@ int main(int argc, char **argv)
         auto out_full = layer2(data);
         t_full = now_s() - t0;
         dump_va(outdir, "out_full.f32", *out_full->data());
+        // the two modules between transform and aggregation, on their own (graph.cpp:174-175)
+        auto Hbn = (*layer2.get_module("bnorm"))(H);
+        auto Hrelu = (*layer2.get_module("relu"))(Hbn);
+        dump_va(outdir, "Hbn.f32", *Hbn->data());
+        dump_va(outdir, "Hrelu.f32", *Hrelu->data());
     }
 
     printf("{\"N\": %zu, \"E\": %zu, \"nnz\": %zu, \"Fin\": %zu, \"Fout\": %zu, \"t_selfloops\": %.6f, "

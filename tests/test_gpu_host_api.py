@@ -36,7 +36,8 @@ def run_driver(d):
                     H=rd("H.f32", np.float32).reshape(n, fout), agg=rd("agg.f32", np.float32).reshape(n, fout),
                     out=rd("out.f32", np.float32).reshape(n, fout), dX=rd("dX.f32", np.float32).reshape(n, fin),
                     dW=rd("dW.f32", np.float32).reshape(fout, fin), dbias=rd("dbias.f32", np.float32),
-                    out_full=rd("out_full.f32", np.float32).reshape(n, fout))
+                    out_full=rd("out_full.f32", np.float32).reshape(n, fout), Hbn=rd("Hbn.f32", np.float32).reshape(n, fout),
+                    Hrelu=rd("Hrelu.f32", np.float32).reshape(n, fout))
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -55,6 +56,10 @@ def test_reference_call_sites_run_on_the_hip_backend(name):
     assert same(got["out"], oracle.aggregate_fwd(rp, ci, got["H"], d["ref_norm"], d["bias"]))
     assert_close(got["out"], d["ref_out"], "out")
     # the whole layer as the reference runs it: layer(data) = transform -> BatchNorm -> ReLU -> aggregate -> + bias
+    ref_bn, _, _ = oracle.bn_relu_fwd(got["H"], do_relu=False)   # oracle == reference on these (pinned), fed this run's H
+    assert_close(got["Hbn"], ref_bn, "nn::BatchNorm forward")
+    assert np.array_equal(got["Hrelu"], np.maximum(got["Hbn"], 0)), "nn::ReLU forward"
+    assert_close(got["Hrelu"], d["ref_Hrelu"], "BatchNorm+ReLU vs reference")
     assert_close(got["out_full"], d["ref_out_full"], "GCNConv::forward (full layer)")
     # autograd: out->backward(G) through Add -> Mul -> MatMul(CSR) -> MatMul -> Transpose
     G64, X64 = d["G"].astype(np.float64), d["X"].astype(np.float64)
