@@ -172,6 +172,8 @@ class ShardedBench:
         t = torch.tensor([p.nnz_local], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
         self.nnz_total = int(t.item())
+        # per-non-zero source scale of the backward aggregation (a coalesced stream; same arithmetic as colscale)
+        self.norm_nz_bwd = ops.gather_rows(p.norm_ext_bwd.reshape(-1, 1), p.bwd.colidx).reshape(-1)
         self.plan_f = ops.SpmmPlan(p.fwd.rowptr, chunk, F) if chunk > 0 else None
         self.plan_b = ops.SpmmPlan(p.bwd.rowptr, chunk, F) if chunk > 0 else None
         nl = p.n_local
@@ -213,7 +215,7 @@ class ShardedBench:
                              plan=self.plan_f, n_rows=nl))
         run(lambda: ops.colsum(Gl, out=self.dbias))
         run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_buf))
-        run(lambda: ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext, out=self.dH, colscale=p.norm_ext_bwd, plan=self.plan_b,
+        run(lambda: ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext, out=self.dH, vals=self.norm_nz_bwd, plan=self.plan_b,
                              n_rows=nl))
         run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
         run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
