@@ -90,11 +90,14 @@ class ShardPlan:
     Rows are LOCAL ids (src - lo), columns stay GLOBAL until HaloSide renumbers them.
     """
 
-    def __init__(self, src, dst, n_nodes, rank, world, dist, csr_builder, cuts=None):
+    def __init__(self, src, dst, n_nodes, rank, world, dist, csr_builder, cuts=None, row_weight=1):
         dev = src.device
         self.rank, self.world, self.n_nodes = rank, world, n_nodes
         if cuts is None:
-            w = torch.bincount(src.to(torch.int64), minlength=n_nodes) + torch.bincount(dst.to(torch.int64), minlength=n_nodes) + 1
+            # cost model of a vertex: `row_weight` for the dense work on its row (three GEMM passes, ~6 F^2 flop) plus one
+            # unit per incident edge for the two aggregations (4 F bytes each): row_weight ~ 0.08 F on MI355X
+            w = torch.bincount(src.to(torch.int64), minlength=n_nodes) + torch.bincount(dst.to(torch.int64), minlength=n_nodes) \
+                + int(row_weight)
             cuts = balanced_cuts(w, world)
         self.cuts = cuts
         lo, hi = cuts[rank], cuts[rank + 1]
@@ -158,7 +161,7 @@ class ShardedBench:
             rp, ci = ops.CsrGraph.csr_from_coo(s_, d_, max(n_rows, n_cols), flags=1)  # self loops handled on global ids
             return rp[: n_rows + 1].contiguous(), ci
 
-        self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once)
+        self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once, row_weight=max(1, round(0.078 * F)))
         del src, dst
         ops._ws_cache.clear()
         torch.cuda.empty_cache()
