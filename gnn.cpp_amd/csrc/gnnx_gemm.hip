@@ -262,35 +262,59 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 using CfgDefault = Cfg<128, 128, 32, 2, 2>;  // 256 threads, 66 KB LDS, 2 workgroups per CU
 using CfgWide = Cfg<128, 256, 16, 2, 4>;     // 512 threads, 49 KB LDS: one pass over A for 256-wide outputs
 using CfgK16 = Cfg<128, 128, 16, 2, 2>;      // 33 KB LDS: 3 workgroups per CU
+using CfgWide32 = Cfg<128, 256, 32, 2, 4>;   // 512 threads, 97 KB LDS: one workgroup per CU, half the barriers
+using CfgTall = Cfg<256, 256, 16, 4, 4>;     // 1024 threads, 66 KB LDS
 
-// Default: the 128 x 256 tile whenever the output is wider than 128 columns (A is then streamed once for a 256-wide
-// output: 115 vs 111 TFLOP/s at the bench shape), else 128 x 128.  GNNX_GEMM_TILE=square|wide|k16 forces one (A/B runs).
-int tile_variant()
+// Tile choice.  Default ("auto"): 256 x 256 / 1024 threads when the output is at least that big (A and B are each
+// streamed once for a 256-wide output: 118-121 TFLOP/s at the bench shape vs 111 for 128 x 128), 128 x 256 for wide
+// but short outputs, 128 x 128 otherwise.  GNNX_GEMM_TILE=square|wide|k16|wide32|tall forces one (A/B experiments).
+enum TileId { kSquare = 0, kWide = 1, kK16 = 2, kWide32 = 3, kTall = 4 };
+
+int forced_tile()
 {
     static const int v = [] {
         const char *e = getenv("GNNX_GEMM_TILE");
-        if (!e) return 1;
-        return !strcmp(e, "wide") ? 1 : (!strcmp(e, "k16") ? 2 : 0);
+        if (!e) return -1;
+        if (!strcmp(e, "square")) return (int)kSquare;
+        if (!strcmp(e, "wide")) return (int)kWide;
+        if (!strcmp(e, "k16")) return (int)kK16;
+        if (!strcmp(e, "wide32")) return (int)kWide32;
+        if (!strcmp(e, "tall")) return (int)kTall;
+        return -1;
     }();
     return v;
 }
 
-struct TileDims { int bm, bn, bk; };
-TileDims tile_dims(int64_t N)
+int pick_tile(int64_t M, int64_t N)
 {
-    int v = tile_variant();
-    if (v == 1 && N > 128) return {CfgWide::BM, CfgWide::BN, CfgWide::BK};
-    if (v == 2) return {CfgK16::BM, CfgK16::BN, CfgK16::BK};
-    return {CfgDefault::BM, CfgDefault::BN, CfgDefault::BK};
+    int f = forced_tile();
+    if (f == kK16 || f == kSquare) return f;
+    if (N <= 128) return kSquare;
+    if (f == kWide || f == kWide32) return f;
+    if (f == kTall) return kTall;
+    return M >= 256 ? kTall : kWide;
+}
+
+struct TileDims { int bm, bn, bk; };
+TileDims tile_dims(int64_t M, int64_t N)
+{
+    switch (pick_tile(M, N)) {
+    case kWide: return {CfgWide::BM, CfgWide::BN, CfgWide::BK};
+    case kK16: return {CfgK16::BM, CfgK16::BN, CfgK16::BK};
+    case kWide32: return {CfgWide32::BM, CfgWide32::BN, CfgWide32::BK};
+    case kTall: return {CfgTall::BM, CfgTall::BN, CfgTall::BK};
+    default: return {CfgDefault::BM, CfgDefault::BN, CfgDefault::BK};
+    }
 }
 
 int choose_splits(int64_t M, int64_t N, int64_t K)
 {
-    TileDims t = tile_dims(N);
+    TileDims t = tile_dims(M, N);
     int64_t tiles = ceil_div(M, t.bm) * ceil_div(N, t.bn);
     int64_t ksteps = ceil_div(K, t.bk);
-    int64_t want = ceil_div(4 * kNumCU, tiles);  // ~4 workgroups per CU
-    if (want > ksteps / 8) want = ksteps / 8;    // keep >= 8 K-steps per split
+    int64_t per_cu = t.bm * t.bn >= 256 * 256 ? 1 : 4;  // workgroups per CU wanted
+    int64_t want = ceil_div(per_cu * kNumCU, tiles);
+    if (want > ksteps / 8) want = ksteps / 8;  // keep >= 8 K-steps per split
     if (want < 1) want = 1;
     if (want > 1024) want = 1024;
     return (int)want;
@@ -324,10 +348,13 @@ int launch_cfg(const GemmArgs &g, int splits, bool va, bool vb, hipStream_t st)
 template <bool A_KC, bool B_KC>
 int launch(const GemmArgs &g, int splits, bool va, bool vb, hipStream_t st)
 {
-    int v = tile_variant();
-    if (v == 1 && g.N > 128) return launch_cfg<CfgWide, A_KC, B_KC>(g, splits, va, vb, st);
-    if (v == 2) return launch_cfg<CfgK16, A_KC, B_KC>(g, splits, va, vb, st);
-    return launch_cfg<CfgDefault, A_KC, B_KC>(g, splits, va, vb, st);
+    switch (pick_tile(g.M, g.N)) {
+    case kWide: return launch_cfg<CfgWide, A_KC, B_KC>(g, splits, va, vb, st);
+    case kK16: return launch_cfg<CfgK16, A_KC, B_KC>(g, splits, va, vb, st);
+    case kWide32: return launch_cfg<CfgWide32, A_KC, B_KC>(g, splits, va, vb, st);
+    case kTall: return launch_cfg<CfgTall, A_KC, B_KC>(g, splits, va, vb, st);
+    default: return launch_cfg<CfgDefault, A_KC, B_KC>(g, splits, va, vb, st);
+    }
 }
 
 }  // namespace
@@ -365,7 +392,7 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     const bool vb = aligned16(d_B) && ldb % 4 == 0 && (b_kc ? K % 4 == 0 : N % 4 == 0);
     int splits = 1;
     if (transA && K > 0) splits = choose_splits(M, N, K);
-    const int bk = tile_dims(N).bk;
+    const int bk = tile_dims(M, N).bk;
     int64_t ksteps = ceil_div(K > 0 ? K : 1, bk);
     g.k_per_split = ceil_div(ksteps, splits) * bk;
     if (splits > 1) {
