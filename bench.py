@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--workload", default="rmat10m_100m_f256", choices=sorted(WORKLOADS))
     ap.add_argument("--chunk", type=int, default=4096, help="plan: split rows longer than this (0 = never)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--native-comm", action="store_true",
+                    help="N>1: halo all-to-all-v and all-reduce through the C-ABI (gnnx_halo_exchange_f32) instead of torch.distributed")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank (rehearsal)")
     ap.add_argument("--cpu-sample-nodes", type=int, default=1_000_000)
     args = ap.parse_args()
@@ -116,7 +118,7 @@ def main():
         runner.workload = args.workload
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
-        runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk)
+        runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm)
     torch.cuda.synchronize()
     t_build = time.time() - t_build0
 

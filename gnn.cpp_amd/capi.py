@@ -87,6 +87,11 @@ _SIGS = {
     "gnnx_bn_relu_fwd_f32": [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp],
     "gnnx_bn_relu_bwd_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp, _sz,
                              _vp],
+    "gnnx_comm_unique_id": [_vp],
+    "gnnx_comm_init": [C.POINTER(_vp), C.c_int, C.c_int, _vp],
+    "gnnx_comm_destroy": [_vp],
+    "gnnx_halo_exchange_f32": [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _i32, _vp],
+    "gnnx_allreduce_sum_f32": [_vp, _vp, _i64, _vp],
     "gnnx_gather_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_scatter_add_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_rmat_edges": [_u64, _i32, _i64, _i64, _f64, _f64, _f64, _vp, _vp, _vp],

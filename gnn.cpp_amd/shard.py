@@ -69,17 +69,57 @@ class HaloSide:
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
 
 
-def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None):
+def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None):
     """buf: [n_local + n_halo, F]; rows [:n_local] are this rank's; fills rows [n_local:] from the owners.
-    pack(src_rows_view, idx, out) gathers rows (gnnx_gather_rows_f32 on GPU)."""
+    pack(src_rows_view, idx, out) gathers rows (gnnx_gather_rows_f32 on GPU).
+    native: a NativeComm => the all-to-all-v runs through the C-ABI (gnnx_halo_exchange_f32, RCCL send/recv group)
+    instead of torch.distributed.all_to_all_single (the same RCCL underneath)."""
     n_send = int(side.send_idx.numel())
     if send_buf is None or send_buf.shape[0] < n_send:
         send_buf = torch.empty((max(n_send, 1), n_feat), dtype=buf.dtype, device=buf.device)
     out = send_buf[:n_send]
     if n_send:
         pack(buf[: side.n_local], side.send_idx, out)
-    dist.all_to_all_single(buf[side.n_local: side.n_local + side.n_halo], out, side.recv_counts, side.send_counts)
+    recv = buf[side.n_local: side.n_local + side.n_halo]
+    if native is not None:
+        native.halo_exchange(out, side.send_counts, recv, side.recv_counts, n_feat)
+    else:
+        dist.all_to_all_single(recv, out, side.recv_counts, side.send_counts)
     return send_buf
+
+
+class NativeComm:
+    """RCCL communicator owned by the C-ABI (gnnx_comm_*).  The 128-byte id is created on rank 0 and shipped with
+    one torch.distributed broadcast (setup only); the per-step exchange and all-reduce then bypass torch."""
+
+    def __init__(self, capi, ops, dist, rank, world, dev):
+        import ctypes as C
+        self.C, self.capi, self.ops, self.world = C, capi, ops, world
+        idbuf = (C.c_char * 128)()
+        if rank == 0:
+            capi.call("gnnx_comm_unique_id", C.cast(idbuf, C.c_void_p))
+        t = torch.frombuffer(bytearray(bytes(idbuf)), dtype=torch.uint8).to(dev)
+        if world > 1:
+            dist.broadcast(t, 0)
+        raw = bytes(t.cpu().numpy().tobytes())
+        self.h = C.c_void_p()
+        capi.call("gnnx_comm_init", C.byref(self.h), world, rank, C.c_char_p(raw))
+
+    def halo_exchange(self, send, send_counts, recv, recv_counts, n_feat):
+        C = self.C
+        sc = (C.c_int64 * self.world)(*[int(v) for v in send_counts])
+        rc = (C.c_int64 * self.world)(*[int(v) for v in recv_counts])
+        self.capi.call("gnnx_halo_exchange_f32", self.h, self.ops._ptr(send) if send.numel() else None, sc,
+                       self.ops._ptr(recv) if recv.numel() else None, rc, int(n_feat), self.ops._stream())
+
+    def allreduce(self, t):
+        self.capi.call("gnnx_allreduce_sum_f32", self.h, self.ops._ptr(t), t.numel(), self.ops._stream())
+
+    def __del__(self):
+        try:
+            self.capi.lib().gnnx_comm_destroy(self.h)
+        except Exception:
+            pass
 
 
 class ShardPlan:
@@ -146,9 +186,10 @@ class ShardPlan:
 class ShardedBench:
     """bench.py runner for N > 1 ranks: same synthetic graph as the single-GPU workload, sharded."""
 
-    def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk):
+    def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, native_comm=False):
         import ctypes as C
         self.C = C
+        self.native = NativeComm(capi, ops, dist, rank, world, dev) if native_comm else None
         self.ops, self.capi, self.dist, self.F = ops, capi, dist, F
         self.rank, self.world = rank, world
         if abc is None:
@@ -213,19 +254,23 @@ class ShardedBench:
 
         Hl, Gl = self.Hext[:nl], self.Gext[:nl]
         run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
-        run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_buf))
+        run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_buf, self.native))
         run(lambda: ops.spmm(p.fwd.rowptr, p.fwd.colidx, self.Hext, out=self.out, rowscale=p.norm, bias=self.bias,
                              plan=self.plan_f, n_rows=nl))
         run(lambda: ops.colsum(Gl, out=self.dbias))
-        run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_buf))
+        run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_buf, self.native))
         run(lambda: ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext, out=self.dH, vals=self.norm_nz_bwd, plan=self.plan_b,
                              n_rows=nl))
         run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
         run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
 
         def reduce_params():
-            dist.all_reduce(self.dW)
-            dist.all_reduce(self.dbias)
+            if self.native is not None:
+                self.native.allreduce(self.dW)
+                self.native.allreduce(self.dbias)
+            else:
+                dist.all_reduce(self.dW)
+                dist.all_reduce(self.dbias)
         run(reduce_params)
         if timed:
             self.ev.append(evs)

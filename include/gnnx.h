@@ -219,6 +219,21 @@ int gnnx_gather_rows_f32(const float *d_X, int64_t ldx, const int32_t *d_idx, in
 int gnnx_scatter_add_rows_f32(const float *d_in, int64_t ldi, const int32_t *d_idx, int64_t n_idx, int32_t n_feat,
                               float *d_Y, int64_t ldy, void *stream);
 
+/* The exchange itself, natively on RCCL (one process per GPU; librccl is bound with dlopen at first use).
+ * Every rank creates the communicator from the same 128-byte id (rank 0 calls gnnx_comm_unique_id and ships it to
+ * the others by whatever channel the host program has).  gnnx_halo_exchange_f32 is the all-to-all-v of the halo
+ * step: rows for peer p are send_rows[p] consecutive rows of d_send (peer-major, as gnnx_gather_rows_f32 packs them
+ * with the peer-major send list), rows from peer p land as recv_rows[p] consecutive rows of d_recv (the [halo] tail of
+ * the feature buffer, halo ids being grouped by owner).  One group of ncclSend/ncclRecv pairs: each pair of GPUs
+ * uses its own xGMI link.  send_rows / recv_rows are HOST arrays of `world` entries. */
+typedef struct gnnx_comm gnnx_comm;
+int gnnx_comm_unique_id(void *id_out_128_bytes);
+int gnnx_comm_init(gnnx_comm **comm, int world, int rank, const void *id_128_bytes);
+int gnnx_comm_destroy(gnnx_comm *comm);
+int gnnx_halo_exchange_f32(gnnx_comm *comm, const float *d_send, const int64_t *send_rows, float *d_recv, const int64_t *recv_rows,
+                           int32_t n_feat, void *stream);
+int gnnx_allreduce_sum_f32(gnnx_comm *comm, float *d_buf, int64_t n, void *stream);
+
 /* ------------------------------------------------------------------ synthetic inputs ------------- */
 /* Counter-based SplitMix64 generators, bit-identical to gnn.cpp_amd/synth.py. */
 int gnnx_rmat_edges(uint64_t seed, int32_t n_nodes, int64_t n_edges, int64_t first_edge, double a, double b,

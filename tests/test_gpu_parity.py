@@ -496,3 +496,22 @@ def test_batchnorm_relu_backward_vs_float64(env, n, F, relu, bn):
         assert np.abs(host(dX) - dx_ref).max() <= 1e-4 * max(1.0, np.abs(dx_ref).max())
     else:
         assert np.array_equal(host(dX), g.astype(np.float32))
+
+
+def test_native_rccl_comm_single_rank(env):
+    """gnnx_comm_* / gnnx_halo_exchange_f32 / gnnx_allreduce_sum_f32 on a one-rank communicator (all this box has):
+    the self-exchange must copy the packed rows into the halo tail and the all-reduce must be the identity."""
+    ops, capi, torch = env["ops"], env["capi"], env["torch"]
+    shard = importlib.import_module("gnncpp_amd.shard")
+    comm = shard.NativeComm(capi, ops, None, 0, 1, env["dev"])
+    send = ops.uniform_pm1(301, (1000, 64))
+    recv = torch.zeros((1000, 64), dtype=torch.float32, device=env["dev"])
+    comm.halo_exchange(send, [1000], recv, [1000], 64)
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    w = ops.uniform_pm1(302, (256, 256))
+    w0 = w.clone()
+    comm.allreduce(w)
+    torch.cuda.synchronize()
+    assert torch.equal(w, w0)
+    comm.halo_exchange(send[:0], [0], recv[:0], [0], 64)  # empty exchange is legal
