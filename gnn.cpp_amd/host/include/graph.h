@@ -74,11 +74,22 @@ public:
     cyg::tptr<float> propagate(const cyg::tensor<int> &edge_index, const cyg::tptr<float> &x, const cyg::tptr<float> *others) override;
     cyg::tptr<float> aggregate_and_update(const cyg::tptr<float> &x, const cyg::tensor<int> &edge_index, const cyg::tptr<float> *other) override;
 
+    // true (default): aggregation + norm scaling + bias run as ONE fused SpMM (row-scale + bias epilogue, load-balancing
+    // plan) recorded as a single autograd op, and the CSR / degree / norm of a graph are cached across calls on the
+    // same Data (a static graph is built once, not three times per forward).  false: op by op through the generic
+    // tensor ops (MatMul, Mul, Add), exactly the reference's sequence; both give the same bits.
+    bool fused = true;
+    void invalidate_graph_cache() { _cache_key = nullptr; }
     // false (default): the reference's full layer, transform -> BatchNorm -> ReLU -> aggregation -> bias.
     // true: only the hot path of BASELINE.json (transform -> aggregation -> bias).
     bool hot_path_only = false;
     size_t _in_channels, _out_channels;
     float _dropout;
+
+private:
+    const void *_cache_key = nullptr;  // identity of the edge_index tensor the cache was built from
+    size_t _cache_edges = 0, _cache_nodes = 0;
+    cyg::tptr<float> _cache_adj, _cache_norm;
 };
 
 }  // namespace graph

@@ -3,6 +3,7 @@
 // src/graph.cpp re-implemented over include/gnnx.h).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <random>
 
 #include "graph.h"
@@ -53,8 +54,28 @@ void *workspace(size_t bytes)
 
 Csr::~Csr()
 {
-    for (void *p : {rowptr, colidx, rowptr_t, colidx_t, coo_src, coo_dst})
+    drop_plans();
+    for (void *p : {rowptr, colidx, rowptr_t, colidx_t, coo_src, coo_dst, norm_per_nz_t})
         if (p) gnnx_free(p);
+}
+
+void Csr::drop_plans()
+{
+    if (plan) gnnx_spmm_plan_destroy(plan);
+    if (plan_t) gnnx_spmm_plan_destroy(plan_t);
+    plan = plan_t = nullptr;
+    plan_feat = 0;
+}
+
+void Csr::ensure_plans(int32_t n_feat)
+{
+    if (plan && plan_feat >= n_feat) return;
+    drop_plans();
+    ensure_transpose();
+    constexpr int32_t kChunk = 4096;  // rows longer than this are cut into chunks
+    gx(gnnx_spmm_plan_create((const int32_t *)rowptr, n, kChunk, n_feat, &plan, current_stream()), "plan");
+    gx(gnnx_spmm_plan_create((const int32_t *)rowptr_t, n, kChunk, n_feat, &plan_t, current_stream()), "plan");
+    plan_feat = n_feat;
 }
 
 static void build_one(const void *src, const void *dst, int64_t n_edges, int32_t n, uint32_t flags, void **rowptr, void **colidx,
@@ -74,7 +95,10 @@ static void build_one(const void *src, const void *dst, int64_t n_edges, int32_t
 void Csr::build()
 {
     build_one(coo_src, coo_dst, n_edges, n, flags, &rowptr, &colidx, &nnz);
-    nnz_t = -1;  // transpose is stale
+    nnz_t = -1;  // transpose and plans are stale
+    drop_plans();
+    if (norm_per_nz_t) gnnx_free(norm_per_nz_t);
+    norm_per_nz_t = nullptr;
 }
 
 void Csr::ensure_transpose()
@@ -440,6 +464,61 @@ tptr<float> MessagePassing::propagate(const tensor<int> &edge_index, const tptr<
     return aggregate_and_update(x, edge_index, nullptr);
 }
 
+namespace {
+// out = norm (.) (A . x) (+ bias) as ONE SpMM with fused epilogue; backward dX = A^T . (norm (.) G), dbias = colsum(G).
+// Same arithmetic, in the same order, as the MatMul -> Mul -> Add chain it replaces (reference graph.cpp:208-209,188).
+class AggregateOp : public cyg::Operation<tensor<float>> {
+public:
+    std::shared_ptr<cyg::detail::Csr> csr;
+    tptr<float> norm;
+    AggregateOp() { name = "GCNAggregate"; }
+    tptr<float> forward(const tptr<float> &adj, const tptr<float> &x, const tptr<float> &norm_, const tptr<float> &bias)
+    {
+        csr = adj->csr();
+        norm = norm_;
+        const auto shp = x->shape();
+        const int32_t f = (int32_t)shp[1];
+        csr->ensure_plans(f);
+        const bool req = x->requires_grad() || (bias && bias->requires_grad());
+        auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, req);
+        cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr, (const int32_t *)csr->colidx, nullptr, nullptr,
+                                          norm->device_data(), bias ? bias->device_data() : nullptr, x->device_data(), f, 0.0f,
+                                          out->device_out(), f, csr->plan, cyg::detail::current_stream()), "aggregate");
+        if (req) context->save_for_backward({x, bias ? bias : x});
+        has_bias = (bool)bias;
+        return out;
+    }
+    void _backward(std::shared_ptr<tensor<float>> g) override
+    {
+        auto var = context->get_variables();
+        CHECK_BACKWARD<tensor<float>>(var, 2);
+        auto x = var[0], bias = var[1];
+        const auto shp = x->shape();
+        const int32_t f = (int32_t)shp[1];
+        void *st = cyg::detail::current_stream();
+        if (has_bias && bias->requires_grad()) {
+            auto db = g->clone(false);
+            db->sum_to_size(bias->shape());
+            bias->backward(db);
+        }
+        if (x->requires_grad()) {
+            csr->ensure_plans(f);
+            if (!csr->norm_per_nz_t) {  // norm[colidx_t[p]] once per graph
+                cyg::detail::gx(gnnx_malloc(&csr->norm_per_nz_t, sizeof(float) * (size_t)std::max<int64_t>(csr->nnz_t, 1)), "aggregate");
+                cyg::detail::gx(gnnx_gather_rows_f32(norm->device_data(), 1, (const int32_t *)csr->colidx_t, csr->nnz_t, 1,
+                                                     (float *)csr->norm_per_nz_t, 1, st), "aggregate");
+            }
+            auto dx = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
+            cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
+                                              (const float *)csr->norm_per_nz_t, nullptr, nullptr, nullptr, g->device_data(), f, 0.0f,
+                                              dx->device_out(), f, csr->plan_t, st), "aggregate");
+            x->backward(dx);
+        }
+    }
+    bool has_bias = false;
+};
+}  // namespace
+
 GCNConv::GCNConv(size_t in_channels, size_t out_channels, float dropout)
     : MessagePassing(), _in_channels(in_channels), _out_channels(out_channels), _dropout(dropout)
 {
@@ -448,6 +527,7 @@ GCNConv::GCNConv(size_t in_channels, size_t out_channels, float dropout)
     register_module("drop", new nn::Dropout(dropout));  // registered, never applied: as in the reference
     register_module("relu", new nn::ReLU());
     register_parameter("bias", std::make_shared<tensor<float>>(std::vector<size_t>{out_channels}, 0.0f, true));
+    if (std::getenv("GNNCPP_UNFUSED")) fused = false;  // run the op-by-op path (tests compare both)
 }
 
 // Same sequence of API calls as the reference layer (graph.cpp:170-191); each lands on the device:
@@ -458,6 +538,32 @@ GCNConv::GCNConv(size_t in_channels, size_t out_channels, float dropout)
 //   propagate, + bias       -> CSR SpMM, row scale, bias broadcast
 tptr<float> GCNConv::forward(Data &&input)
 {
+    if (fused) {
+        // static-graph cache: adjacency (dedupe + diagonal strip) and norm are built once per edge_index tensor
+        tensor<int> *ei = input.edge_index();
+        if (_cache_key != ei || _cache_edges != ei->numel() || _cache_nodes != input.num_nodes()) {
+            auto adj = edge_to_adj_mat(*ei, nullptr, input.num_nodes());
+            adj->fill_diagonal_(0);  // == add_self_loops(..., fillValue 0): self loops removed (graph.cpp:172)
+            auto deg = adj->sum(-1, true) + 1;
+            deg = deg->pow(-0.5);
+            auto norm = adj->mm(deg);
+            norm *= deg;
+            _cache_adj = adj;
+            _cache_norm = norm;
+            _cache_key = ei;
+            _cache_edges = ei->numel();
+            _cache_nodes = input.num_nodes();
+        }
+        auto out = (*get_module("lin"))(input.x());
+        if (!hot_path_only) {
+            out = (*get_module("bnorm"))(out);
+            out = (*get_module("relu"))(out);
+        }
+        auto op = std::make_unique<AggregateOp>();
+        auto res = op->forward(_cache_adj, out, _cache_norm, get_parameter("bias"));
+        if (res->requires_grad()) res->grad_fn = std::move(op);
+        return res;
+    }
     auto [edge_index, _] = add_self_loops(*input.edge_index(), nullptr, 0, (int)input.num_nodes());
     auto out = (*get_module("lin"))(input.x());
     if (!hot_path_only) {
@@ -484,6 +590,12 @@ tptr<float> GCNConv::propagate(const tensor<int> &edge_index, const tptr<float> 
 tptr<float> GCNConv::aggregate_and_update(const tptr<float> &x, const tensor<int> &edge_index, const tptr<float> *norm)
 {
     auto adj_mat = edge_to_adj_mat(edge_index, nullptr, x->shape()[0]);
+    if (fused) {
+        auto op = std::make_unique<AggregateOp>();
+        auto res = op->forward(adj_mat, x, *norm, nullptr);
+        if (res->requires_grad()) res->grad_fn = std::move(op);
+        return res;
+    }
     auto agg_x = adj_mat->mm(x);
     agg_x = agg_x * *norm;
     return agg_x;

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DRIVER = os.path.join(ROOT, "tests", "cpp", "dropin_driver")
 
 
-def run_driver(d):
+def run_driver(d, unfused=False):
     assert os.path.exists(DRIVER), "build it with __graft_entry__.build()"
     with tempfile.TemporaryDirectory() as td:
         cpath = os.path.join(td, "case.bin")
@@ -28,7 +28,10 @@ def run_driver(d):
                 np.ascontiguousarray(d[k], dtype=np.int32).tofile(f)
             for k in ("X", "W", "bias", "G"):
                 np.ascontiguousarray(d[k], dtype=np.float32).tofile(f)
-        r = subprocess.run([DRIVER, cpath, td, "full"], capture_output=True, text=True, timeout=300)
+        env = dict(os.environ)
+        if unfused:
+            env["GNNCPP_UNFUSED"] = "1"  # op-by-op MatMul/Mul/Add instead of the fused aggregation op
+        r = subprocess.run([DRIVER, cpath, td, "full"], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         n, fin, fout = d["n"], d["fin"], d["fout"]
         rd = lambda nm, dt: np.fromfile(os.path.join(td, nm), dtype=dt)  # noqa: E731
@@ -38,6 +41,14 @@ def run_driver(d):
                     dW=rd("dW.f32", np.float32).reshape(fout, fin), dbias=rd("dbias.f32", np.float32),
                     out_full=rd("out_full.f32", np.float32).reshape(n, fout), Hbn=rd("Hbn.f32", np.float32).reshape(n, fout),
                     Hrelu=rd("Hrelu.f32", np.float32).reshape(n, fout))
+
+
+@pytest.mark.parametrize("name", ["karate_l1", "rmat1024", "cora_l2"])
+def test_fused_and_op_by_op_paths_give_the_same_bits(name):
+    d = load_case(name)
+    a, b = run_driver(d, unfused=False), run_driver(d, unfused=True)
+    for k in ("ei2", "s", "norm", "H", "agg", "out", "dX", "dW", "dbias", "out_full", "Hbn", "Hrelu"):
+        assert np.array_equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("name", CASES)
