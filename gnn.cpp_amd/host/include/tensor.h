@@ -59,7 +59,7 @@ struct Store {
     ~Store()
     {
         delete host;
-        if (dev) gnnx_free(dev);
+        if (dev) dev_free(dev, n * sizeof(T));
     }
     void adopt_host(std::valarray<T> *h)
     {
@@ -83,7 +83,7 @@ struct Store {
     }
     void ensure_dev_alloc()
     {
-        if (!dev && n) gx(gnnx_malloc(&dev, n * sizeof(T)), "alloc");
+        if (!dev && n) dev = dev_alloc(n * sizeof(T));
     }
     // device pointer, valid contents
     T *d()
@@ -252,11 +252,11 @@ public:
     }
     // backend-side constructors
     struct device_tag {};
+    // op results: never leaves, so no gradient buffer is attached (backward() only accumulates into leaves)
     tensor(device_tag, std::vector<size_t> dims, bool requires_grad) : _dims(dims), _requires_grad(requires_grad)
     {
         CHECK_VALID_DIMS(dims);
         _st = std::make_shared<detail::Store<T>>(numel_of(dims));
-        init_grad();
     }
     tensor(std::shared_ptr<detail::Csr> csr, bool) : _dims({(size_t)csr->n, (size_t)csr->n}), _requires_grad(false), _csr(csr) {}
 
@@ -323,8 +323,9 @@ public:
     void zero_grad()
     {
         if (typeid(T) != typeid(float)) throw std::runtime_error(ERROR_GRAD_DTYPE);
+        // lazily zero: the first device use memsets HBM, the first host use creates a zero valarray -- no host
+        // allocation of N x F zeros per call
         _grad = std::make_shared<detail::Store<float>>(numel());
-        _grad->adopt_host(new std::valarray<float>(0.0f, numel()));
     }
 
     // drop / insert size-1 dimensions (reference tensor.h:232-252); metadata only

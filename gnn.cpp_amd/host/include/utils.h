@@ -112,7 +112,14 @@ void *current_stream();
 void set_current_stream(void *stream);
 // grow-only device scratch for workspaces (csr build, split-K slabs, colsum partials)
 void *workspace(size_t bytes);
+// Size-bucketed caching allocator for tensor storage: every op result is a fresh tensor (reference semantics), and a
+// hipMalloc/hipFree pair per op costs milliseconds plus a device-wide sync at these sizes.  Blocks go back to a
+// free list keyed by their (256-B rounded) size and are reused by the next tensor of that size; all work is on one
+// in-order stream, so reuse needs no event.  cyg::empty_cache() returns the cached blocks to the driver.
+void *dev_alloc(size_t bytes);
+void dev_free(void *ptr, size_t bytes);
 }  // namespace detail
+void empty_cache();
 }  // namespace cyg
 
 #endif

@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <random>
+#include <unordered_map>
+#include <vector>
 
 #include "graph.h"
 #include "nn.h"
@@ -50,6 +52,37 @@ void *workspace(size_t bytes)
         g_ws_bytes = bytes;
     }
     return g_ws;
+}
+
+static std::unordered_map<size_t, std::vector<void *>> &pool()
+{
+    static std::unordered_map<size_t, std::vector<void *>> p;
+    return p;
+}
+static size_t bucket(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+void *dev_alloc(size_t bytes)
+{
+    if (bytes == 0) return nullptr;
+    const size_t b = bucket(bytes);
+    auto &fl = pool()[b];
+    if (!fl.empty()) {
+        void *p = fl.back();
+        fl.pop_back();
+        return p;
+    }
+    void *p = nullptr;
+    int st = gnnx_malloc(&p, b);
+    if (st != GNNX_OK) {  // out of memory: give the cached blocks back and retry once
+        cyg::empty_cache();
+        gx(gnnx_malloc(&p, b), "alloc");
+    }
+    return p;
+}
+
+void dev_free(void *ptr, size_t bytes)
+{
+    if (ptr) pool()[bucket(bytes)].push_back(ptr);
 }
 
 Csr::~Csr()
@@ -108,6 +141,15 @@ void Csr::ensure_transpose()
 }
 
 }  // namespace detail
+
+void empty_cache()
+{
+    detail::gx(gnnx_stream_sync(detail::current_stream()), "empty_cache");
+    for (auto &[b, fl] : detail::pool()) {
+        for (void *p : fl) gnnx_free(p);
+        fl.clear();
+    }
+}
 
 static std::mt19937_64 &engine()
 {

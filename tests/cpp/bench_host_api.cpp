@@ -1,0 +1,78 @@
+// API-level benchmark: the GCN layer through the C++ mirror of the reference API (graph::GCNConv on graph::Data),
+// forward + backward, to show what a user of the reference's call sites gets on an MI355X.
+//   bench_host_api [n_nodes=1000000] [n_edges=10000000] [features=128] [steps=5] [hot_path_only=1]
+// Edges: R-MAT from the same SplitMix64 stream as gnn.cpp_amd/synth.py (seed 1, a,b,c = 0.57,0.19,0.19).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "graph.h"
+#include "nn.h"
+#include "tensor.h"
+
+using namespace cyg;
+using namespace std;
+
+static inline uint64_t splitmix64(uint64_t x)
+{
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv)
+{
+    const long n = argc > 1 ? atol(argv[1]) : 1000000, e = argc > 2 ? atol(argv[2]) : 10000000;
+    const size_t F = argc > 3 ? atol(argv[3]) : 128;
+    const int steps = argc > 4 ? atoi(argv[4]) : 5;
+    const bool hot = argc > 5 ? atoi(argv[5]) != 0 : true;
+    int scale = 1;
+    while ((1l << scale) < n) scale++;
+    const uint64_t key = splitmix64(1), G = 0x9E3779B97F4A7C15ull;
+    const uint32_t ta = (uint32_t)(0.57 * 4294967296.0), tb = (uint32_t)(0.76 * 4294967296.0), tc = (uint32_t)(0.95 * 4294967296.0);
+    vector<int> src(e), dst(e);
+    double t0 = now_s();
+#pragma omp parallel for
+    for (long i = 0; i < e; i++) {
+        uint64_t s = 0, d = 0;
+        for (int l = 0; l < scale; l++) {
+            uint32_t r = (uint32_t)(splitmix64(key ^ (((uint64_t)i * 64 + l) * G)) >> 32);
+            s = (s << 1) | (r >= tb);
+            d = (d << 1) | (((r >= ta) & (r < tb)) | (r >= tc));
+        }
+        src[i] = (int)(s % n);
+        dst[i] = (int)(d % n);
+    }
+    double t_gen = now_s() - t0;
+
+    manual_seed(7);
+    auto ei = graph::vec_to_edge_list(src, dst);
+    auto x = randn({(size_t)n, F}, -1, 1, true);
+    auto g = randn({(size_t)n, F}, -1, 1, false);
+    graph::Data data(x, ei.get());
+    graph::GCNConv layer(F, F);
+    layer.hot_path_only = hot;
+
+    t0 = now_s();
+    auto out = layer(data);  // first call: uploads, CSR build, norm, plans
+    out->backward(g);
+    gnnx_device_sync();
+    double t_first = now_s() - t0;
+
+    t0 = now_s();
+    for (int s = 0; s < steps; s++) {
+        layer.zero_grad();
+        auto o = layer(data);
+        o->backward(g);
+    }
+    gnnx_device_sync();
+    double ms = (now_s() - t0) / steps * 1e3;
+    printf("{\"bench\": \"host_api GCNConv fwd+bwd\", \"n_nodes\": %ld, \"n_edges\": %ld, \"features\": %zu, \"hot_path_only\": %d, "
+           "\"ms_per_step\": %.3f, \"first_call_s\": %.3f, \"edge_gen_s\": %.3f, \"out_checksum\": %.6e}\n",
+           n, e, F, (int)hot, ms, t_first, t_gen, (double)(*out->data())[12345 % (n * F)]);
+    return 0;
+}
