@@ -150,9 +150,10 @@ def main():
         roof["achieved"] = float(t.item())
         roof["frac"] = roof["achieved"] / roof["peak"]
 
-    cpu = None
+    cpu = cpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pkg, args, F, abc, seed)
+        cpu_ref = cpu_reference(pkg)
 
     if rank == 0:
         line = {
@@ -174,6 +175,7 @@ def main():
                        "plan_chunk": args.chunk},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "cpu_reference": cpu_ref,
             "kernels_ms": runner.kernel_times(),
             "build_s": t_build,
             "device": torch.cuda.get_device_name(local_rank),
@@ -286,6 +288,43 @@ def cpu_baseline(pkg, args, F, abc, seed):
             "sample": f"{args.workload} scaled to {n} nodes / {e} generated edges (nnz {len(ci)}), {F} features, "
                       f"one layer fwd+bwd in {dt:.2f} s, OpenMP over rows on {cores} threads",
             "seconds": dt}
+
+
+def cpu_reference(pkg):
+    """The REAL reference (oracle/_ref/ref_driver, compiled from /root/reference in the build container) timed on this
+    box on the largest BASELINE config it can run: Cora-sized N=2708 / E=10556, 1433->16 (its dense N x N path is
+    O(N^2 F) and overflows `int` beyond N = 46340, so the bench workload itself is out of its reach).  Single-threaded,
+    like the reference.  None when the binary did not travel."""
+    import subprocess
+    import tempfile
+    import oracle  # locates oracle/_ref
+    drv = oracle.ref_driver_path()
+    if drv is None:
+        return None
+    n, e, fin, fout = 2708, 10556, 1433, 16
+    src, dst = pkg.synth.uniform_edges(42, n, e)
+    X = pkg.synth.uniform_pm1(171, (n, fin))
+    W = pkg.synth.uniform_pm1(172, (fout, fin), scale=fin ** -0.5)
+    b = np.zeros(fout, dtype=np.float32)
+    G = pkg.synth.uniform_pm1(174, (n, fout))
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            cpath = os.path.join(td, "case.bin")
+            with open(cpath, "wb") as f:
+                np.array([n, e, fin, fout], dtype=np.int32).tofile(f)
+                for a in (src, dst):
+                    np.ascontiguousarray(a, dtype=np.int32).tofile(f)
+                for a in (X, W, b, G):
+                    np.ascontiguousarray(a, dtype=np.float32).tofile(f)
+            r = subprocess.run([drv, cpath, td], capture_output=True, text=True, timeout=300)
+            t = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as ex:  # the baseline is informational: never fail the bench because of it
+        return {"error": str(ex)[:200]}
+    secs = t["t_linear"] + t["t_aggregate"] + t["t_backward"]
+    return {"value": t["nnz"] / secs, "unit": "edges/s", "cores": 1, "kind": "reference",
+            "sample": f"Cora-sized N={n} E={e} (nnz {t['nnz']}), {fin}->{fout}: Linear {t['t_linear']:.3f} s + aggregate "
+                      f"{t['t_aggregate']:.3f} s + backward {t['t_backward']:.3f} s (+ dense norm {t['t_norm']:.3f} s, not counted)",
+            "seconds": secs}
 
 
 if __name__ == "__main__":
