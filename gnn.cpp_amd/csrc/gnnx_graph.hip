@@ -91,17 +91,51 @@ __global__ void deg_rsqrt_kernel(const int32_t *rowptr, int32_t n_rows, float *s
     s[i] = (float)(1.0 / sqrt((double)deg));
 }
 
-// norm_i = fl(fl(sum_{j desc} s_j) * s_i): one lane per row, sequential in the reference's matmul order
-// (descending column) => bit-identical.  N x 1 SpMV, done once per graph (not on the per-step path).
+// norm_i = fl(fl(sum_{j desc} s_j) * s_i), strictly sequential in the reference's matmul order (descending column)
+// => bit-identical.  N x 1 SpMV, once per graph (not on the per-step path).
+//   short rows: one lane per row;
+//   rows of >= kLongRow non-zeros (power-law hubs, a 100k-degree row would keep one lane busy for tens of ms) are
+//   appended to a list and summed by a whole wavefront each: 64 values are fetched in parallel (the next 64 already in
+//   flight), then added one by one IN ORDER through v_readlane -- same additions, same order, ~50x the load parallelism.
+constexpr int kLongRow = 128;
+
 __global__ void norm_kernel(const int32_t *rowptr, const int32_t *colidx, int32_t n_rows, const float *s_rows,
-                            const float *s_cols, float *norm)
+                            const float *s_cols, float *norm, int32_t *long_rows, int32_t *long_count)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     int32_t b = rowptr[i], e = rowptr[i + 1];
+    if (e - b >= kLongRow) {
+        long_rows[atomicAdd(long_count, 1)] = i;  // list order does not matter: each row is summed independently
+        return;
+    }
     float acc = 0.f;
     for (int32_t p = e - 1; p >= b; p--) acc = __fadd_rn(acc, s_cols[colidx[p]]);
     norm[i] = __fmul_rn(acc, s_rows[i]);
+}
+
+__global__ __launch_bounds__(256) void norm_long_kernel(const int32_t *rowptr, const int32_t *colidx, const float *s_rows,
+                                                         const float *s_cols, float *norm, const int32_t *long_rows,
+                                                         const int32_t *long_count)
+{
+    const int lane = threadIdx.x & 63;
+    const int32_t n_long = *long_count;
+    const int32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    for (int32_t k = wave; k < n_long; k += n_waves) {
+        const int32_t row = long_rows[k];
+        const int32_t b = rowptr[row], e = rowptr[row + 1];
+        float acc = 0.f;
+        int32_t q = e - 1 - lane;
+        float v = s_cols[colidx[q >= b ? q : b]];  // unpredicated; out-of-range lanes are never added
+        for (int32_t hi = e; hi > b; hi -= 64) {
+            const int32_t qn = hi - 64 - 1 - lane;  // next chunk, in flight during the serial adds below
+            const float vn = s_cols[colidx[qn >= b ? qn : b]];
+            const int cnt = hi - b < 64 ? hi - b : 64;
+            for (int j = 0; j < cnt; j++) acc = __fadd_rn(acc, __shfl(v, j, 64));
+            v = vn;
+        }
+        if (lane == 0) norm[row] = __fmul_rn(acc, s_rows[row]);
+    }
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -226,8 +260,16 @@ GNNX_API int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_coli
         // rows' own s: d_s when written here, else the caller's column-indexed vector is also row-indexed
         const float *s_rows = d_s ? d_s : d_s_cols;
         const float *s_cols = d_s_cols ? d_s_cols : d_s;
-        hipLaunchKernelGGL(norm_kernel, grid, dim3(T), 0, st, d_rowptr, d_colidx, n_rows, s_rows, s_cols, d_norm);
+        // scratch for the list of long rows: stream-ordered allocation, this is a once-per-graph build call
+        int32_t *list = nullptr;
+        GNNX_HIP_CHECK(hipMallocAsync((void **)&list, sizeof(int32_t) * ((size_t)n_rows + 1), st));
+        int32_t *count = list + n_rows;
+        GNNX_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(norm_kernel, grid, dim3(T), 0, st, d_rowptr, d_colidx, n_rows, s_rows, s_cols, d_norm, list, count);
         GNNX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(norm_long_kernel, dim3(1024), dim3(256), 0, st, d_rowptr, d_colidx, s_rows, s_cols, d_norm, list, count);
+        GNNX_LAUNCH_CHECK();
+        GNNX_HIP_CHECK(hipFreeAsync(list, st));
     }
     return GNNX_OK;
 }
