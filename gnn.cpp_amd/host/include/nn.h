@@ -91,6 +91,34 @@ public:
     float _p;
 };
 
+// mean softmax cross-entropy of [N,C] logits against [N] class ids; forward arithmetic of the reference
+// (nn.cpp:442-453: -log(exp(x_t) / (sum_c exp(x_c) + 1e-20)), no max-subtraction); backward (softmax - onehot)/N
+// (the reference's own backward throws).
+cyg::tptr<float> cross_entropy_loss(const cyg::tptr<float> logits, const cyg::tptr<int> target);
+
+// Optimisers over device-resident parameters (reference nn.h:156-191).  SGD is the textbook update
+// p -= lr * (g + weight_decay * p) (+ momentum buffers); the reference's step() reads an empty velocity vector
+// (nn.cpp:414) and cannot run, so there is nothing to be bit-compatible with.
+class Optimizer {
+public:
+    explicit Optimizer(std::vector<cyg::tptr<float>> parameters) : _parameters(std::move(parameters)) {}
+    void zero_grad();
+    std::vector<cyg::tptr<float>> _parameters;
+};
+
+class SGD : public Optimizer {
+public:
+    SGD(std::vector<cyg::tptr<float>> parameters, float lr, float momentum = 0, float dampening = 0, float weight_decay = 0,
+        bool nestorov = false)
+        : Optimizer(std::move(parameters)), _lr(lr), _dampening(dampening), _momentum(momentum), _weight_decay(weight_decay),
+          _nestorov(nestorov)
+    {
+    }
+    void step();
+    float _lr, _dampening, _momentum, _weight_decay;
+    bool _nestorov;
+};
+
 }  // namespace nn
 
 #endif

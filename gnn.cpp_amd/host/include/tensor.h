@@ -284,6 +284,14 @@ public:
         return _st->d();
     }
     T *device_out() { return _st->d_out(); }
+    // valid device contents that a kernel is about to update in place (optimiser step)
+    T *device_inplace()
+    {
+        materialize();
+        T *p = _st->d();
+        _st->host_ok = false;
+        return p;
+    }
     // storage as it is laid out ([rows, cols] of the UNtransposed buffer) + whether this tensor views it transposed
     T *device_storage(bool &transposed)
     {

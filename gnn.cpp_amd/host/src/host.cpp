@@ -394,6 +394,76 @@ tptr<float> ReLU::forward(const tptr<float> &input_tensor)
     return out;
 }
 
+// ---- loss + optimiser
+namespace {
+class CrossEntropyOp : public cyg::Operation<tensor<float>> {
+public:
+    tptr<int> target;
+    CrossEntropyOp() { name = "CrossEntropy"; }
+    tptr<float> forward(const tptr<float> &logits, const tptr<int> &tgt)
+    {
+        if (logits->rank() != 2 || tgt->rank() != 1)
+            throw std::runtime_error("invalid input, logits must be of rank 2 and targets must be 1D tensor");
+        const auto shp = logits->shape();
+        if (tgt->numel() != shp[0]) throw std::runtime_error(ERROR_SIZE_MISMATCH);
+        target = tgt;
+        size_t wsb = 0;
+        detail::gx(gnnx_softmax_ce_workspace((int64_t)shp[0], &wsb), "cross_entropy");
+        auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1}, logits->requires_grad());
+        detail::gx(gnnx_softmax_ce_f32(logits->device_data(), (int64_t)shp[1], tgt->device_data(), (int64_t)shp[0], (int32_t)shp[1],
+                                       out->device_out(), nullptr, 0, detail::workspace(wsb), wsb, detail::current_stream()),
+                   "cross_entropy");
+        if (out->requires_grad()) context->save_for_backward({logits});
+        return out;
+    }
+    void _backward(std::shared_ptr<tensor<float>> g) override
+    {
+        auto var = context->get_variables();
+        CHECK_BACKWARD<tensor<float>>(var, 1);
+        auto logits = var[0];
+        if (!logits->requires_grad()) return;
+        const auto shp = logits->shape();
+        size_t wsb = 0;
+        detail::gx(gnnx_softmax_ce_workspace((int64_t)shp[0], &wsb), "cross_entropy");
+        auto d = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
+        void *st = detail::current_stream();
+        detail::gx(gnnx_softmax_ce_f32(logits->device_data(), (int64_t)shp[1], target->device_data(), (int64_t)shp[0], (int32_t)shp[1],
+                                       nullptr, d->device_out(), (int64_t)shp[1], detail::workspace(wsb), wsb, st), "cross_entropy");
+        const float up = g->item();  // upstream scalar (1 for loss->backward())
+        if (up != 1.0f) {
+            auto scaled = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
+            detail::gx(gnnx_fill_f32(scaled->device_out(), (int64_t)scaled->numel(), 0.0f, st), "cross_entropy");
+            detail::gx(gnnx_axpy_f32((int64_t)scaled->numel(), up, d->device_data(), scaled->device_inplace(), st), "cross_entropy");
+            d = scaled;
+        }
+        logits->backward(d);
+    }
+};
+}  // namespace
+
+tptr<float> cross_entropy_loss(const tptr<float> logits, const tptr<int> target)
+{
+    auto op = std::make_unique<CrossEntropyOp>();
+    auto out = op->forward(logits, target);
+    if (out->requires_grad()) out->grad_fn = std::move(op);
+    return out;
+}
+
+void Optimizer::zero_grad()
+{
+    for (auto &p : _parameters) p->zero_grad();
+}
+
+void SGD::step()
+{
+    if (_momentum != 0) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);  // plain SGD only (momentum: next)
+    for (auto &p : _parameters) {
+        float *g = p->device_grad();
+        if (!g) continue;
+        detail::gx(gnnx_sgd_step_f32(p->device_inplace(), g, (int64_t)p->numel(), _lr, _weight_decay, detail::current_stream()), "SGD");
+    }
+}
+
 }  // namespace nn
 
 // ---------------------------------------------------------------------------------------------------- graph

@@ -273,3 +273,62 @@ def gcn_layer_bwd(g, X, W, G):
     dH = aggregate_bwd(g, G)
     dX, dW = linear_bwd(dH, X, W)
     return dict(dbias=dbias, dH=dH, dX=dX, dW=dW)
+
+
+# ---- whole training step: multi-layer GCN + softmax cross-entropy + SGD ----------
+def softmax_ce(logits, target, want_grad=True):
+    """(mean loss as a 1-element device tensor, dlogits or None): gnnx_softmax_ce_f32 (reference forward nn.cpp:442-453)."""
+    N, Cn = logits.shape
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    d = torch.empty_like(logits) if want_grad else None
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_softmax_ce_workspace", N, C.byref(wsb))
+    ws = _workspace(wsb.value, logits.device, "ce")
+    capi.call("gnnx_softmax_ce_f32", _ptr(logits), _ld(logits), _ptr(target), N, Cn, _ptr(loss), _ptr(d), _ld(d) if want_grad else 0,
+              _ptr(ws), wsb.value, _stream())
+    return loss, d
+
+
+def sgd_step(param, grad, lr, weight_decay=0.0):
+    capi.call("gnnx_sgd_step_f32", _ptr(param), _ptr(grad), param.numel(), float(lr), float(weight_decay), _stream())
+    return param
+
+
+class GcnStack:
+    """L GCN layers on one graph: h_{l+1} = act( norm (.) (A . (h_l W_l^T)) + b_l ), ReLU between layers, none after the
+    last.  forward / backward / SGD step, every op a C-ABI call; activations are kept for backward."""
+
+    def __init__(self, g, dims, seed=0, device="cuda"):
+        self.g = g
+        self.W = [uniform_pm1(seed + 2 * l, (dims[l + 1], dims[l]), scale=dims[l] ** -0.5, device=device) for l in range(len(dims) - 1)]
+        self.b = [torch.zeros(dims[l + 1], dtype=torch.float32, device=device) for l in range(len(dims) - 1)]
+        self.dW = [torch.zeros_like(w) for w in self.W]
+        self.db = [torch.zeros_like(b) for b in self.b]
+        self._saved = None
+
+    def forward(self, X):
+        saved, h = [], X
+        L = len(self.W)
+        for l in range(L):
+            H = linear_fwd(h, self.W[l])
+            Z = aggregate_fwd(self.g, H, self.b[l])
+            Y = bn_relu_fwd(Z, relu=True) if l + 1 < L else Z
+            saved.append((h, Z, Y))
+            h = Y
+        self._saved = saved
+        return h
+
+    def backward(self, dOut):
+        G = dOut
+        for l in reversed(range(len(self.W))):
+            h, Z, Y = self._saved[l]
+            if l + 1 < len(self.W):
+                G, _, _ = bn_relu_bwd(Z, Y, G, relu=True)
+            colsum(G, out=self.db[l])
+            dH = aggregate_bwd(self.g, G)
+            G, _ = linear_bwd(dH, h, self.W[l], dW=self.dW[l])
+        return G
+
+    def step(self, lr, weight_decay=0.0):
+        for p, gr in zip(self.W + self.b, self.dW + self.db):
+            sgd_step(p, gr, lr, weight_decay)

@@ -211,6 +211,21 @@ int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_
                          float *d_dX, int64_t ldo, float *d_dgamma, float *d_dbeta, void *d_workspace, size_t workspace_bytes,
                          void *stream);
 
+/* ------------------------------------------------------------------ next row: loss + optimiser ---- */
+/*
+ * Softmax cross-entropy on the last layer's logits and the SGD update, so a multi-layer GCN runs as a whole training
+ * step on the device.
+ *   loss    = mean_i -log( exp(x_i[t_i]) / (sum_c exp(x_ic) + 1e-20) )     the reference's forward, nn.cpp:442-453
+ *             (no max-subtraction, like the reference); d_loss: one float on the device (may be NULL)
+ *   dlogits = (softmax(x_i) - onehot(t_i)) / N                             textbook (the reference's backward throws);
+ *             may be NULL.  Synchronises `stream` (validates the targets: GNNX_ERR_INDEX_RANGE).
+ *   sgd     : p -= lr * (g + weight_decay * p)                             textbook (nn.cpp:395-421 indexes an empty vector)
+ */
+int gnnx_softmax_ce_workspace(int64_t n_rows, size_t *bytes);
+int gnnx_softmax_ce_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes, float *d_loss,
+                        float *d_dlogits, int64_t ldd, void *d_workspace, size_t workspace_bytes, void *stream);
+int gnnx_sgd_step_f32(float *d_param, const float *d_grad, int64_t n, float lr, float weight_decay, void *stream);
+
 /* ------------------------------------------------------------------ halo (multi-GPU) ------------- */
 /* Pack rows for the all-to-all-v send buffer: out[k,:] = X[idx[k],:]; and the reverse for backward:
  * Y[idx[k],:] += in[k,:] (idx may repeat across calls but NOT within one call => no atomics, deterministic). */

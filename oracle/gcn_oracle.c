@@ -323,6 +323,24 @@ API void gcn_oracle_bn_relu_fwd(const float *X, int64_t N, int32_t F, const floa
     free(sd);
 }
 
+/* Softmax cross-entropy, forward value only (the reference's backward throws): nn.cpp:442-453.
+ *   x_n = logits->at(target); out = exp(x_n) / (exp(logits)->sum(-1) + 1e-20); out = -(log(out)); out->sum() / numel
+ * row sums and the final sum walk UP (functional::sum materialises), every op separately rounded. */
+API float gcn_oracle_cross_entropy(const float *logits, const int32_t *target, int64_t N, int32_t Cn)
+{
+    float total = 0.0f;
+    for (int64_t i = 0; i < N; i++) {
+        const float *x = logits + i * Cn;
+        float s = expf(x[0]);
+        for (int32_t c = 1; c < Cn; c++) s += expf(x[c]);
+        float denom = s + (float)1e-20;
+        float o = expf(x[target[i]]) / denom;
+        float l = logf(o) * -1.0f;
+        total = i == 0 ? l : total + l;
+    }
+    return total / (float)(int)N;
+}
+
 /* out[d] = powf((float)d, -0.5f) for d in [0,n): the libm call behind functional.h:253 (std::pow on valarrays),
  * exposed so the tests can measure where a device-side (float)(1/sqrt((double)d)) differs from it. */
 API void gcn_oracle_powf_table(int32_t n, float *out)

@@ -15,7 +15,7 @@ _lib = None
 
 __all__ = ["build", "coo_to_csr", "csr_transpose", "degree_norm", "linear_fwd", "aggregate_fwd",
            "aggregate_bwd", "colsum", "linear_bwd", "dense_aggregate", "set_threads", "max_threads",
-           "powf_table", "bn_relu_fwd", "gcn_layer_fwd", "gcn_layer_bwd", "ref_driver_path"]
+           "powf_table", "bn_relu_fwd", "cross_entropy", "gcn_layer_fwd", "gcn_layer_bwd", "ref_driver_path"]
 
 
 def build():
@@ -170,6 +170,15 @@ def bn_relu_fwd(X, gamma=None, beta=None, eps=1e-5, do_bn=True, do_relu=True):
     _L().gcn_oracle_bn_relu_fwd(_p(X), C.c_int64(N), C.c_int32(F), _p(gamma), _p(beta), C.c_float(eps), C.c_int(int(do_bn)),
                                 C.c_int(int(do_relu)), _p(Y), _p(mean), _p(var))
     return Y, mean, var
+
+
+def cross_entropy(logits, target):
+    """Mean softmax cross-entropy, the reference's forward arithmetic (nn.cpp:442-453)."""
+    logits = _f32(logits)
+    target = np.ascontiguousarray(target, dtype=np.int32)
+    L = _L()
+    L.gcn_oracle_cross_entropy.restype = C.c_float
+    return float(L.gcn_oracle_cross_entropy(_p(logits), _p(target), C.c_int64(logits.shape[0]), C.c_int32(logits.shape[1])))
 
 
 def powf_table(n):

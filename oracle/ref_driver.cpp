@@ -145,6 +145,13 @@ int main(int argc, char **argv)
         auto Hrelu = (*layer2.get_module("relu"))(Hbn);
         dump_va(outdir, "Hbn.f32", *Hbn->data());
         dump_va(outdir, "Hrelu.f32", *Hrelu->data());
+        // softmax cross-entropy of the layer output against synthetic targets t_i = (7 i + 3) mod F_out (nn.cpp:442-453)
+        vector<int> tgt(N);
+        for (size_t i = 0; i < N; i++) tgt[i] = (int)((7 * i + 3) % Fout);
+        vector<size_t> td = {N};
+        auto target = make_shared<tensor<int>>(td, new valarray<int>(tgt.data(), N), false);
+        auto loss = nn::cross_entropy_loss(out_full, target);
+        dump_va(outdir, "loss.f32", *loss->data());
     }
 
     printf("{\"N\": %zu, \"E\": %zu, \"nnz\": %zu, \"Fin\": %zu, \"Fout\": %zu, \"t_selfloops\": %.6f, "

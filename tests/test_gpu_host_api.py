@@ -40,15 +40,15 @@ def run_driver(d, unfused=False):
                     out=rd("out.f32", np.float32).reshape(n, fout), dX=rd("dX.f32", np.float32).reshape(n, fin),
                     dW=rd("dW.f32", np.float32).reshape(fout, fin), dbias=rd("dbias.f32", np.float32),
                     out_full=rd("out_full.f32", np.float32).reshape(n, fout), Hbn=rd("Hbn.f32", np.float32).reshape(n, fout),
-                    Hrelu=rd("Hrelu.f32", np.float32).reshape(n, fout))
+                    Hrelu=rd("Hrelu.f32", np.float32).reshape(n, fout), loss=rd("loss.f32", np.float32))
 
 
 @pytest.mark.parametrize("name", ["karate_l1", "rmat1024", "cora_l2"])
 def test_fused_and_op_by_op_paths_give_the_same_bits(name):
     d = load_case(name)
     a, b = run_driver(d, unfused=False), run_driver(d, unfused=True)
-    for k in ("ei2", "s", "norm", "H", "agg", "out", "dX", "dW", "dbias", "out_full", "Hbn", "Hrelu"):
-        assert np.array_equal(a[k], b[k]), k
+    for k in ("ei2", "s", "norm", "H", "agg", "out", "dX", "dW", "dbias", "out_full", "Hbn", "Hrelu", "loss"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -72,6 +72,11 @@ def test_reference_call_sites_run_on_the_hip_backend(name):
     assert np.array_equal(got["Hrelu"], np.maximum(got["Hbn"], 0)), "nn::ReLU forward"
     assert_close(got["Hrelu"], d["ref_Hrelu"], "BatchNorm+ReLU vs reference")
     assert_close(got["out_full"], d["ref_out_full"], "GCNConv::forward (full layer)")
+    # nn::cross_entropy_loss on the layer output (targets (7i+3) mod F_out); NaN where the reference's own value is NaN
+    if np.isnan(d["ref_loss"][0]):
+        assert np.isnan(got["loss"][0])
+    else:
+        assert abs(float(got["loss"][0]) - float(d["ref_loss"][0])) <= 1e-5 * max(1.0, abs(float(d["ref_loss"][0])))
     # autograd: out->backward(G) through Add -> Mul -> MatMul(CSR) -> MatMul -> Transpose
     G64, X64 = d["G"].astype(np.float64), d["X"].astype(np.float64)
     rT, cT = oracle.csr_transpose(rp, ci, d["n"])

@@ -573,3 +573,73 @@ def test_multi_layer_gcn_at_baseline_sizes_vs_oracle(env, n, e, F, L, abc, seed)
         rdX, _ = oracle.linear_bwd(dHh, host(inputs[l]), Ws[l], need_dw=False)
         assert_close(host(dX), rdX, f"layer {l} dX", absum=a64(dHh) @ a64(Ws[l]))
         G = dX
+
+
+# ------------------------------------------------------------------ next row: loss + optimiser + multi-layer step
+def test_softmax_cross_entropy_vs_oracle_and_float64(env):
+    ops = env["ops"]
+    n, c = 20000, 47
+    X = synth.uniform_pm1(501, (n, c)) * 4.0
+    t = ((7 * np.arange(n) + 3) % c).astype(np.int32)
+    loss, d = ops.softmax_ce(dev(env, X), dev(env, t))
+    ref = oracle.cross_entropy(X, t)
+    assert abs(float(host(loss)[0]) - ref) <= 1e-5 * max(1.0, abs(ref))
+    x = X.astype(np.float64)
+    p = np.exp(x) / np.exp(x).sum(1, keepdims=True)
+    p[np.arange(n), t] -= 1.0
+    assert np.abs(host(d) - p / n).max() <= 1e-5 / n * 10
+    with pytest.raises(env["capi"].GnnxError):
+        ops.softmax_ce(dev(env, X), dev(env, np.full(n, c, dtype=np.int32)))
+
+
+def test_two_layer_training_step_vs_float64(env):
+    """Whole step of a 2-layer GCN (transform, aggregate, ReLU, transform, aggregate, softmax-CE, backward, SGD) against a
+    float64 numpy evaluation of the same network; then the loss goes down under SGD."""
+    ops, torch = env["ops"], env["torch"]
+    n, e, dims = 3000, 24000, [32, 16, 7]
+    src, dst = synth.rmat_edges(77, n, e)
+    g = ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), n)
+    rp, ci = oracle.coo_to_csr(src, dst, n)
+    _, norm = oracle.degree_norm(rp, ci, n)
+    X = synth.uniform_pm1(601, (n, dims[0]))
+    t = ((7 * np.arange(n) + 3) % dims[-1]).astype(np.int32)
+    net = ops.GcnStack(g, dims, seed=610)
+    for l in range(2):
+        net.b[l].copy_(dev(env, synth.uniform_pm1(620 + l, (dims[l + 1],), scale=0.2)))
+    W = [host(w).astype(np.float64) for w in net.W]
+    b = [host(v).astype(np.float64) for v in net.b]
+    logits = net.forward(dev(env, X))
+    loss, dlog = ops.softmax_ce(logits, dev(env, t))
+    net.backward(dlog)
+    # ---- float64 reference
+    import scipy.sparse as sp
+    A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(n, n))
+    S = sp.diags(norm.astype(np.float64)) @ A
+    x0 = X.astype(np.float64)
+    z1 = S @ (x0 @ W[0].T) + b[0]
+    y1 = np.maximum(z1, 0)
+    z2 = S @ (y1 @ W[1].T) + b[1]
+    ex = np.exp(z2)
+    p = ex / ex.sum(1, keepdims=True)
+    loss_ref = float(-np.log(p[np.arange(n), t]).mean())
+    dz2 = p.copy()
+    dz2[np.arange(n), t] -= 1
+    dz2 /= n
+    dh2 = S.T @ dz2
+    dW1, db1 = dh2.T @ y1, dz2.sum(0)
+    dz1 = (dh2 @ W[1]) * (z1 > 0)
+    dh1 = S.T @ dz1
+    dW0, db0 = dh1.T @ x0, dz1.sum(0)
+    assert abs(float(host(loss)[0]) - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+    for got, ref, nm in ((net.dW[1], dW1, "dW1"), (net.db[1], db1, "db1"), (net.dW[0], dW0, "dW0"), (net.db[0], db0, "db0")):
+        err = np.abs(host(got) - ref).max()
+        assert err <= 2e-5 * max(np.abs(ref).max(), 1e-3), f"{nm}: {err:.3e} vs scale {np.abs(ref).max():.3e}"
+    # ---- SGD: the loss decreases
+    losses = []
+    for _ in range(20):
+        logits = net.forward(dev(env, X))
+        loss, dlog = ops.softmax_ce(logits, dev(env, t))
+        losses.append(float(host(loss)[0]))
+        net.backward(dlog)
+        net.step(lr=0.5)
+    assert losses[-1] < losses[0] * 0.98 and all(np.isfinite(losses))
