@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--workload", default="rmat10m_100m_f256", choices=sorted(WORKLOADS))
     ap.add_argument("--chunk", type=int, default=4096, help="plan: split rows longer than this (0 = never)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-layers", type=int, default=0,
+                    help="N=1 only: time a whole training step of an L-layer GCN instead (forward, softmax-CE, backward, SGD); "
+                         "value counts L*nnz edges per step")
     ap.add_argument("--native-comm", action="store_true",
                     help="N>1: halo all-to-all-v and all-reduce through the C-ABI (gnnx_halo_exchange_f32) instead of torch.distributed")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank (rehearsal)")
@@ -113,7 +116,10 @@ def main():
 
     n, e, F, abc, seed = WORKLOADS[args.workload]
     t_build0 = time.time()
-    if world == 1 and not args.force_sharded:
+    if world == 1 and not args.force_sharded and args.train_layers > 0:
+        runner = TrainStep(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk, args.train_layers)
+        runner.workload = args.workload
+    elif world == 1 and not args.force_sharded:
         runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk)
         runner.workload = args.workload
     else:
@@ -142,7 +148,7 @@ def main():
         dt = float(t.item())
 
     ms_per_step = dt / args.steps * 1e3
-    nnz_total = runner.nnz_total
+    nnz_total = runner.nnz_total * max(1, args.train_layers)
     roof = runner.roofline()
     if dist:  # slowest rank's forward SpMM defines the job's roofline line
         t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=dev)
@@ -170,7 +176,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": nnz_total,
-                       "features": F, "layer": f"{F}->{F}", "step": "layer fwd+bwd",
+                       "features": F, "layer": f"{F}->{F}",
+                       "step": "layer fwd+bwd" if not args.train_layers else
+                       f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 else f"1-D vertex shard x{world}, halo all-to-all-v",
                        "plan_chunk": args.chunk},
             "roofline": roof,
@@ -255,6 +263,38 @@ class SingleGpu:
                 "traffic_source": tr[1] if tr else None,
                 "algorithmic_bytes_per_launch": B, "bytes_per_edge": B / max(1, self.g.nnz), "avg_launch_ms": ms,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0}
+
+
+class TrainStep(SingleGpu):
+    """Whole training step of an L-layer GCN (ops.GcnStack): forward with ReLU between layers, softmax cross-entropy
+    against synthetic labels, backward, SGD.  Reuses SingleGpu's graph / plans / roofline bookkeeping."""
+
+    def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk, layers):
+        super().__init__(ops, capi, pkg, dev, n, e, F, abc, seed, chunk)
+        for nm in ("H", "out", "dH", "dX", "G"):
+            setattr(self, nm, None)  # free the single-layer buffers
+        torch.cuda.empty_cache()
+        self.net = ops.GcnStack(self.g, [F] * (layers + 1), seed=seed + 100, device=dev)
+        self.target = (torch.arange(n, device=dev, dtype=torch.int64) * 7 + 3).remainder(F).to(torch.int32)
+        self.names = ["train_step"]
+
+    def step(self, timed=False):
+        ops = self.ops
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if timed:
+            a, b = self.capi.Event(), self.capi.Event()
+            a.record(stream)
+        logits = self.net.forward(self.X)
+        _, dlog = ops.softmax_ce(logits, self.target)
+        self.net.backward(dlog)
+        self.net.step(lr=1e-3)
+        if timed:
+            b.record(stream)
+            self.ev.append([(a, b)])
+
+    def roofline(self):
+        return {"bound": "hbm", "kernel": "n/a for --train-layers (see the default run)", "achieved": None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": None, "traffic": None}
 
 
 def cpu_baseline(pkg, args, F, abc, seed):
