@@ -175,7 +175,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": nnz_total,
+            "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": runner.nnz_total,
                        "features": F, "layer": f"{F}->{F}",
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
