@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--train-layers", type=int, default=0,
                     help="N=1 only: time a whole training step of an L-layer GCN instead (forward, softmax-CE, backward, SGD); "
                          "value counts L*nnz edges per step")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="N=1: capture one step (6 kernel launches + their small helpers) into a hipGraph and replay it in the "
+                         "timed loop -- for launch-bound sizes such as the Cora-sized config")
     ap.add_argument("--native-comm", action="store_true",
                     help="N>1: halo all-to-all-v and all-reduce through the C-ABI (gnnx_halo_exchange_f32) instead of torch.distributed")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank (rehearsal)")
@@ -131,12 +134,28 @@ def main():
     for _ in range(args.warmup):
         runner.step()
     torch.cuda.synchronize()
+    graph = None
+    if args.hip_graph and world == 1 and not args.force_sharded and not args.train_layers:
+        # the C-ABI compute calls neither allocate nor synchronise, so a step is capturable as is (workspaces were
+        # grown by the warm-up); capture runs on a side stream, replay on the current one
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            runner.step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            runner.step()
+        torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        runner.step(timed=True)
+        if graph is not None:
+            graph.replay()
+        else:
+            runner.step(timed=True)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -149,6 +168,9 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     nnz_total = runner.nnz_total * max(1, args.train_layers)
+    if graph is not None:  # per-kernel HIP events are not recorded inside a replayed graph: time the kernels once eagerly
+        runner.step(timed=True)
+        torch.cuda.synchronize()
     roof = runner.roofline()
     if dist:  # slowest rank's forward SpMM defines the job's roofline line
         t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=dev)
@@ -180,7 +202,7 @@ def main():
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 else f"1-D vertex shard x{world}, halo all-to-all-v",
-                       "plan_chunk": args.chunk},
+                       "plan_chunk": args.chunk, "hip_graph": graph is not None},
             "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,

@@ -226,6 +226,26 @@ def test_spmm_split_rows_plan(env):
     assert same(host(ops.aggregate_fwd(g, dev(env, H), use_plan=False)), ref)
 
 
+@pytest.mark.parametrize("F", [16, 7, 33])
+def test_spmm_split_rows_plan_narrow_features(env, F):
+    """The plan (chunk items + combine) through the one-row-per-group kernel used at F <= 64, vector and scalar lanes."""
+    ops = env["ops"]
+    n = 5000
+    src, dst, rp, ci, g = make_graph(env, n, 120000, seed=15)
+    deg = np.diff(rp)
+    assert deg.max() > 500
+    s, norm = oracle.degree_norm(rp, ci, n)
+    H = synth.uniform_pm1(33, (n, F))
+    bias = synth.uniform_pm1(34, (F,))
+    ref = oracle.aggregate_fwd(rp, ci, H, norm, bias)
+    plan = ops.SpmmPlan(g.rowptr, 64, F)
+    assert plan.n_split_rows == int((deg > 64).sum())
+    out = host(ops.spmm(g.rowptr, g.colidx, dev(env, H), rowscale=g.norm, bias=dev(env, bias), plan=plan))
+    assert same(out[deg <= 64], ref[deg <= 64])
+    assert np.abs(out - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    assert same(host(ops.spmm(g.rowptr, g.colidx, dev(env, H), rowscale=g.norm, bias=dev(env, bias))), ref)
+
+
 def test_spmm_vals_and_sym_mode(env):
     """Mode SYM (textbook D^-1/2 A D^-1/2) and per-edge values, vs float64 numpy."""
     ops = env["ops"]
