@@ -257,6 +257,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *slab, i
     }
 }
 
+// Calibration: register-only MFMA loop (4 independent accumulators per wavefront, no memory traffic) -- what the
+// fp32 matrix pipe sustains on THIS chip at the clock it holds under load; the GEMM's fraction of that is the honest
+// utilisation figure next to the 157.3 TFLOP/s datasheet peak.
+__global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float *sink)
+{
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = (float)(threadIdx.x + r);
+    float a = 1.0f + threadIdx.x * 1e-3f, b = 1.0f - threadIdx.x * 1e-3f;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][7];
+    if (s == 12345.678f) sink[0] = s;  // keep the loop alive
+}
+
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 using CfgDefault = Cfg<128, 128, 32, 2, 2>;  // 256 threads, 66 KB LDS, 2 workgroups per CU
@@ -264,11 +285,12 @@ using CfgWide = Cfg<128, 256, 16, 2, 4>;     // 512 threads, 49 KB LDS: one pass
 using CfgK16 = Cfg<128, 128, 16, 2, 2>;      // 33 KB LDS: 3 workgroups per CU
 using CfgWide32 = Cfg<128, 256, 32, 2, 4>;   // 512 threads, 97 KB LDS: one workgroup per CU, half the barriers
 using CfgTall = Cfg<256, 256, 16, 4, 4>;     // 1024 threads, 66 KB LDS
+using CfgTall32 = Cfg<256, 256, 32, 4, 4>;   // 1024 threads, 132 KB LDS: half the barriers
 
-// Tile choice.  Default ("auto"): 256 x 256 / 1024 threads when the output is at least that big (A and B are each
+// Tile choice.  Default ("auto"): 256 x 256 x 32 / 1024 threads (132 KB LDS) when the output is at least that big (A and B are each
 // streamed once for a 256-wide output: 118-121 TFLOP/s at the bench shape vs 111 for 128 x 128), 128 x 256 for wide
 // but short outputs, 128 x 128 otherwise.  GNNX_GEMM_TILE=square|wide|k16|wide32|tall forces one (A/B experiments).
-enum TileId { kSquare = 0, kWide = 1, kK16 = 2, kWide32 = 3, kTall = 4 };
+enum TileId { kSquare = 0, kWide = 1, kK16 = 2, kWide32 = 3, kTall = 4, kTall32 = 5 };
 
 int forced_tile()
 {
@@ -280,6 +302,7 @@ int forced_tile()
         if (!strcmp(e, "k16")) return (int)kK16;
         if (!strcmp(e, "wide32")) return (int)kWide32;
         if (!strcmp(e, "tall")) return (int)kTall;
+        if (!strcmp(e, "tall32")) return (int)kTall32;
         return -1;
     }();
     return v;
@@ -291,8 +314,8 @@ int pick_tile(int64_t M, int64_t N)
     if (f == kK16 || f == kSquare) return f;
     if (N <= 128) return kSquare;
     if (f == kWide || f == kWide32) return f;
-    if (f == kTall) return kTall;
-    return M >= 256 ? kTall : kWide;
+    if (f == kTall || f == kTall32) return f;
+    return M >= 256 ? kTall32 : kWide;
 }
 
 struct TileDims { int bm, bn, bk; };
@@ -303,6 +326,7 @@ TileDims tile_dims(int64_t M, int64_t N)
     case kK16: return {CfgK16::BM, CfgK16::BN, CfgK16::BK};
     case kWide32: return {CfgWide32::BM, CfgWide32::BN, CfgWide32::BK};
     case kTall: return {CfgTall::BM, CfgTall::BN, CfgTall::BK};
+    case kTall32: return {CfgTall32::BM, CfgTall32::BN, CfgTall32::BK};
     default: return {CfgDefault::BM, CfgDefault::BN, CfgDefault::BK};
     }
 }
@@ -353,11 +377,21 @@ int launch(const GemmArgs &g, int splits, bool va, bool vb, hipStream_t st)
     case kK16: return launch_cfg<CfgK16, A_KC, B_KC>(g, splits, va, vb, st);
     case kWide32: return launch_cfg<CfgWide32, A_KC, B_KC>(g, splits, va, vb, st);
     case kTall: return launch_cfg<CfgTall, A_KC, B_KC>(g, splits, va, vb, st);
+    case kTall32: return launch_cfg<CfgTall32, A_KC, B_KC>(g, splits, va, vb, st);
     default: return launch_cfg<CfgDefault, A_KC, B_KC>(g, splits, va, vb, st);
     }
 }
 
 }  // namespace
+
+GNNX_API int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_sink, double *flops_out, void *stream)
+{
+    GNNX_REQUIRE(iters > 0 && n_workgroups > 0 && d_sink, GNNX_ERR_INVALID_ARG, "bad arguments");
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3((uint32_t)n_workgroups), dim3(256), 0, as_stream(stream), iters, d_sink);
+    GNNX_LAUNCH_CHECK();
+    if (flops_out) *flops_out = (double)n_workgroups * 4 /*waves*/ * 4 /*acc*/ * (double)iters * (2.0 * 32 * 32 * 2);
+    return GNNX_OK;
+}
 
 GNNX_API int gnnx_gemm_workspace(int transA, int transB, int64_t M, int64_t N, int64_t K, size_t *bytes)
 {

@@ -158,6 +158,11 @@ int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float
                   int64_t lda, const float *d_B, int64_t ldb, float beta, float *d_C, int64_t ldc,
                   void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Calibration aid for the roofline: a register-only v_mfma_f32_32x32x2_f32 loop (no memory traffic).  *flops_out is
+ * the number of flops the launch performs; time it with events to get the fp32 matrix rate this chip sustains at the
+ * clock it holds under load. */
+int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_sink, double *flops_out, void *stream);
+
 /* ------------------------------------------------------------------ small ops on the path -------- */
 /* dbias: out[f] = beta*out[f] + sum_i G[i,f]  (Add::_backward -> sum_to_size, reference operation.h:114-128,
  * tensor.h:618-638).  Two-stage deterministic tree (fixed grid); workspace gnnx_colsum_workspace() bytes. */

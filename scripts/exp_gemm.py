@@ -56,3 +56,16 @@ def main():
 
 
 main()
+
+
+def mfma_peak():
+    sink = torch.zeros(16, dtype=torch.float32, device=dev)
+    fl = C.c_double(0)
+    for wgs in (256, 512, 1024, 2048):
+        capi.call("gnnx_mfma_peak_f32", 20000, wgs, C.c_void_p(sink.data_ptr()), C.byref(fl), None)
+        ms = timeit(lambda: capi.call("gnnx_mfma_peak_f32", 20000, wgs, C.c_void_p(sink.data_ptr()), C.byref(fl), None), reps=3)
+        print(f"mfma peak loop, {wgs} workgroups x 4 waves: {fl.value / ms / 1e9:.1f} TFLOP/s", flush=True)
+
+
+if os.environ.get("PEAK"):
+    mfma_peak()
