@@ -174,6 +174,22 @@ __device__ __forceinline__ void epilogue_store(typename Vec<VEC>::type acc, int3
     *dst = acc;
 }
 
+// Same epilogue with the per-row scale and the bias already in registers.  Inside the streaming loop a fresh vector load
+// (bias[f], rowscale[row]) would have to wait behind the whole batch of neighbour rows just put in flight -- VMEM returns
+// in order -- i.e. drain the pipeline at every row boundary; so both are fetched ahead (bias once per group, rowscale
+// one entry per lane for the block's rows).
+template <int VEC>
+__device__ __forceinline__ void epilogue_store_pre(typename Vec<VEC>::type acc, int32_t row, int32_t f0, const SpmmArgs &a,
+                                                   bool has_rs, float rs, bool has_bias, typename Vec<VEC>::type bias)
+{
+    using V = typename Vec<VEC>::type;
+    if (has_rs) acc = mul_rn(acc, rs);
+    if (has_bias) acc = add_rn(acc, bias);
+    V *dst = reinterpret_cast<V *>(a.Y + (int64_t)row * a.ldy + f0);
+    if (a.beta) acc = add_rn(*dst, acc);
+    *dst = acc;
+}
+
 // grid.x = n_item_blocks + n_row_blocks ; grid.y = feature tiles of G*VEC features.
 template <int G, int VEC, int U, int MODE>
 __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_blocks)
@@ -240,12 +256,15 @@ struct Stream {
     bool active;
     int32_t r0;      // first row of the block
     int32_t rp_l;    // lane l holds rowptr[r0 + min(l, nr)]
+    float rs_l;      // lane l holds rowscale[r0 + min(l, nr - 1)] (if any)
+    V bias_v;        // this lane's slice of the bias (if any)
 
     __device__ __forceinline__ int32_t rp(int l) const { return bcast<G>(rp_l, l, gbase); }
 
     __device__ __forceinline__ void flush(V &acc, int r) const
     {
-        if (active) epilogue_store<VEC>(acc, r0 + r, f0, a);
+        const float rs = __int_as_float(bcast<G>(__float_as_int(rs_l), r, gbase));
+        if (active) epilogue_store_pre<VEC>(acc, r0 + r, f0, a, a.rowscale != nullptr, rs, a.bias != nullptr, bias_v);
         zero(acc);
     }
 
@@ -393,7 +412,11 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
         nr = a.n_rows - r0 < R ? a.n_rows - r0 : R;
     }
     const int gbase = (tid & 63) - li;
-    Stream<G, VEC, B, MODE> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)]};
+    typename Vec<VEC>::type bias_v;
+    zero(bias_v);
+    if (a.bias && active) bias_v = ld_vec(reinterpret_cast<const typename Vec<VEC>::type *>(a.bias + f0));
+    const float rs_l = a.rowscale ? a.rowscale[r0 + (li < nr ? li : nr - 1)] : 1.f;
+    Stream<G, VEC, B, MODE> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)], rs_l, bias_v};
 
     uint64_t hub = 0;  // bit l: local row l is a hub (left to the chunk items)
     if (a.split_threshold > 0) {
