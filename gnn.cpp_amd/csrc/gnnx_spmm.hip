@@ -435,6 +435,130 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     }
 }
 
+// ---- LDS-staged variant (measurement only: GNNX_SPMM_VARIANT=lds, F = 256, forward mode) ---------------------------
+// Same streaming structure, but the neighbour rows land in LDS through LDS-DMA (global_load_lds_dwordx4: one 1-KiB
+// row per wave-instruction, per-lane source address = a row gather) and are summed from there, B = 16 rows per batch,
+// two batches of slots per wavefront (the BASELINE north_star's "LDS staging of feature tiles").  No VGPRs are spent on
+// rows in flight; a row is still consumed by one wavefront only, i.e. LDS adds a write + a read per byte and shares
+// nothing.  Kept to put a number on that choice.  LDS reads go through inline asm: behind a
+// pending LDS-DMA hipcc would otherwise insert s_waitcnt vmcnt(0) in front of every ds_read and drain the pipeline.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef float f32x4_lds __attribute__((ext_vector_type(4)));
+
+template <int B>
+__global__ __launch_bounds__(64) void spmm_lds_kernel(SpmmArgs a, int32_t n_item_blocks)
+{
+    constexpr int G = 64, VEC = 4;
+    __shared__ float lds[2 * B * 256];
+    const int li = threadIdx.x;
+    const int32_t f0 = li * VEC;
+    const float *xf = a.X + f0;
+    if ((int32_t)blockIdx.x < n_item_blocks) {
+        int32_t it = blockIdx.x;
+        if (it >= a.n_items) return;
+        int4 item = a.items[it];
+        item.y = __builtin_amdgcn_readfirstlane(item.y);
+        item.z = __builtin_amdgcn_readfirstlane(item.z);
+        item.w = __builtin_amdgcn_readfirstlane(item.w);
+        auto acc = gather_range<G, VEC, 8, 0>(item.y, item.z, xf, li, a);
+        *reinterpret_cast<float4 *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
+        return;
+    }
+    const int32_t blk = blockIdx.x - n_item_blocks;
+    int32_t r0, nr;
+    if (a.block_starts) {
+        if (blk >= a.n_blocks) return;
+        r0 = __builtin_amdgcn_readfirstlane(a.block_starts[blk]);
+        nr = __builtin_amdgcn_readfirstlane(a.block_starts[blk + 1]) - r0;
+    } else {
+        constexpr int R = StreamCfg<G>::R;
+        const int64_t r0l = (int64_t)blk * R;
+        if (r0l >= a.n_rows) return;
+        r0 = (int32_t)r0l;
+        nr = a.n_rows - r0 < R ? a.n_rows - r0 : R;
+    }
+    const int32_t rp_l = a.rowptr[r0 + (li < nr ? li : nr)];
+    const float rs_l = a.rowscale ? a.rowscale[r0 + (li < nr ? li : nr - 1)] : 1.f;
+    float4 bias_v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) bias_v = *reinterpret_cast<const float4 *>(a.bias + f0);
+    auto rp = [&](int l) { return __builtin_amdgcn_readlane(rp_l, l); };
+    auto flush = [&](float4 &acc, int r) {
+        const float rs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs_l), r));
+        epilogue_store_pre<VEC>(acc, r0 + r, f0, a, a.rowscale != nullptr, rs, a.bias != nullptr, bias_v);
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    uint64_t hub = 0;
+    if (a.split_threshold > 0) {
+        const int32_t nxt = __shfl(rp_l, li + 1, 64);
+        hub = __ballot(li < nr && nxt - rp_l > a.split_threshold);
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t *)lds + (uint32_t)f0 * 4u;  // this lane's 16 bytes of slot 0
+    auto issue = [&](int buf, int32_t chunk_c, int k0) {
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const int32_t c = __builtin_amdgcn_readlane(chunk_c, k0 + u);
+            __builtin_amdgcn_global_load_lds(xf + (int64_t)c * a.ldx, (lds_void_t *)(lds + (buf * B + u) * 256), 16, 0, 0);
+        }
+    };
+    int sa = 0;
+    while (sa < nr) {
+        const uint64_t rest = hub >> sa;
+        if (rest & 1) { sa++; continue; }
+        const int run = rest ? __builtin_ctzll(rest) : 64;
+        const int sb = sa + run < nr ? sa + run : nr;
+        const int32_t lo = rp(sa), hi = rp(sb);
+        const int32_t total = hi - lo;
+        int r = sb - 1;
+        int32_t rs = rp(r);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (total > 0) {
+            auto fetch = [&](int cidx) {
+                int32_t q = hi - 1 - (cidx * G + li);
+                return a.colidx[q < lo ? lo : q];
+            };
+            int32_t cur = fetch(0), nxt = fetch(1);
+            int cidx = 1, buf = 0;
+            issue(0, cur, 0);
+            for (int32_t e = 0; e < total; e += B) {
+                const int kn = (e + B) % G;
+                if (kn == 0) { cur = nxt; cidx++; nxt = fetch(cidx); }
+                issue(buf ^ 1, cur, kn);  // batch e+B in flight (clamped past the end: an in-range row, never added)
+                // all but the B DMAs just issued have completed: batch e is in LDS (and older stores have left)
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+                for (int u0 = 0; u0 < B; u0 += 4) {
+                    f32x4_lds v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(lds_base + (uint32_t)((buf * B + u0 + j) * 1024)) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int u = u0 + j;
+                        if (e + u < total) {
+                            const int32_t q = hi - 1 - (e + u);
+                            while (q < rs) {
+                                flush(acc, r);
+                                r--;
+                                rs = rp(r);
+                            }
+                            acc = add_rn(acc, make_float4(v[j].x, v[j].y, v[j].z, v[j].w));
+                        }
+                    }
+                }
+                buf ^= 1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued tail batch must land before its slots are reused
+        }
+        while (r >= sa) {
+            flush(acc, r);
+            r--;
+        }
+        sa = sb;
+    }
+}
+
 // Combine the partial slabs of split rows in chunk order (chunk 0 holds the HIGHEST columns), then the
 // same epilogue as the main kernel.  One G-lane group per split row.
 template <int G, int VEC>
@@ -501,6 +625,12 @@ bool use_stream_kernel(int G)
     return G >= 32;
 }
 
+bool use_lds_variant()
+{
+    static const bool v = [] { const char *e = getenv("GNNX_SPMM_VARIANT"); return e && strcmp(e, "lds") == 0; }();
+    return v;
+}
+
 // Row r opens a new block when it starts a new group of kPlanBlockRows rows or when its first non-zero falls
 // into another block_nnz-sized bucket than the previous row's: a block then streams < block_nnz + (its last
 // row's degree) non-zeros, whatever the degree skew, and clustered heavy rows end up in blocks of their own.
@@ -537,6 +667,20 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, hipStream_t st
     const bool general = a.vals != nullptr;
     bool stream = false;
     if constexpr (G >= 8) stream = use_stream_kernel(G);
+    if constexpr (G == 64 && VEC == 4) {
+        if (use_lds_variant() && a.n_feat == 256 && !general && !a.colscale) {  // measurement variant, forward mode only
+            grid.x = (uint32_t)(a.n_items + (a.block_starts ? a.n_blocks : ceil_div(a.n_rows, StreamCfg<64>::R)));
+            grid.y = 1;
+            hipLaunchKernelGGL((spmm_lds_kernel<16>), grid, dim3(64), 0, st, a, (int32_t)a.n_items);
+            GNNX_LAUNCH_CHECK();
+            if (plan && plan->n_split_rows > 0) {
+                dim3 cgrid((uint32_t)ceil_div(plan->n_split_rows, GROUPS), 1);
+                hipLaunchKernelGGL((spmm_combine_kernel<G, VEC>), cgrid, dim3(256), 0, st, a, plan->d_rows, plan->n_split_rows);
+                GNNX_LAUNCH_CHECK();
+            }
+            return GNNX_OK;
+        }
+    }
     if (stream) {
         if constexpr (G >= 8) {
             constexpr int R = StreamCfg<G>::R;

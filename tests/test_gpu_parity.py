@@ -663,3 +663,17 @@ def test_two_layer_training_step_vs_float64(env):
         net.backward(dlog)
         net.step(lr=0.05)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_lds_staged_variant_is_bit_exact_too(env):
+    """GNNX_SPMM_VARIANT=lds (LDS-DMA staging of the neighbour rows, kept as a measured alternative: DESIGN.md 4.1) is read
+    once per process, so run the F = 256 parity cases in a child interpreter with the variable set."""
+    import os
+    import subprocess
+    import sys
+    from tests.helpers import ROOT
+    e = dict(os.environ, GNNX_SPMM_VARIANT="lds")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "spmm_forward_backward_bit_exact_vs_oracle or spmm_accumulate or golden_aggregate"],
+                       capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
