@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--train-layers", type=int, default=0,
                     help="N=1 only: time a whole training step of an L-layer GCN instead (forward, softmax-CE, backward, SGD); "
                          "value counts L*nnz edges per step")
+    ap.add_argument("--sym", action="store_true",
+                    help="N=1: Mode SYM, the textbook D^-1/2 A D^-1/2 aggregation of the north_star (per-edge scale) instead of the "
+                         "reference's factorised norm (Mode REF, the parity-graded default); same kernel, +4 B/edge of traffic")
     ap.add_argument("--hip-graph", action="store_true",
                     help="N=1: capture one step (6 kernel launches + their small helpers) into a hipGraph and replay it in the "
                          "timed loop -- for launch-bound sizes such as the Cora-sized config")
@@ -125,6 +128,7 @@ def main():
     elif world == 1 and not args.force_sharded:
         runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk)
         runner.workload = args.workload
+        runner.sym = args.sym
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
         runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm)
@@ -202,7 +206,7 @@ def main():
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 else f"1-D vertex shard x{world}, halo all-to-all-v",
-                       "plan_chunk": args.chunk, "hip_graph": graph is not None},
+                       "plan_chunk": args.chunk, "hip_graph": graph is not None, "mode": "SYM" if args.sym else "REF"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,
@@ -260,10 +264,11 @@ class SingleGpu:
             else:
                 fn()
 
+        sym = getattr(self, "sym", False)
         run(lambda: ops.linear_fwd(self.X, self.W, out=self.H))
-        run(lambda: ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
+        run(lambda: ops.aggregate_fwd_sym(g, self.H, self.bias, out=self.out) if sym else ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
         run(lambda: ops.colsum(self.G, out=self.dbias))
-        run(lambda: ops.aggregate_bwd(g, self.G, out=self.dH))
+        run(lambda: ops.aggregate_bwd_sym(g, self.G, out=self.dH) if sym else ops.aggregate_bwd(g, self.G, out=self.dH))
         run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
         run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
         if timed:

@@ -255,6 +255,25 @@ def aggregate_bwd(g, G, out=None, beta=0.0, use_plan=True):
     return spmm(g.rowptr_t, g.colidx_t, G, out=out, vals=g.norm_per_nz_t, beta=beta, plan=g.plan_t if use_plan else None)
 
 
+def aggregate_fwd_sym(g, H, bias=None, out=None, self_term=False, use_plan=True):
+    """Mode SYM, the textbook layer the north_star writes: out = D^-1/2 A D^-1/2 . H (+ bias), s = (1 + deg)^-1/2 as in the
+    reference's degree block (graph.cpp:178,183); with self_term the D^-1/2 (A + I) D^-1/2 form.  Unlike Mode REF (the
+    reference's factorised norm, graph.cpp:196-199) the scale is applied per edge: colscale = s, rowscale = s."""
+    out = spmm(g.rowptr, g.colidx, H, out=out, colscale=g.s, rowscale=g.s, bias=bias, plan=g.plan if use_plan else None)
+    if self_term:  # + s_i^2 * H_i
+        s2 = g.s * g.s
+        axpy(1.0, rowscale(H, s2), out)
+    return out
+
+
+def aggregate_bwd_sym(g, G, out=None, self_term=False, use_plan=True):
+    """dH = D^-1/2 A^T D^-1/2 . G (+ s^2 (.) G): the same kernel on the transposed CSR."""
+    out = spmm(g.rowptr_t, g.colidx_t, G, out=out, colscale=g.s, rowscale=g.s, plan=g.plan_t if use_plan else None)
+    if self_term:
+        axpy(1.0, rowscale(G, g.s * g.s), out)
+    return out
+
+
 def linear_bwd(dH, X, W, dX=None, dW=None, beta_dw=0.0):
     """dX = dH . W ; dW = dH^T . X  (operation.h:516-531, :416-433)."""
     dX = gemm(dH, W, out=dX)

@@ -677,3 +677,29 @@ def test_lds_staged_variant_is_bit_exact_too(env):
                         "-k", "spmm_forward_backward_bit_exact_vs_oracle or spmm_accumulate or golden_aggregate"],
                        capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("self_term", [False, True])
+def test_mode_sym_textbook_normalisation(env, self_term):
+    """The textbook D^-1/2 (A [+ I]) D^-1/2 . H of the north_star (Mode SYM), forward and backward, vs float64."""
+    import scipy.sparse as sp
+    ops = env["ops"]
+    n, F = 6000, 96
+    src, dst, rp, ci, g = make_graph(env, n, 50000, seed=23)
+    s = host(g.s).astype(np.float64)
+    A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(n, n))
+    M = sp.diags(s) @ (A + (sp.identity(n) if self_term else 0 * sp.identity(n))) @ sp.diags(s)
+    H = synth.uniform_pm1(701, (n, F))
+    G = synth.uniform_pm1(702, (n, F))
+    bias = synth.uniform_pm1(703, (F,))
+    out = host(ops.aggregate_fwd_sym(g, dev(env, H), dev(env, bias), self_term=self_term))
+    ref = M @ H.astype(np.float64) + bias
+    absum = abs(M) @ np.abs(H).astype(np.float64) + np.abs(bias)
+    assert_close(out, ref.astype(np.float32), "SYM forward", absum=absum)
+    dH = host(ops.aggregate_bwd_sym(g, dev(env, G), self_term=self_term))
+    refb = M.T @ G.astype(np.float64)
+    assert_close(dH, refb.astype(np.float32), "SYM backward", absum=abs(M).T @ np.abs(G).astype(np.float64))
+    # adjointness of the pair
+    a = float((out.astype(np.float64) - bias) .ravel() @ G.astype(np.float64).ravel())
+    b = float(H.astype(np.float64).ravel() @ dH.astype(np.float64).ravel())
+    assert abs(a - b) <= 1e-5 * max(abs(a), abs(b), 1.0)
