@@ -186,7 +186,8 @@ class ShardPlan:
 class ShardedBench:
     """bench.py runner for N > 1 ranks: same synthetic graph as the single-GPU workload, sharded."""
 
-    def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, native_comm=False):
+    def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, native_comm=False,
+                 global_inputs=False):
         import ctypes as C
         self.C = C
         self.native = NativeComm(capi, ops, dist, rank, world, dev) if native_comm else None
@@ -221,12 +222,18 @@ class ShardedBench:
         self.plan_f = ops.SpmmPlan(p.fwd.rowptr, chunk, F) if chunk > 0 else None
         self.plan_b = ops.SpmmPlan(p.bwd.rowptr, chunk, F) if chunk > 0 else None
         nl = p.n_local
-        self.X = ops.uniform_pm1(seed + 10 + 1000 * rank, (nl, F), device=dev)
+        if global_inputs:  # rows [lo, hi) of the SAME X / G a single-GPU run generates (tests compare against it)
+            self.X = ops.uniform_pm1(seed + 10, (n, F), device=dev)[p.lo: p.hi].clone()
+        else:
+            self.X = ops.uniform_pm1(seed + 10 + 1000 * rank, (nl, F), device=dev)
         self.W = ops.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5, device=dev)
         self.bias = torch.zeros(F, dtype=torch.float32, device=dev)
         self.Hext = torch.empty((nl + p.fwd.n_halo, F), dtype=torch.float32, device=dev)   # [local | halo]
         self.Gext = torch.empty((nl + p.bwd.n_halo, F), dtype=torch.float32, device=dev)
-        self.Gext[:nl] = ops.uniform_pm1(seed + 12 + 1000 * rank, (nl, F), device=dev)
+        if global_inputs:
+            self.Gext[:nl] = ops.uniform_pm1(seed + 12, (n, F), device=dev)[p.lo: p.hi]
+        else:
+            self.Gext[:nl] = ops.uniform_pm1(seed + 12 + 1000 * rank, (nl, F), device=dev)
         self.out = torch.empty((nl, F), dtype=torch.float32, device=dev)
         self.dH = torch.empty((nl, F), dtype=torch.float32, device=dev)
         self.dX = torch.empty((nl, F), dtype=torch.float32, device=dev)

@@ -1,0 +1,128 @@
+"""The sharded step (gnn.cpp_amd/shard.py ShardedBench: plan, norm exchange, halo all-to-all-v, SpMM over [local|halo],
+GEMMs, parameter all-reduce) on ONE GPU: P ranks run as threads of this process and talk through an in-process stand-in
+for torch.distributed (same call signatures, data moved with device copies).  What it proves that the gloo/CPU tests and
+the single-rank rehearsal cannot: the real HIP kernels on the real [local | halo] buffers of every rank reproduce the
+single-GPU result -- forward and backward aggregation bit for bit, dW / dbias after the all-reduce within tolerance."""
+import importlib
+import threading
+
+import numpy as np
+import pytest
+
+from tests.helpers import pkg
+
+pytestmark = pytest.mark.gpu
+
+
+class LoopbackWorld:
+    """Minimal torch.distributed look-alike for P threads sharing one device."""
+
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def rank_view(self, rank):
+        return _RankDist(self, rank)
+
+
+class _RankDist:
+    def __init__(self, w, rank):
+        self.w, self.rank = w, rank
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
+        w, P = self.w, self.w.world
+        if input_split_sizes is None:
+            n = inp.shape[0] // P
+            input_split_sizes = [n] * P
+            output_split_sizes = [n] * P
+        w.slots[self.rank] = (inp, list(input_split_sizes))
+        w.bar.wait()
+        off = 0
+        for q in range(P):
+            src, splits = w.slots[q]
+            start = sum(splits[: self.rank])
+            cnt = splits[self.rank]
+            assert cnt == output_split_sizes[q], (self.rank, q, cnt, output_split_sizes[q])
+            if cnt:
+                out[off: off + cnt].copy_(src[start: start + cnt])
+            off += cnt
+        import torch
+        torch.cuda.synchronize()
+        w.bar.wait()
+
+    def all_reduce(self, t, op=None):
+        import torch
+        w = self.w
+        w.slots[self.rank] = t.clone()
+        w.bar.wait()
+        total = w.slots[0].clone()
+        for q in range(1, w.world):
+            total += w.slots[q]
+        torch.cuda.synchronize()
+        w.bar.wait()
+        t.copy_(total)
+
+    def barrier(self):
+        self.w.bar.wait()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_equals_single_gpu(world):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("needs a HIP device")
+    ops = importlib.import_module("gnncpp_amd.ops")
+    capi = importlib.import_module("gnncpp_amd.capi")
+    shard = importlib.import_module("gnncpp_amd.shard")
+    dev = torch.device("cuda:0")
+    n, e, F, abc, seed = 200_000, 2_000_000, 64, (0.57, 0.19, 0.19), 5
+    # ---- single-GPU reference (exact mode: no plan)
+    src, dst = ops.rmat_edges(seed, n, e, *abc, device=dev)
+    g = ops.CsrGraph.from_coo(src, dst, n)
+    X = ops.uniform_pm1(seed + 10, (n, F), device=dev)
+    W = ops.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5, device=dev)
+    G = ops.uniform_pm1(seed + 12, (n, F), device=dev)
+    bias = torch.zeros(F, dtype=torch.float32, device=dev)
+    H = ops.linear_fwd(X, W)
+    out_ref = ops.aggregate_fwd(g, H, bias, use_plan=False)
+    dH_ref = ops.aggregate_bwd(g, G, use_plan=False)
+    dX_ref, dW_ref = ops.linear_bwd(dH_ref, X, W)
+    dbias_ref = ops.colsum(G)
+    torch.cuda.synchronize()
+
+    lw = LoopbackWorld(world)
+    runners, errors = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 0, global_inputs=True)
+            r.step()
+            torch.cuda.synchronize()
+            runners[rank] = r
+        except Exception as ex:  # noqa: BLE001
+            import traceback
+            errors.append((rank, traceback.format_exc()))
+            lw.bar.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(k,)) for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors[0][1]
+    nnz = sum(r.plan.nnz_local for r in runners)
+    assert nnz == g.nnz
+    for r in runners:
+        lo, hi = r.plan.lo, r.plan.hi
+        assert torch.equal(r.plan.norm, g.norm[lo:hi]), "sharded norm differs"
+        assert torch.equal(r.out, out_ref[lo:hi]), "sharded forward aggregation not bit-identical to single GPU"
+        assert torch.equal(r.dH, dH_ref[lo:hi]), "sharded backward aggregation not bit-identical to single GPU"
+        assert float((r.dX - dX_ref[lo:hi]).abs().max()) <= 1e-5 * max(1.0, float(dX_ref.abs().max()))
+        # parameters were all-reduced: every rank holds the global sums
+        scale = float((dH_ref.abs().t().double() @ X.abs().double()).max())
+        assert float((r.dW - dW_ref).abs().max()) <= 1e-5 * max(1.0, scale)
+        assert float((r.dbias - dbias_ref).abs().max()) <= 1e-5 * max(1.0, float(G.abs().double().sum(0).max()))
+    cuts = runners[0].plan.cuts
+    assert cuts[0] == 0 and cuts[-1] == n and all(r.plan.cuts == cuts for r in runners)
