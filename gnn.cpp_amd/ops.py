@@ -13,6 +13,7 @@ Mirrors the call structure of the reference's GCNConv (src/graph.cpp:170-212):
   linear_bwd                                                              504-534,416-433
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -40,8 +41,10 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device, tag):
-    """Grow-only device scratch buffer per (device, tag) -- allocated outside the timed/compute calls."""
-    key = (str(device), tag)
+    """Grow-only device scratch buffer per (host thread, device, tag) -- allocated outside the timed/compute calls.
+    Per thread because a scratch buffer is only safe to share between calls that are ordered on one stream by one
+    submitter (the loopback test runs several ranks as threads of one process)."""
+    key = (threading.get_ident(), str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

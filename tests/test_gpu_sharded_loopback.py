@@ -67,7 +67,7 @@ class _RankDist:
         self.w.bar.wait()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_step_equals_single_gpu(world):
     import torch
     if not torch.cuda.is_available():
