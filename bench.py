@@ -289,6 +289,9 @@ class SingleGpu:
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                 "traffic_source": tr[1] if tr else None,
                 "algorithmic_bytes_per_launch": B, "bytes_per_edge": B / max(1, self.g.nnz), "avg_launch_ms": ms,
+                "median_launch_ms": float(np.median([st[1][0].elapsed_ms(st[1][1]) for st in self.ev])) if self.ev else None,
+                # the cache-perfect lower bound (every feature row read once) beside the gather figure
+                "cache_perfect_bytes": 4 * (self.n + 1) + 4 * self.g.nnz + 4 * self.n + 8 * self.F * self.n,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0}
 
 
@@ -325,36 +328,46 @@ class TrainStep(SingleGpu):
 
 
 def cpu_baseline(pkg, args, F, abc, seed):
-    """The CPU oracle (port of the reference arithmetic, OpenMP over rows) on a bounded sample of the same
-    workload: same generator, same average degree and feature width, fewer nodes."""
+    """The CPU oracle (port of the reference arithmetic) on bounded samples of the same workload: same generator, same
+    average degree and feature width, fewer nodes.  Two legs: OpenMP over rows on every host thread
+    (the reported `value`), and one thread -- the reference itself is single-threaded -- on a 10x smaller sample."""
     import oracle  # checker / reported baseline only
     wl_n, wl_e = WORKLOADS[args.workload][:2]
-    n = min(args.cpu_sample_nodes, wl_n)
-    e = int(round(wl_e * (n / wl_n)))
-    if abc is None:
-        src, dst = pkg.synth.uniform_edges(seed, n, e)
-    else:
-        src, dst = pkg.synth.rmat_edges(seed, n, e, *abc)
-    rng = np.random.default_rng(seed)  # same distribution as the device inputs (U[-1,1)), cheaper to draw
-    X = rng.random((n, F), dtype=np.float32) * 2 - 1
-    W = pkg.synth.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5)
-    bias = np.zeros(F, dtype=np.float32)
-    G = rng.random((n, F), dtype=np.float32) * 2 - 1
-    rp, ci = oracle.coo_to_csr(src, dst, n)
-    rT, cT = oracle.csr_transpose(rp, ci, n)
-    s, norm = oracle.degree_norm(rp, ci, n)
+
+    def leg(n, threads):
+        e = int(round(wl_e * (n / wl_n)))
+        if abc is None:
+            src, dst = pkg.synth.uniform_edges(seed, n, e)
+        else:
+            src, dst = pkg.synth.rmat_edges(seed, n, e, *abc)
+        rng = np.random.default_rng(seed)  # same distribution as the device inputs (U[-1,1)), cheaper to draw
+        X = rng.random((n, F), dtype=np.float32) * 2 - 1
+        W = pkg.synth.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5)
+        bias = np.zeros(F, dtype=np.float32)
+        G = rng.random((n, F), dtype=np.float32) * 2 - 1
+        rp, ci = oracle.coo_to_csr(src, dst, n)
+        rT, cT = oracle.csr_transpose(rp, ci, n)
+        s, norm = oracle.degree_norm(rp, ci, n)
+        oracle.set_threads(threads)
+        t0 = time.perf_counter()
+        H = oracle.linear_fwd(X, W)
+        oracle.aggregate_fwd(rp, ci, H, norm, bias)
+        oracle.colsum(G)
+        dH = oracle.aggregate_bwd(rT, cT, G, norm)
+        oracle.linear_bwd(dH, X, W)
+        dt = time.perf_counter() - t0
+        return n, e, len(ci), dt
+
     cores = oracle.max_threads()
-    t0 = time.perf_counter()
-    H = oracle.linear_fwd(X, W)
-    oracle.aggregate_fwd(rp, ci, H, norm, bias)
-    oracle.colsum(G)
-    dH = oracle.aggregate_bwd(rT, cT, G, norm)
-    oracle.linear_bwd(dH, X, W)
-    dt = time.perf_counter() - t0
-    return {"value": len(ci) / dt, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"{args.workload} scaled to {n} nodes / {e} generated edges (nnz {len(ci)}), {F} features, "
+    n, e, nnz, dt = leg(min(args.cpu_sample_nodes, wl_n), cores)
+    n1, e1, nnz1, dt1 = leg(max(1, min(args.cpu_sample_nodes, wl_n) // 10), 1)
+    oracle.set_threads(cores)
+    return {"value": nnz / dt, "unit": "edges/s", "cores": cores, "kind": "port",
+            "sample": f"{args.workload} scaled to {n} nodes / {e} generated edges (nnz {nnz}), {F} features, "
                       f"one layer fwd+bwd in {dt:.2f} s, OpenMP over rows on {cores} threads",
-            "seconds": dt}
+            "seconds": dt,
+            "single_thread": {"value": nnz1 / dt1, "unit": "edges/s", "cores": 1,
+                              "sample": f"{n1} nodes / {e1} generated edges (nnz {nnz1}), {F} features, {dt1:.2f} s"}}
 
 
 def cpu_reference(pkg):
