@@ -79,6 +79,8 @@ _SIGS = {
     "gnnx_rowscale_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_bias_add_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_axpy_f32": [_i64, _f32, _vp, _vp, _vp],
+    "gnnx_binary_bcast_f32": [C.c_int, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp],
+    "gnnx_rowsum_f32": [_vp, _i64, _i64, _i32, _vp, _vp],
     "gnnx_fill_f32": [_vp, _i64, _f32, _vp],
     "gnnx_pow_f32": [_vp, _i64, _f32, _vp, _vp],
     "gnnx_csr_rowsum_f32": [_vp, _vp, _i32, _vp, _vp],

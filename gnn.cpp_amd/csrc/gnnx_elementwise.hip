@@ -196,6 +196,43 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *X, int64_t 
         if (c0 + k < Cc && r0 + tx < R) Y[(c0 + k) * ldy + r0 + tx] = tile[tx][k];
 }
 
+
+// General 2-D broadcast elementwise op (reference functional.h:163-239 add/mul/div over utils.h:181-228 broadcast):
+// Y[r][c] = A[r*ars + c*acs] (op) B[r*brs + c*bcs]; a stride of 0 broadcasts that dimension.  One rounding per element.
+template <int OP>
+__global__ __launch_bounds__(256) void binary_bcast_kernel(const float *A, int64_t ars, int64_t acs, const float *B, int64_t brs,
+                                                            int64_t bcs, int64_t n_rows, int64_t n_cols, float *Y, int64_t ldy)
+{
+    int64_t total = n_rows * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i / n_cols, c = i - r * n_cols;
+        float a = A[r * ars + c * acs], b = B[r * brs + c * bcs];
+        float y = OP == 0 ? __fadd_rn(a, b) : OP == 1 ? __fsub_rn(a, b) : OP == 2 ? __fmul_rn(a, b) : __fdiv_rn(a, b);
+        Y[r * ldy + c] = y;
+    }
+}
+
+// out[r] = sum_c X[r][c], ascending c (functional::sum walks UP, reference functional.h:267-296); one wavefront per row
+__global__ __launch_bounds__(256) void rowsum_kernel(const float *X, int64_t ldx, int64_t n_rows, int32_t n_cols, float *out)
+{
+    int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= n_rows) return;
+    // lane l owns the contiguous slice [l*w, (l+1)*w): partial sums combine left to right, so a row of <= 64 columns
+    // is summed in exactly the reference's order
+    const int32_t w = (n_cols + 63) / 64;
+    float acc = 0.f;
+    for (int32_t c = lane * w; c < (lane + 1) * w && c < n_cols; c++) acc = __fadd_rn(acc, X[r * ldx + c]);
+    __shared__ float part[4][64];
+    part[threadIdx.x >> 6][lane] = acc;
+    __syncthreads();
+    if (lane == 0) {
+        float s = 0.f;
+        for (int l = 0; l < 64; l++) s = __fadd_rn(s, part[threadIdx.x >> 6][l]);
+        out[r] = s;
+    }
+}
+
 // ---- halo pack / unpack: one G-lane group per row, 16 B per lane ---------------------------------------
 template <int VEC, bool SCATTER_ADD>
 __global__ __launch_bounds__(256) void rows_kernel(const float *in, int64_t ldi, const int32_t *idx, int64_t n_idx,
@@ -317,6 +354,44 @@ GNNX_API int gnnx_bias_add_f32(const float *d_X, int64_t ldx, const float *d_b, 
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     hipLaunchKernelGGL(rowwise_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, d_b, n_rows,
                        n_feat, d_Y, ldy);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_binary_bcast_f32(int op, int64_t n_rows, int64_t n_cols, const float *d_A, int64_t a_row_stride,
+                                   int64_t a_col_stride, const float *d_B, int64_t b_row_stride, int64_t b_col_stride, float *d_Y,
+                                   int64_t ldy, void *stream)
+{
+    GNNX_REQUIRE(op >= GNNX_OP_ADD && op <= GNNX_OP_DIV, GNNX_ERR_INVALID_ARG, "unknown op %d", op);
+    GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0 || n_cols == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_A && d_B && d_Y && ldy >= n_cols, GNNX_ERR_INVALID_ARG, "null pointer or ldy < n_cols");
+    GNNX_REQUIRE(a_row_stride >= 0 && a_col_stride >= 0 && b_row_stride >= 0 && b_col_stride >= 0, GNNX_ERR_INVALID_ARG,
+                 "negative stride");
+    int64_t blocks = ceil_div(n_rows * n_cols, 256);
+    if (blocks > 8192) blocks = 8192;
+    dim3 g((uint32_t)blocks), b(256);
+    hipStream_t st = as_stream(stream);
+#define GNNX_BIN(OPV) hipLaunchKernelGGL(binary_bcast_kernel<OPV>, g, b, 0, st, d_A, a_row_stride, a_col_stride, d_B, b_row_stride, \
+                                         b_col_stride, n_rows, n_cols, d_Y, ldy)
+    switch (op) {
+    case GNNX_OP_ADD: GNNX_BIN(0); break;
+    case GNNX_OP_SUB: GNNX_BIN(1); break;
+    case GNNX_OP_MUL: GNNX_BIN(2); break;
+    default: GNNX_BIN(3); break;
+    }
+#undef GNNX_BIN
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_rowsum_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_cols, float *d_out, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_X && d_out && ldx >= n_cols, GNNX_ERR_INVALID_ARG, "null pointer or ldx < n_cols");
+    hipLaunchKernelGGL(rowsum_kernel, dim3((uint32_t)ceil_div(n_rows, 4)), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_cols,
+                       d_out);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }

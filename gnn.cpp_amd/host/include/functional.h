@@ -23,6 +23,52 @@ inline bool is_row_of(const std::vector<size_t> &big, const std::vector<size_t> 
 {
     return big.size() == 2 && ((small.size() == 1 && small[0] == big[1]) || (small.size() == 2 && small[0] == 1 && small[1] == big[1]));
 }
+// [N,F] / [N,1] / [1,F] / [F] / one element, as a (rows, cols) pair; false when the rank is above 2
+inline bool as_2d(const std::vector<size_t> &d, size_t &r, size_t &c)
+{
+    if (d.size() == 1) { r = 1; c = d[0]; return true; }
+    if (d.size() == 2) { r = d[0]; c = d[1]; return true; }
+    return false;
+}
+// General 2-D broadcast through gnnx_binary_bcast_f32; the result takes the shape of the higher-rank / larger operand.
+inline tptr<float> binary_bcast(int op, const tptr<float> &lhs, const tptr<float> &rhs, const char *what)
+{
+    auto ls = lhs->shape(), rs = rhs->shape();
+    size_t lr, lc, rr, rc;
+    if (ls == rs) {  // same shape, any rank: flat
+        auto out = new_out(ls, lhs->requires_grad() || rhs->requires_grad());
+        detail::gx(gnnx_binary_bcast_f32(op, 1, (int64_t)lhs->numel(), lhs->device_data(), 0, 1, rhs->device_data(), 0, 1,
+                                         out->device_out(), (int64_t)lhs->numel(), detail::current_stream()), what);
+        return out;
+    }
+    if (lhs->numel() == 1 || rhs->numel() == 1) {  // a one-element operand against any rank: flat, stride 0 on the scalar
+        const bool lscalar = lhs->numel() == 1 && rhs->numel() != 1;
+        const auto &big = lscalar ? rhs : lhs;
+        auto out = new_out(big->shape().size() >= (lscalar ? ls : rs).size() ? big->shape() : (lscalar ? ls : rs),
+                           lhs->requires_grad() || rhs->requires_grad());
+        detail::gx(gnnx_binary_bcast_f32(op, 1, (int64_t)big->numel(), lhs->device_data(), 0, lhs->numel() == 1 ? 0 : 1,
+                                         rhs->device_data(), 0, rhs->numel() == 1 ? 0 : 1, out->device_out(), (int64_t)big->numel(),
+                                         detail::current_stream()), what);
+        return out;
+    }
+    if (!as_2d(ls, lr, lc) || !as_2d(rs, rr, rc)) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    if (!is_broadcastable(ls, rs)) CHECK_EQUAL_SIZES(rs, ls);
+    const size_t n = std::max(lr, rr), f = std::max(lc, rc);
+    if ((lr != n && lr != 1) || (rr != n && rr != 1) || (lc != f && lc != 1) || (rc != f && rc != 1))
+        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    std::vector<size_t> od = (ls.size() == 2 || rs.size() == 2) ? std::vector<size_t>{n, f} : std::vector<size_t>{f};
+    auto out = new_out(od, lhs->requires_grad() || rhs->requires_grad());
+    auto stride = [&](size_t r, size_t c, int64_t &s_r, int64_t &s_c) {
+        s_r = (r == n && n > 1) ? (int64_t)c : 0;
+        s_c = (c == f && f > 1) ? 1 : 0;
+    };
+    int64_t ars, acs, brs, bcs;
+    stride(lr, lc, ars, acs);
+    stride(rr, rc, brs, bcs);
+    detail::gx(gnnx_binary_bcast_f32(op, (int64_t)n, (int64_t)f, lhs->device_data(), ars, acs, rhs->device_data(), brs, bcs,
+                                     out->device_out(), (int64_t)f, detail::current_stream()), what);
+    return out;
+}
 }  // namespace impl
 
 // [N,F]+[N,F] (same shape: copy + axpy) and [N,F]+[F] (bias broadcast, reference functional.h:163-187)
@@ -49,8 +95,7 @@ tptr<T> add(const tptr<T> &lhs, const tptr<T> &rhs)
             return out;
         }
         if (impl::is_row_of(rs, ls)) return add(rhs, lhs);
-        if (!is_broadcastable(ls, rs)) CHECK_EQUAL_SIZES(rs, ls);
-        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        return impl::binary_bcast(GNNX_OP_ADD, lhs, rhs, "add");  // any other 2-D broadcast
     }
 }
 
@@ -77,9 +122,16 @@ tptr<T> mul(const tptr<T> &lhs, const tptr<T> &rhs)
                        "mul");
             return out;
         }
-        if (!is_broadcastable(ls, rs)) CHECK_EQUAL_SIZES(rs, ls);
-        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        return impl::binary_bcast(GNNX_OP_MUL, lhs, rhs, "mul");  // any other 2-D broadcast
     }
+}
+
+// elementwise quotient with the same broadcast (reference functional.h:216-239); off the hot path, here for operator/
+template <class T>
+tptr<T> div(const tptr<T> &lhs, const tptr<T> &rhs)
+{
+    if constexpr (!std::is_same_v<T, float>) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+    else return impl::binary_bcast(GNNX_OP_DIV, lhs, rhs, "div");
 }
 
 // elementwise power with a scalar exponent (deg->pow(-0.5), reference graph.cpp:183 -> functional.h:242-264)
@@ -125,6 +177,13 @@ tptr<T> sum(const tptr<T> &base, int dim, bool keepdim)
             detail::gx(gnnx_colsum_workspace((int64_t)shp[0], (int32_t)shp[1], &wsb), "sum");
             detail::gx(gnnx_colsum_f32(base->device_data(), (int64_t)shp[1], (int64_t)shp[0], (int32_t)shp[1], 0.0f, out->device_out(),
                                        detail::workspace(wsb), wsb, st), "sum");
+            return out;
+        }
+        if (rank == 2 && dim == 1) {  // row sums: undoes a column broadcast (sum_to_size to [N,1])
+            std::vector<size_t> od = keepdim ? std::vector<size_t>{shp[0], 1} : std::vector<size_t>{shp[0]};
+            auto out = impl::new_out(od, base->requires_grad());
+            detail::gx(gnnx_rowsum_f32(base->device_data(), (int64_t)shp[1], (int64_t)shp[0], (int32_t)shp[1], out->device_out(), st),
+                       "sum");
             return out;
         }
         throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);

@@ -172,6 +172,8 @@ tptr<T> add(const tptr<T> &lhs, const tptr<T> &rhs);
 template <class T>
 tptr<T> mul(const tptr<T> &lhs, const tptr<T> &rhs);
 template <class T>
+tptr<T> div(const tptr<T> &lhs, const tptr<T> &rhs);
+template <class T>
 tptr<T> pow(const tptr<T> &base, float exponent);
 template <class T>
 tptr<T> sum(const tptr<T> &base, int dim, bool keepdim);
@@ -186,6 +188,8 @@ class Add;
 template <class T>
 class Mul;
 template <class T>
+class Div;
+template <class T>
 class MatMul;
 template <class T>
 class Transpose;
@@ -199,7 +203,11 @@ class tensor : public std::enable_shared_from_this<tensor<T>> {
     friend tptr<T> operator+(tptr<T> lhs, const tptr<T> &rhs) { return lhs->add(rhs); }
     friend tptr<T> operator+(tptr<T> lhs, const float &rhs) { return lhs->add(rhs); }
     friend tptr<T> operator+(tptr<T> lhs, const int &rhs) { return lhs->add((float)rhs); }
+    friend tptr<T> operator-(const tptr<T> &lhs) { return lhs->mul(-1.0f); }
     friend tptr<T> operator-(tptr<T> lhs, const float &rhs) { return lhs->add(-rhs); }
+    friend tptr<T> operator-(tptr<T> lhs, const tptr<T> &rhs) { return lhs->add(-rhs); }  // add(-rhs), as the reference spells it
+    friend tptr<T> operator/(tptr<T> lhs, const tptr<T> &rhs) { return lhs->div(rhs); }
+    friend tptr<T> operator/(tptr<T> lhs, const float &rhs) { return lhs->div(rhs); }
     friend tptr<T> operator*(tptr<T> lhs, const tptr<T> &rhs) { return lhs->mul(rhs); }
     friend tptr<T> operator*(tptr<T> lhs, const float &rhs) { return lhs->mul(rhs); }
     friend tptr<T> operator*=(tptr<T> lhs, const tptr<T> &rhs)
@@ -220,6 +228,29 @@ class tensor : public std::enable_shared_from_this<tensor<T>> {
     {
         lhs->check_in_place();
         auto out = lhs + rhs;
+        lhs->assign_from(*out);
+        return lhs;
+    }
+    friend tptr<T> operator*=(tptr<T> lhs, const float &rhs)
+    {
+        lhs->check_in_place();
+        auto out = lhs * rhs;
+        lhs->assign_from(*out);
+        return lhs;
+    }
+    template <class A>
+    friend tptr<T> operator-=(tptr<T> lhs, const A &rhs)
+    {
+        lhs->check_in_place();
+        auto out = lhs - rhs;
+        lhs->assign_from(*out);
+        return lhs;
+    }
+    template <class A>
+    friend tptr<T> operator/=(tptr<T> lhs, const A &rhs)
+    {
+        lhs->check_in_place();
+        auto out = lhs / rhs;
         lhs->assign_from(*out);
         return lhs;
     }
@@ -373,7 +404,7 @@ public:
         if (out->requires_grad()) out->grad_fn = std::move(op);
         return out;
     }
-    tptr<T> add(const float &other) { return add(std::make_shared<tensor<T>>(_dims, static_cast<T>(other), false)); }
+    tptr<T> add(const float &other) { return add(std::make_shared<tensor<T>>(std::vector<size_t>{1}, static_cast<T>(other), false)); }
     tptr<T> mul(const tptr<T> &other)
     {
         CHECK_ARGS_OPS_BROADCAST(shape(), other->shape());
@@ -382,7 +413,16 @@ public:
         if (out->requires_grad()) out->grad_fn = std::move(op);
         return out;
     }
-    tptr<T> mul(const float &other) { return mul(std::make_shared<tensor<T>>(_dims, static_cast<T>(other), false)); }
+    tptr<T> mul(const float &other) { return mul(std::make_shared<tensor<T>>(std::vector<size_t>{1}, static_cast<T>(other), false)); }
+    tptr<T> div(const tptr<T> &other)
+    {
+        CHECK_ARGS_OPS_BROADCAST(shape(), other->shape());
+        auto op = std::make_unique<Div<tensor<T>>>();
+        auto out = op->forward(this->shared_from_this(), other);
+        if (out->requires_grad()) out->grad_fn = std::move(op);
+        return out;
+    }
+    tptr<T> div(const float &other) { return div(std::make_shared<tensor<T>>(std::vector<size_t>{1}, static_cast<T>(other), false)); }
     tptr<T> mm(const tptr<T> &other)
     {
         CHECK_MM_DIMS(shape(), other->shape());
@@ -626,6 +666,42 @@ public:
             auto g = functional::mul(incoming_grad, rhs);
             g->sum_to_size(lhs->shape());
             lhs->backward(g);
+        }
+    }
+};
+
+// y = a / b:  dy/da = G / b ;  dy/db = G * (-a / b^2)   (reference operation.h:170-208)
+template <class T>
+class Div : public Operation<T> {
+public:
+    Div() { this->name = "Div"; }
+    std::shared_ptr<T> forward(const std::shared_ptr<T> &numerator, const std::shared_ptr<T> &denominator)
+    {
+        auto output = functional::div(numerator, denominator);
+        if (output->requires_grad()) this->context->save_for_backward({numerator, denominator});
+        return output;
+    }
+    void _backward(std::shared_ptr<tensor<float>> incoming_grad) override
+    {
+        auto var = this->context->get_variables();
+        CHECK_BACKWARD<T>(var, 2);
+        auto num = var[0], den = var[1];
+        if (num->requires_grad()) {
+            auto g = functional::div(incoming_grad, den);
+            g->requires_grad_(false);
+            g->sum_to_size(num->shape());
+            num->backward(g);
+        }
+        if (den->requires_grad()) {
+            auto neg = std::make_shared<tensor<float>>(std::vector<size_t>{1}, -1.0f, false);
+            auto cn = functional::mul(num, neg);                       // -a
+            auto cd = functional::mul(den, den);                       // b^2
+            cn->requires_grad_(false);
+            cd->requires_grad_(false);
+            auto g = functional::mul(incoming_grad, functional::div(cn, cd));
+            g->requires_grad_(false);
+            g->sum_to_size(den->shape());
+            den->backward(g);
         }
     }
 };

@@ -185,6 +185,32 @@ def bias_add(X, b, out=None):
     return out
 
 
+_BINARY_OPS = {"add": 0, "sub": 1, "mul": 2, "div": 3}
+
+
+def binary(op, A, B, out=None):
+    """`A (op) B` with the API's 2-D broadcast (reference functional.h:163-239, utils.h:181-228): each operand is [N,F],
+    [N,1], [1,F], [F] or a one-element tensor."""
+    def as2d(t):
+        return t.reshape(1, -1) if t.dim() <= 1 else t
+    A2, B2 = as2d(A), as2d(B)
+    n, f = max(A2.shape[0], B2.shape[0]), max(A2.shape[1], B2.shape[1])
+    for t in (A2, B2):
+        if t.shape[0] not in (1, n) or t.shape[1] not in (1, f) or not t.is_contiguous():
+            raise ValueError("operands are not broadcastable 2-D contiguous tensors")
+    strides = lambda t: (t.shape[1] if t.shape[0] == n and n > 1 else 0, 1 if t.shape[1] == f and f > 1 else 0)  # noqa: E731
+    out = torch.empty((n, f), dtype=torch.float32, device=A.device) if out is None else out
+    (ars, acs), (brs, bcs) = strides(A2), strides(B2)
+    capi.call("gnnx_binary_bcast_f32", _BINARY_OPS[op], n, f, _ptr(A2), ars, acs, _ptr(B2), brs, bcs, _ptr(out), _ld(out), _stream())
+    return out
+
+
+def rowsum(X, out=None):
+    out = torch.empty((X.shape[0],), dtype=torch.float32, device=X.device) if out is None else out
+    capi.call("gnnx_rowsum_f32", _ptr(X), _ld(X), X.shape[0], X.shape[1], _ptr(out), _stream())
+    return out
+
+
 def axpy(a, x, y):
     capi.call("gnnx_axpy_f32", x.numel(), float(a), _ptr(x), _ptr(y), _stream())
     return y

@@ -181,6 +181,17 @@ int gnnx_bias_add_f32(const float *d_X, int64_t ldx, const float *d_b, int64_t n
                       int64_t ldy, void *stream);
 int gnnx_axpy_f32(int64_t n, float a, const float *d_x, float *d_y, void *stream);
 
+/* General 2-D broadcast of the API's elementwise operators (operator+ - * / on tensors: reference tensor.h:30-77 ->
+ * functional.h:163-239, broadcast rule utils.h:181-228):  Y[r][c] = A[r*a_row_stride + c*a_col_stride] (op)
+ * B[r*b_row_stride + c*b_col_stride], a stride of 0 broadcasts that dimension ([N,F] op [N,1], [N,F] op [F],
+ * [N,F] op scalar, either side).  Each element is rounded once (IEEE add / sub / mul / div).  Y may alias A or B when
+ * the aliased operand is not broadcast.  rowsum is the reduction that undoes a column broadcast in backward
+ * (sum_to_size to [N,1], tensor.h:618-638): out[r] = sum_c X[r][c]. */
+enum { GNNX_OP_ADD = 0, GNNX_OP_SUB = 1, GNNX_OP_MUL = 2, GNNX_OP_DIV = 3 };
+int gnnx_binary_bcast_f32(int op, int64_t n_rows, int64_t n_cols, const float *d_A, int64_t a_row_stride, int64_t a_col_stride,
+                          const float *d_B, int64_t b_row_stride, int64_t b_col_stride, float *d_Y, int64_t ldy, void *stream);
+int gnnx_rowsum_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_cols, float *d_out, void *stream);
+
 /* Elementwise helpers behind the tensor API mirror (gnn.cpp_amd/host/):
  *   fill      : x[i] = value                                   (tensor(dims, value) ctor, reference tensor.h:106)
  *   pow       : y[i] = pow(x[i], e); e == -0.5 is the correctly rounded 1/sqrt (the GCN degree scaling,

@@ -87,3 +87,12 @@ def test_reference_call_sites_run_on_the_hip_backend(name):
         assert_close(got["dX"], d["ref_dX"], "dX")
     else:
         assert_close(got["dX"][d["ref_dX_rows"]], d["ref_dX_sample"], "dX rows")
+
+
+def test_operator_classes_like_the_reference_operation_tests():
+    """tests/cpp/test_host_ops_gpu.cpp: Add / Mul / Div forward + backward closed forms of the reference's
+    tests/operation.test.cpp:32-89 (exact), the broadcast shapes of the path, in-place operators, dense row sums."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_ops_gpu")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

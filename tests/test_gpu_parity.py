@@ -703,3 +703,31 @@ def test_mode_sym_textbook_normalisation(env, self_term):
     a = float((out.astype(np.float64) - bias) .ravel() @ G.astype(np.float64).ravel())
     b = float(H.astype(np.float64).ravel() @ dH.astype(np.float64).ravel())
     assert abs(a - b) <= 1e-5 * max(abs(a), abs(b), 1.0)
+
+
+# ---- the API's elementwise operators with broadcast (gnnx_binary_bcast_f32) and dense row sums (gnnx_rowsum_f32)
+@pytest.mark.parametrize("op,fn", [("add", np.add), ("sub", np.subtract), ("mul", np.multiply), ("div", np.divide)])
+def test_binary_broadcast_is_ieee_exact(env, op, fn):
+    ops = env["ops"]
+    n, f = 1000, 37
+    A = synth.uniform_pm1(900, (n, f))
+    col = synth.uniform_pm1(901, (n, 1)) + np.float32(2)
+    row = synth.uniform_pm1(902, (f,)) + np.float32(2)
+    one = np.array([1.5], dtype=np.float32)
+    for lhs, rhs in ((A, A[::-1].copy()), (A, col), (A, row), (col, A), (row, A), (A, one), (col, row.reshape(1, f))):
+        got = host(ops.binary(op, dev(env, lhs), dev(env, rhs)))
+        l2 = lhs.reshape(1, -1) if lhs.ndim == 1 else lhs
+        r2 = rhs.reshape(1, -1) if rhs.ndim == 1 else rhs
+        assert same(got, fn(l2, r2).astype(np.float32)), (op, lhs.shape, rhs.shape)
+
+
+def test_rowsum_walks_up_like_functional_sum(env):
+    ops = env["ops"]
+    X = synth.uniform_pm1(903, (513, 64))
+    exp = np.zeros(513, dtype=np.float32)
+    for j in range(64):
+        exp = exp + X[:, j]          # ascending, one rounding per add
+    assert same(host(ops.rowsum(dev(env, X))), exp)
+    Xw = synth.uniform_pm1(904, (77, 300))  # wider than a wavefront: lane slices, then left to right
+    got = host(ops.rowsum(dev(env, Xw)))
+    assert np.abs(got.astype(np.float64) - Xw.astype(np.float64).sum(1)).max() <= 1e-5 * np.abs(Xw).sum(1).max()
