@@ -35,6 +35,12 @@ def lib():
     return _lib
 
 
+class SpmmFusion(C.Structure):
+    """`gnnx_spmm_fusion` of include/gnnx.h."""
+    _fields_ = [("bn_mean", C.c_void_p), ("bn_var", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
+                ("bn_eps", C.c_float), ("relu_in", C.c_int), ("relu_out", C.c_int)]
+
+
 def declared_symbols():
     """Every function name include/gnnx.h declares (used by the CPU test that the library exports them all)."""
     text = open(HEADER_PATH).read()
@@ -71,6 +77,7 @@ _SIGS = {
     "gnnx_spmm_plan_destroy": [_vp],
     "gnnx_spmm_plan_info": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
     "gnnx_spmm_csr_f32": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp, _i64, _vp, _vp],
+    "gnnx_spmm_csr_fused_f32": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _vp, _i64, _vp, _vp, _vp],
     "gnnx_gemm_workspace": [C.c_int, C.c_int, _i64, _i64, _i64, C.POINTER(_sz)],
     "gnnx_gemm_f32": [C.c_int, C.c_int, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _sz, _vp],
     "gnnx_mfma_peak_f32": [_i32, _i32, _vp, C.POINTER(_f64), _vp],
@@ -88,8 +95,8 @@ _SIGS = {
     "gnnx_bn_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_bn_stats_f32": [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp],
     "gnnx_bn_relu_fwd_f32": [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp],
-    "gnnx_bn_relu_bwd_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp, _sz,
-                             _vp],
+    "gnnx_bn_relu_bwd_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp,
+                             _sz, _vp],
     "gnnx_softmax_ce_workspace": [_i64, C.POINTER(_sz)],
     "gnnx_softmax_ce_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _sz, _vp],
     "gnnx_sgd_step_f32": [_vp, _vp, _i64, _f32, _f32, _vp],

@@ -86,17 +86,35 @@ struct OpSqDev {
         a0 += d * d;
     }
 };
+// Did the forward ReLU pass this element?  From the saved forward output when there is one; otherwise (fused forward,
+// gnnx_spmm_csr_fused_f32: the rectified activations were never stored) by redoing the forward arithmetic on x.
+__device__ __forceinline__ bool relu_passed(const float *Y, int64_t yi, float x, int32_t f, const float *mean, const float *var, float eps,
+                                            const float *gamma, const float *beta)
+{
+    if (Y) return Y[yi] > 0.f;
+    float v = x;
+    if (mean) {
+        v = __fdiv_rn(__fsub_rn(v, mean[f]), sqrtf(__fadd_rn(var[f], eps)));
+        if (gamma) v = __fmul_rn(v, gamma[f]);
+        if (beta) v = __fadd_rn(v, beta[f]);
+    }
+    return v > 0.f;
+}
+
 // g = dY * (Y > 0 or no relu);  sums of g and of g * xhat
 struct OpBnBwd {
     static constexpr bool kTwo = true;
     const float *X, *Y, *dY, *mean, *rstd;
     int64_t ldx, ldy, ldd;
     int relu;
+    const float *var, *gamma, *beta;
+    float eps;
     __device__ __forceinline__ void term(int64_t r, int32_t f, float &a0, float &a1) const
     {
         float g = dY[r * ldd + f];
-        if (relu && !(Y[r * ldy + f] > 0.f)) g = 0.f;
-        float xhat = (X[r * ldx + f] - mean[f]) * rstd[f];
+        const float x = X[r * ldx + f];
+        if (relu && !relu_passed(Y, r * ldy + f, x, f, mean, var, eps, gamma, beta)) g = 0.f;
+        float xhat = (x - mean[f]) * rstd[f];
         a0 += g;
         a1 += g * xhat;
     }
@@ -131,7 +149,7 @@ __global__ __launch_bounds__(256) void rstd_kernel(const float *var, float eps, 
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t ldd,
                                                       int64_t n_rows, int32_t n_feat, const float *mean, const float *rstd,
                                                       const float *gamma, const float *dbeta, const float *dgamma, int relu, float *dX,
-                                                      int64_t ldo)
+                                                      int64_t ldo, const float *var, const float *beta, float eps)
 {
     int64_t total = n_rows * n_feat;
     const float inv_n = 1.0f / (float)n_rows;
@@ -139,9 +157,10 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *X, int64_t ldx
         int64_t r = i / n_feat;
         int32_t f = (int32_t)(i - r * n_feat);
         float g = dY[r * ldd + f];
-        if (relu && !(Y[r * ldy + f] > 0.f)) g = 0.f;
+        const float x = X[r * ldx + f];
+        if (relu && !relu_passed(Y, r * ldy + f, x, f, mean, var, eps, gamma, beta)) g = 0.f;
         if (mean) {
-            float xhat = (X[r * ldx + f] - mean[f]) * rstd[f];
+            float xhat = (x - mean[f]) * rstd[f];
             float gm = gamma ? gamma[f] : 1.f;
             g = gm * rstd[f] * (g - dbeta[f] * inv_n - xhat * dgamma[f] * inv_n);
         }
@@ -222,12 +241,12 @@ GNNX_API int gnnx_bn_relu_fwd_f32(const float *d_X, int64_t ldx, int64_t n_rows,
 
 GNNX_API int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
                                   int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps,
-                                  const float *d_gamma, int relu, float *d_dX, int64_t ldo, float *d_dgamma, float *d_dbeta,
-                                  void *d_workspace, size_t workspace_bytes, void *stream)
+                                  const float *d_gamma, const float *d_beta, int relu, float *d_dX, int64_t ldo, float *d_dgamma,
+                                  float *d_dbeta, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     GNNX_REQUIRE(n_rows > 0 && n_feat > 0, GNNX_ERR_INVALID_ARG, "empty batch");
     GNNX_REQUIRE(d_X && d_dY && d_dX && ldx >= n_feat && ldd >= n_feat && ldo >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld");
-    GNNX_REQUIRE(!relu || (d_Y && ldy >= n_feat), GNNX_ERR_INVALID_ARG, "relu backward needs the forward output");
+    GNNX_REQUIRE(!d_Y || ldy >= n_feat, GNNX_ERR_INVALID_ARG, "ldy < n_feat");
     GNNX_REQUIRE((d_mean == nullptr) == (d_var == nullptr), GNNX_ERR_INVALID_ARG, "mean and var go together");
     hipStream_t st = as_stream(stream);
     int64_t blocks = ceil_div(n_rows * n_feat, 256);
@@ -235,7 +254,7 @@ GNNX_API int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_
     if (!d_mean) {  // ReLU only
         hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat,
                            (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                           (const float *)nullptr, relu, d_dX, ldo);
+                           (const float *)nullptr, relu, d_dX, ldo, (const float *)nullptr, (const float *)nullptr, 0.f);
         GNNX_LAUNCH_CHECK();
         return GNNX_OK;
     }
@@ -247,10 +266,11 @@ GNNX_API int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_
     float *rstd = ws + (size_t)2 * n_blocks_for(n_rows) * n_feat;
     hipLaunchKernelGGL(rstd_kernel, dim3((uint32_t)ceil_div(n_feat, 256)), dim3(256), 0, st, d_var, eps, n_feat, rstd);
     GNNX_LAUNCH_CHECK();
-    int rc = reduce(OpBnBwd{d_X, d_Y, d_dY, d_mean, rstd, ldx, ldy, ldd, relu}, n_rows, n_feat, 1.0f, d_dbeta, d_dgamma, ws, st);
+    int rc = reduce(OpBnBwd{d_X, d_Y, d_dY, d_mean, rstd, ldx, ldy, ldd, relu, d_var, d_gamma, d_beta, eps}, n_rows, n_feat, 1.0f, d_dbeta,
+                    d_dgamma, ws, st);
     if (rc) return rc;
     hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean,
-                       (const float *)rstd, d_gamma, (const float *)d_dbeta, (const float *)d_dgamma, relu, d_dX, ldo);
+                       (const float *)rstd, d_gamma, (const float *)d_dbeta, (const float *)d_dgamma, relu, d_dX, ldo, d_var, d_beta, eps);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }

@@ -70,6 +70,10 @@ struct SpmmArgs {
     // row blocks of the streaming kernel (plan): nullptr => fixed blocks of StreamCfg<G>::R rows
     const int32_t *block_starts;
     int32_t n_blocks;
+    // fusion (gnnx_spmm_csr_fused_f32): ReLU on the stored row; BatchNorm / ReLU applied to every gathered row of X
+    int32_t relu_out;
+    const float *pro_mean, *pro_var, *pro_gamma, *pro_beta;
+    float pro_eps;
 };
 
 template <int VEC> struct Vec;
@@ -94,8 +98,66 @@ __device__ __forceinline__ float4 mul_rn(float4 a, float s)
 __device__ __forceinline__ void zero(float4 &v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void zero(float &v) { v = 0.f; }
 
+__device__ __forceinline__ float relu1(float v) { return v > 0.f ? v : 0.f; }  // where(x > 0, x, 0), nn.cpp:229-237
+__device__ __forceinline__ float relu_v(float v) { return relu1(v); }
+__device__ __forceinline__ float4 relu_v(float4 v) { return make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)); }
+
+// Prologue on a gathered row (MODE 3..5): the modules GCNConv::forward runs between transform and aggregation
+// (graph.cpp:174-175) folded into the gather, so the normalised / rectified H is never written to HBM.  Same separately
+// rounded op order as gnnx_bn_relu_fwd_f32 (sub, div, mul, add, where): fused and unfused results are the same bits.
+constexpr bool pro_bn(int MODE) { return MODE == 4 || MODE == 5; }
+constexpr bool pro_relu(int MODE) { return MODE == 3 || MODE == 5; }
+template <int VEC> struct ProConst { typename Vec<VEC>::type mean, sd, gamma, beta; };
+
+template <int MODE>
+__device__ __forceinline__ float pro1(float v, float mean, float sd, float gamma, float beta)
+{
+    if constexpr (pro_bn(MODE)) {
+        v = __fdiv_rn(__fsub_rn(v, mean), sd);
+        v = __fmul_rn(v, gamma);
+        v = __fadd_rn(v, beta);
+    }
+    if constexpr (pro_relu(MODE)) v = relu1(v);
+    return v;
+}
+template <int MODE>
+__device__ __forceinline__ float pro_apply(float v, const ProConst<1> &c) { return pro1<MODE>(v, c.mean, c.sd, c.gamma, c.beta); }
+template <int MODE>
+__device__ __forceinline__ float4 pro_apply(float4 v, const ProConst<4> &c)
+{
+    return make_float4(pro1<MODE>(v.x, c.mean.x, c.sd.x, c.gamma.x, c.beta.x), pro1<MODE>(v.y, c.mean.y, c.sd.y, c.gamma.y, c.beta.y),
+                       pro1<MODE>(v.z, c.mean.z, c.sd.z, c.gamma.z, c.beta.z), pro1<MODE>(v.w, c.mean.w, c.sd.w, c.gamma.w, c.beta.w));
+}
+__device__ __forceinline__ float sd_of(float var, float eps) { return sqrtf(__fadd_rn(var, eps)); }  // (var + eps)->pow(0.5)
+__device__ __forceinline__ float4 sd_of(float4 var, float eps)
+{
+    return make_float4(sd_of(var.x, eps), sd_of(var.y, eps), sd_of(var.z, eps), sd_of(var.w, eps));
+}
+__device__ __forceinline__ void splat(float &v, float x) { v = x; }
+__device__ __forceinline__ void splat(float4 &v, float x) { v = make_float4(x, x, x, x); }
+
+template <int VEC, int MODE, class ARGS>
+__device__ __forceinline__ ProConst<VEC> pro_load(const ARGS &a, int32_t f0, bool active)
+{
+    using V = typename Vec<VEC>::type;
+    ProConst<VEC> c;
+    splat(c.mean, 0.f);
+    splat(c.sd, 1.f);
+    splat(c.gamma, 1.f);
+    splat(c.beta, 0.f);
+    if constexpr (pro_bn(MODE)) {
+        if (active) {
+            c.mean = ld_vec(reinterpret_cast<const V *>(a.pro_mean + f0));
+            c.sd = sd_of(ld_vec(reinterpret_cast<const V *>(a.pro_var + f0)), a.pro_eps);
+            if (a.pro_gamma) c.gamma = ld_vec(reinterpret_cast<const V *>(a.pro_gamma + f0));
+            if (a.pro_beta) c.beta = ld_vec(reinterpret_cast<const V *>(a.pro_beta + f0));
+        }
+    }
+    return c;
+}
+
 // MODE 0: plain gather-add (forward).  MODE 1: gathered row scaled by colscale[c] (backward: norm (.) G).
-// MODE 2: general (vals and/or colscale).
+// MODE 2: general (vals and/or colscale).  MODE 3 / 4 / 5: forward with a ReLU / BatchNorm / BatchNorm+ReLU prologue.
 //
 // Broadcast lane `src` (index inside the G-lane row group) of v to the whole group.  At G == 64 the source
 // lane is wave-uniform => v_readlane into an SGPR, so the neighbour row's base address is scalar and the
@@ -112,7 +174,7 @@ __device__ __forceinline__ int32_t bcast(int32_t v, int src, int gbase)
 // conditional load into branch + s_waitcnt vmcnt(0) per element, which serialises the gather.
 template <int G, int VEC, int B, int MODE>
 __device__ __forceinline__ void gather_batch(typename Vec<VEC>::type &acc, int k, int32_t myc, float mysc, float myval,
-                                             int gbase, const float *xf, const SpmmArgs &a)
+                                             int gbase, const float *xf, const SpmmArgs &a, const ProConst<VEC> &pc)
 {
     using V = typename Vec<VEC>::type;
     int32_t c[B];
@@ -124,7 +186,8 @@ __device__ __forceinline__ void gather_batch(typename Vec<VEC>::type &acc, int k
 #pragma unroll
     for (int u = 0; u < B; u++) {
         V t = v[u];
-        if constexpr (MODE >= 1) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(mysc), k + u, gbase)));
+        if constexpr (MODE >= 3) t = pro_apply<MODE>(t, pc);
+        if constexpr (MODE == 1 || MODE == 2) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(mysc), k + u, gbase)));
         if constexpr (MODE == 2) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(myval), k + u, gbase)));
         acc = add_rn(acc, t);
     }
@@ -136,7 +199,7 @@ __device__ __forceinline__ void gather_batch(typename Vec<VEC>::type &acc, int k
 // neighbour from the top), together with their colscale / vals, then handed out by bcast().
 template <int G, int VEC, int U, int MODE>
 __device__ __forceinline__ typename Vec<VEC>::type gather_range(int32_t b, int32_t e, const float *xf, int li,
-                                                                const SpmmArgs &a)
+                                                                const SpmmArgs &a, const ProConst<VEC> &pc)
 {
     using V = typename Vec<VEC>::type;
     constexpr int UE = U < G ? U : G;
@@ -155,10 +218,10 @@ __device__ __forceinline__ typename Vec<VEC>::type gather_range(int32_t b, int32
         }
         const int n = (hi - b) < G ? (hi - b) : G;
         int k = 0;
-        for (; k + UE <= n; k += UE) gather_batch<G, VEC, UE, MODE>(acc, k, myc, mysc, myval, gbase, xf, a);
-        if constexpr (UE >= 8) if (k + 4 <= n) { gather_batch<G, VEC, 4, MODE>(acc, k, myc, mysc, myval, gbase, xf, a); k += 4; }
-        if constexpr (UE >= 4) if (k + 2 <= n) { gather_batch<G, VEC, 2, MODE>(acc, k, myc, mysc, myval, gbase, xf, a); k += 2; }
-        if constexpr (UE >= 2) if (k + 1 <= n) { gather_batch<G, VEC, 1, MODE>(acc, k, myc, mysc, myval, gbase, xf, a); k += 1; }
+        for (; k + UE <= n; k += UE) gather_batch<G, VEC, UE, MODE>(acc, k, myc, mysc, myval, gbase, xf, a, pc);
+        if constexpr (UE >= 8) if (k + 4 <= n) { gather_batch<G, VEC, 4, MODE>(acc, k, myc, mysc, myval, gbase, xf, a, pc); k += 4; }
+        if constexpr (UE >= 4) if (k + 2 <= n) { gather_batch<G, VEC, 2, MODE>(acc, k, myc, mysc, myval, gbase, xf, a, pc); k += 2; }
+        if constexpr (UE >= 2) if (k + 1 <= n) { gather_batch<G, VEC, 1, MODE>(acc, k, myc, mysc, myval, gbase, xf, a, pc); k += 1; }
     }
     return acc;
 }
@@ -171,6 +234,7 @@ __device__ __forceinline__ void epilogue_store(typename Vec<VEC>::type acc, int3
     if (a.bias) acc = add_rn(acc, ld_vec(reinterpret_cast<const V *>(a.bias + f0)));
     V *dst = reinterpret_cast<V *>(a.Y + (int64_t)row * a.ldy + f0);
     if (a.beta) acc = add_rn(*dst, acc);
+    if (a.relu_out) acc = relu_v(acc);
     *dst = acc;
 }
 
@@ -187,6 +251,7 @@ __device__ __forceinline__ void epilogue_store_pre(typename Vec<VEC>::type acc, 
     if (has_bias) acc = add_rn(acc, bias);
     V *dst = reinterpret_cast<V *>(a.Y + (int64_t)row * a.ldy + f0);
     if (a.beta) acc = add_rn(*dst, acc);
+    if (a.relu_out) acc = relu_v(acc);
     *dst = acc;
 }
 
@@ -202,6 +267,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_bl
     const int32_t f0 = (blockIdx.y * G + li) * VEC;
     const bool active = f0 + VEC <= a.n_feat;
     const float *xf = a.X + (active ? f0 : 0);  // lanes past n_feat read feature 0 and never store
+    const ProConst<VEC> pc = pro_load<VEC, MODE>(a, f0, active);
 
     if ((int32_t)blockIdx.x < n_item_blocks) {
         // ---- chunk item of a long row: partial sum into the plan's slab
@@ -214,7 +280,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_bl
             item.z = __builtin_amdgcn_readfirstlane(item.z);
             item.w = __builtin_amdgcn_readfirstlane(item.w);
         }
-        auto acc = gather_range<G, VEC, U, MODE>(item.y, item.z, xf, li, a);
+        auto acc = gather_range<G, VEC, U, MODE>(item.y, item.z, xf, li, a, pc);
         if (active) *reinterpret_cast<typename Vec<VEC>::type *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
         return;
     }
@@ -227,7 +293,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_bl
         e = __builtin_amdgcn_readfirstlane(e);
     }
     if (a.split_threshold > 0 && e - b > a.split_threshold) return;  // handled by chunk items + combine
-    auto acc = gather_range<G, VEC, U, MODE>(b, e, xf, li, a);
+    auto acc = gather_range<G, VEC, U, MODE>(b, e, xf, li, a, pc);
     if (active) epilogue_store<VEC>(acc, row, f0, a);
 }
 
@@ -258,6 +324,7 @@ struct Stream {
     int32_t rp_l;    // lane l holds rowptr[r0 + min(l, nr)]
     float rs_l;      // lane l holds rowscale[r0 + min(l, nr - 1)] (if any)
     V bias_v;        // this lane's slice of the bias (if any)
+    ProConst<VEC> pc;  // this lane's slice of the prologue constants (MODE >= 3)
 
     __device__ __forceinline__ int32_t rp(int l) const { return bcast<G>(rp_l, l, gbase); }
 
@@ -295,7 +362,7 @@ struct Stream {
         for (int u = 0; u < B; u++) c[u] = bcast<G>(ch.c, k0 + u, gbase);
 #pragma unroll
         for (int u = 0; u < B; u++) b.v[u] = ld_vec(reinterpret_cast<const V *>(xf + (int64_t)c[u] * a.ldx));
-        if constexpr (MODE >= 1) {
+        if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
             for (int u = 0; u < B; u++) b.sc[u] = __int_as_float(bcast<G>(__float_as_int(ch.sc), k0 + u, gbase));
         }
@@ -319,7 +386,8 @@ struct Stream {
                     rs = rp(r);
                 }
                 V t = b.v[u];
-                if constexpr (MODE >= 1) t = mul_rn(t, b.sc[u]);
+                if constexpr (MODE >= 3) t = pro_apply<MODE>(t, pc);
+                if constexpr (MODE == 1 || MODE == 2) t = mul_rn(t, b.sc[u]);
                 if constexpr (MODE == 2) t = mul_rn(t, b.val[u]);
                 acc = add_rn(acc, t);
             }
@@ -380,6 +448,7 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     const int32_t f0 = (blockIdx.y * G + li) * VEC;
     const bool active = f0 + VEC <= a.n_feat;
     const float *xf = a.X + (active ? f0 : 0);
+    const ProConst<VEC> pc = pro_load<VEC, MODE>(a, f0, active);
 
     if ((int32_t)blockIdx.x < n_item_blocks) {  // chunk item of a hub row -> partial slab (same as spmm_kernel)
         int32_t it = blockIdx.x * GROUPS + grp;
@@ -390,7 +459,7 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
             item.z = __builtin_amdgcn_readfirstlane(item.z);
             item.w = __builtin_amdgcn_readfirstlane(item.w);
         }
-        auto acc = gather_range<G, VEC, 8, MODE>(item.y, item.z, xf, li, a);
+        auto acc = gather_range<G, VEC, 8, MODE>(item.y, item.z, xf, li, a, pc);
         if (active) *reinterpret_cast<typename Vec<VEC>::type *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
         return;
     }
@@ -416,7 +485,7 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     zero(bias_v);
     if (a.bias && active) bias_v = ld_vec(reinterpret_cast<const typename Vec<VEC>::type *>(a.bias + f0));
     const float rs_l = a.rowscale ? a.rowscale[r0 + (li < nr ? li : nr - 1)] : 1.f;
-    Stream<G, VEC, B, MODE> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)], rs_l, bias_v};
+    Stream<G, VEC, B, MODE> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)], rs_l, bias_v, pc};
 
     uint64_t hub = 0;  // bit l: local row l is a hub (left to the chunk items)
     if (a.split_threshold > 0) {
@@ -460,7 +529,7 @@ __global__ __launch_bounds__(64) void spmm_lds_kernel(SpmmArgs a, int32_t n_item
         item.y = __builtin_amdgcn_readfirstlane(item.y);
         item.z = __builtin_amdgcn_readfirstlane(item.z);
         item.w = __builtin_amdgcn_readfirstlane(item.w);
-        auto acc = gather_range<G, VEC, 8, 0>(item.y, item.z, xf, li, a);
+        auto acc = gather_range<G, VEC, 8, 0>(item.y, item.z, xf, li, a, ProConst<VEC>{});
         *reinterpret_cast<float4 *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
         return;
     }
@@ -654,8 +723,38 @@ __global__ void plan_block_fill_kernel(const int32_t *flag, const int32_t *pos, 
     starts[pos[r]] = r;
 }
 
+template <int G, int VEC, int U, int TPB>
+void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32_t n_item_blocks)
+{
+#define GNNX_STREAM(M) hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, M, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks)
+    switch (mode) {
+    case 0: GNNX_STREAM(0); break;
+    case 1: GNNX_STREAM(1); break;
+    case 2: GNNX_STREAM(2); break;
+    case 3: GNNX_STREAM(3); break;
+    case 4: GNNX_STREAM(4); break;
+    default: GNNX_STREAM(5); break;
+    }
+#undef GNNX_STREAM
+}
+
 template <int G, int VEC, int U>
-int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, hipStream_t st)
+void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32_t n_item_blocks)
+{
+#define GNNX_ROWS(M) hipLaunchKernelGGL((spmm_kernel<G, VEC, U, M>), grid, dim3(256), 0, st, a, n_item_blocks)
+    switch (mode) {
+    case 0: GNNX_ROWS(0); break;
+    case 1: GNNX_ROWS(1); break;
+    case 2: GNNX_ROWS(2); break;
+    case 3: GNNX_ROWS(3); break;
+    case 4: GNNX_ROWS(4); break;
+    default: GNNX_ROWS(5); break;
+    }
+#undef GNNX_ROWS
+}
+
+template <int G, int VEC, int U>
+int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipStream_t st)
 {
     constexpr int GROUPS = 256 / G;
     const int feat_per_tile = G * VEC;
@@ -664,11 +763,12 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, hipStream_t st
     dim3 grid;
     int32_t n_item_blocks = (int32_t)ceil_div(a.n_items, GROUPS);
     grid.y = (uint32_t)ceil_div(a.n_feat, feat_per_tile);
-    const bool general = a.vals != nullptr;
+    // kernel MODE: 0 forward, 1 colscale (backward), 2 general (vals), 3/4/5 forward with ReLU / BN / BN+ReLU prologue
+    const int mode = a.vals != nullptr ? 2 : (a.colscale ? 1 : (pro ? 2 + pro : 0));
     bool stream = false;
     if constexpr (G >= 8) stream = use_stream_kernel(G);
     if constexpr (G == 64 && VEC == 4) {
-        if (use_lds_variant() && a.n_feat == 256 && !general && !a.colscale) {  // measurement variant, forward mode only
+        if (use_lds_variant() && a.n_feat == 256 && mode == 0 && !a.relu_out) {  // measurement variant, forward mode only
             grid.x = (uint32_t)(a.n_items + (a.block_starts ? a.n_blocks : ceil_div(a.n_rows, StreamCfg<64>::R)));
             grid.y = 1;
             hipLaunchKernelGGL((spmm_lds_kernel<16>), grid, dim3(64), 0, st, a, (int32_t)a.n_items);
@@ -687,39 +787,17 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, hipStream_t st
             // One wavefront per workgroup: a workgroup's CU slot is held until its slowest wavefront ends, and
             // blocks of a power-law graph differ a lot in non-zeros, so multi-wave workgroups strand slots.
             static const int tpb_env = [] { const char *v = getenv("GNNX_SPMM_TPB"); return v ? atoi(v) : 64; }();
-            if (tpb_env == 256) {
-                constexpr int TPB = 256;
-                n_item_blocks = (int32_t)ceil_div(a.n_items, TPB / G);
-                grid.x = (uint32_t)(n_item_blocks + (a.block_starts ? ceil_div(a.n_blocks, TPB / G)
-                                                                    : ceil_div(a.n_rows, (int64_t)(TPB / G) * R)));
-                if (general)
-                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 2, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
-                else if (a.colscale)
-                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 1, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
-                else
-                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 0, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
-            } else {
-                constexpr int TPB = 64;
-                n_item_blocks = (int32_t)ceil_div(a.n_items, TPB / G);
-                grid.x = (uint32_t)(n_item_blocks + (a.block_starts ? ceil_div(a.n_blocks, TPB / G)
-                                                                    : ceil_div(a.n_rows, (int64_t)(TPB / G) * R)));
-                if (general)
-                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 2, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
-                else if (a.colscale)
-                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 1, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
-                else
-                    hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 0, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks);
-            }
+            const int tpb = tpb_env == 256 ? 256 : 64;
+            n_item_blocks = (int32_t)ceil_div(a.n_items, tpb / G);
+            grid.x = (uint32_t)(n_item_blocks + (a.block_starts ? ceil_div(a.n_blocks, tpb / G)
+                                                                : ceil_div(a.n_rows, (int64_t)(tpb / G) * R)));
+            if (tpb == 256) launch_stream<G, VEC, U, 256>(mode, grid, st, a, n_item_blocks);
+            else launch_stream<G, VEC, U, 64>(mode, grid, st, a, n_item_blocks);
         }
     } else {
         grid.x = (uint32_t)(n_item_blocks + ceil_div(a.n_rows, GROUPS));
         if (grid.x == 0) return GNNX_OK;
-        if (general)
-            hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 2>), grid, dim3(256), 0, st, a, n_item_blocks);
-        else if (a.colscale)
-            hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 1>), grid, dim3(256), 0, st, a, n_item_blocks);
-        else
-            hipLaunchKernelGGL((spmm_kernel<G, VEC, U, 0>), grid, dim3(256), 0, st, a, n_item_blocks);
+        launch_rows<G, VEC, U>(mode, grid, st, a, n_item_blocks);
     }
     GNNX_LAUNCH_CHECK();
     if (plan && plan->n_split_rows > 0) {
@@ -815,10 +893,10 @@ GNNX_API int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_split_ro
     return GNNX_OK;
 }
 
-GNNX_API int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
-                               const int32_t *d_colidx, const float *d_vals, const float *d_colscale,
-                               const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx,
-                               float beta, float *d_Y, int64_t ldy, const gnnx_spmm_plan *plan, void *stream)
+namespace {
+int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr, const int32_t *d_colidx, const float *d_vals,
+              const float *d_colscale, const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx, float beta,
+              float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan, void *stream)
 {
     GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
     if (n_rows == 0 || n_feat == 0) return GNNX_OK;
@@ -832,6 +910,20 @@ GNNX_API int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, c
                      "plan was built for at most %d features, got %d", plan->max_feat, n_feat);
     }
     SpmmArgs a{};
+    int pro = 0;  // 0 none, 1 ReLU, 2 BatchNorm, 3 BatchNorm + ReLU
+    if (fusion) {
+        const bool bn = fusion->bn_mean != nullptr;
+        GNNX_REQUIRE((fusion->bn_mean == nullptr) == (fusion->bn_var == nullptr), GNNX_ERR_INVALID_ARG, "bn_mean and bn_var go together");
+        GNNX_REQUIRE(bn || (!fusion->bn_gamma && !fusion->bn_beta), GNNX_ERR_INVALID_ARG, "bn_gamma / bn_beta without bn_mean");
+        pro = bn ? (fusion->relu_in ? 3 : 2) : (fusion->relu_in ? 1 : 0);
+        GNNX_REQUIRE(pro == 0 || (!d_vals && !d_colscale), GNNX_ERR_UNSUPPORTED, "a prologue goes with the forward mode only");
+        a.relu_out = fusion->relu_out != 0;
+        a.pro_mean = fusion->bn_mean;
+        a.pro_var = fusion->bn_var;
+        a.pro_gamma = fusion->bn_gamma;
+        a.pro_beta = fusion->bn_beta;
+        a.pro_eps = fusion->bn_eps;
+    }
     a.n_rows = n_rows;
     a.n_feat = n_feat;
     a.rowptr = d_rowptr;
@@ -857,20 +949,41 @@ GNNX_API int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, c
         a.partial_ld = plan->max_feat;
     }
     hipStream_t st = as_stream(stream);
-    auto aligned16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    auto aligned16 = [](const void *p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const bool vec4 = (n_feat % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(d_X) && aligned16(d_Y) &&
-                      (!d_bias || aligned16(d_bias));
+                      aligned16(d_bias) && aligned16(a.pro_mean) && aligned16(a.pro_var) && aligned16(a.pro_gamma) &&
+                      aligned16(a.pro_beta);
     if (vec4) {
         int lanes = n_feat / 4;
-        if (lanes > 32) return launch_mode<64, 4, 8>(a, plan, st);
-        if (lanes > 16) return launch_mode<32, 4, 8>(a, plan, st);
-        if (lanes > 8) return launch_mode<16, 4, 8>(a, plan, st);
-        if (lanes > 4) return launch_mode<8, 4, 8>(a, plan, st);
-        return launch_mode<4, 4, 8>(a, plan, st);
+        if (lanes > 32) return launch_mode<64, 4, 8>(a, plan, pro, st);
+        if (lanes > 16) return launch_mode<32, 4, 8>(a, plan, pro, st);
+        if (lanes > 8) return launch_mode<16, 4, 8>(a, plan, pro, st);
+        if (lanes > 4) return launch_mode<8, 4, 8>(a, plan, pro, st);
+        return launch_mode<4, 4, 8>(a, plan, pro, st);
     }
-    if (n_feat > 32) return launch_mode<64, 1, 8>(a, plan, st);
-    if (n_feat > 16) return launch_mode<32, 1, 8>(a, plan, st);
-    if (n_feat > 8) return launch_mode<16, 1, 8>(a, plan, st);
-    if (n_feat > 4) return launch_mode<8, 1, 8>(a, plan, st);
-    return launch_mode<4, 1, 8>(a, plan, st);
+    if (n_feat > 32) return launch_mode<64, 1, 8>(a, plan, pro, st);
+    if (n_feat > 16) return launch_mode<32, 1, 8>(a, plan, pro, st);
+    if (n_feat > 8) return launch_mode<16, 1, 8>(a, plan, pro, st);
+    if (n_feat > 4) return launch_mode<8, 1, 8>(a, plan, pro, st);
+    return launch_mode<4, 1, 8>(a, plan, pro, st);
+}
+}  // namespace
+
+GNNX_API int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
+                               const int32_t *d_colidx, const float *d_vals, const float *d_colscale,
+                               const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx,
+                               float beta, float *d_Y, int64_t ldy, const gnnx_spmm_plan *plan, void *stream)
+{
+    return spmm_impl(n_rows, n_cols, n_feat, d_rowptr, d_colidx, d_vals, d_colscale, d_rowscale, d_bias, d_X, ldx, beta, d_Y, ldy,
+                     nullptr, plan, stream);
+}
+
+GNNX_API int gnnx_spmm_csr_fused_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
+                                     const int32_t *d_colidx, const float *d_vals, const float *d_colscale,
+                                     const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx, float beta,
+                                     float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan,
+                                     void *stream)
+{
+    return spmm_impl(n_rows, n_cols, n_feat, d_rowptr, d_colidx, d_vals, d_colscale, d_rowscale, d_bias, d_X, ldx, beta, d_Y, ldy,
+                     fusion, plan, stream);
 }

@@ -67,6 +67,7 @@ public:
     explicit BatchNorm(const size_t &num_features, const float &eps = 1e-05, const float &momentum = 0.1, const bool &affine = true,
                        const bool &track_running_stats = true, const std::string &n = "BatchNorm");
     cyg::tptr<float> forward(const cyg::tptr<float> &x) override;
+    bool uses_batch_stats() const { return training || !_tracking_running_stats; }
 
     size_t _num_features;
     float _eps, _momentum;

@@ -317,7 +317,7 @@ public:
         auto dgamma = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
         auto dbeta = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
         detail::gx(gnnx_bn_relu_bwd_f32(x->device_data(), f, nullptr, 0, g->device_data(), f, n, f, mean->device_data(), var->device_data(),
-                                        eps, gamma->device_data(), 0, dx->device_out(), f, dgamma->device_out(), dbeta->device_out(),
+                                        eps, gamma->device_data(), nullptr, 0, dx->device_out(), f, dgamma->device_out(), dbeta->device_out(),
                                         detail::workspace(wsb), wsb, detail::current_stream()), "BatchNorm");
         if (x->requires_grad()) x->backward(dx);
         if (gamma->requires_grad()) gamma->backward(dgamma);
@@ -350,7 +350,7 @@ public:
         const auto shp = x->shape();
         auto dx = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
         detail::gx(gnnx_bn_relu_bwd_f32(x->device_data(), (int64_t)shp[1], y->device_data(), (int64_t)shp[1], g->device_data(),
-                                        (int64_t)shp[1], (int64_t)shp[0], (int32_t)shp[1], nullptr, nullptr, 0.f, nullptr, 1,
+                                        (int64_t)shp[1], (int64_t)shp[0], (int32_t)shp[1], nullptr, nullptr, 0.f, nullptr, nullptr, 1,
                                         dx->device_out(), (int64_t)shp[1], nullptr, nullptr, nullptr, 0, detail::current_stream()), "ReLU");
         if (x->requires_grad()) x->backward(dx);
     }
@@ -629,6 +629,88 @@ public:
     }
     bool has_bias = false;
 };
+
+// transform output H -> [BatchNorm (batch statistics) -> ReLU] -> aggregation + bias as ONE op: the two modules of
+// graph.cpp:174-175 ride in the SpMM's gather (gnnx_spmm_csr_fused_f32), so neither BN(H) nor relu(BN(H)) is written to HBM;
+// backward recomputes the ReLU mask from H.  Same arithmetic, same bits as running the three ops one after the other.
+class BnReluAggregateOp : public cyg::Operation<tensor<float>> {
+public:
+    std::shared_ptr<cyg::detail::Csr> csr;
+    tptr<float> norm, mean, var;
+    float eps = 1e-5f;
+    bool has_beta = false;
+    BnReluAggregateOp() { name = "GCNBnReluAggregate"; }
+    tptr<float> forward(const tptr<float> &adj, const tptr<float> &h, const tptr<float> &norm_, const tptr<float> &bias,
+                        const tptr<float> &gamma, const tptr<float> &beta)
+    {
+        csr = adj->csr();
+        norm = norm_;
+        const auto shp = h->shape();
+        const int64_t n = (int64_t)shp[0];
+        const int32_t f = (int32_t)shp[1];
+        void *st = cyg::detail::current_stream();
+        csr->ensure_plans(f);
+        mean = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
+        var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
+        size_t wsb = 0;
+        cyg::detail::gx(gnnx_bn_workspace(n, f, &wsb), "BatchNorm");
+        cyg::detail::gx(gnnx_bn_stats_f32(h->device_data(), f, n, f, mean->device_out(), var->device_out(), cyg::detail::workspace(wsb),
+                                          wsb, st), "BatchNorm");
+        const bool req = h->requires_grad() || bias->requires_grad() || gamma->requires_grad() || (beta && beta->requires_grad());
+        auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, req);
+        gnnx_spmm_fusion fu{};
+        fu.bn_mean = mean->device_data();
+        fu.bn_var = var->device_data();
+        fu.bn_gamma = gamma->device_data();
+        fu.bn_beta = beta ? beta->device_data() : nullptr;
+        fu.bn_eps = eps;
+        fu.relu_in = 1;
+        cyg::detail::gx(gnnx_spmm_csr_fused_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr, (const int32_t *)csr->colidx, nullptr,
+                                                nullptr, norm->device_data(), bias->device_data(), h->device_data(), f, 0.0f,
+                                                out->device_out(), f, &fu, csr->plan, st), "aggregate");
+        has_beta = (bool)beta;
+        if (req) context->save_for_backward({h, bias, gamma, beta ? beta : gamma});
+        return out;
+    }
+    void _backward(std::shared_ptr<tensor<float>> g) override
+    {
+        auto v = context->get_variables();
+        CHECK_BACKWARD<tensor<float>>(v, 4);
+        auto h = v[0], bias = v[1], gamma = v[2], beta = v[3];
+        const auto shp = h->shape();
+        const int64_t n = (int64_t)shp[0];
+        const int32_t f = (int32_t)shp[1];
+        void *st = cyg::detail::current_stream();
+        if (bias->requires_grad()) {
+            auto db = g->clone(false);
+            db->sum_to_size(bias->shape());
+            bias->backward(db);
+        }
+        if (!(h->requires_grad() || gamma->requires_grad() || (has_beta && beta->requires_grad()))) return;
+        csr->ensure_plans(f);
+        if (!csr->norm_per_nz_t) {
+            cyg::detail::gx(gnnx_malloc(&csr->norm_per_nz_t, sizeof(float) * (size_t)std::max<int64_t>(csr->nnz_t, 1)), "aggregate");
+            cyg::detail::gx(gnnx_gather_rows_f32(norm->device_data(), 1, (const int32_t *)csr->colidx_t, csr->nnz_t, 1,
+                                                 (float *)csr->norm_per_nz_t, 1, st), "aggregate");
+        }
+        auto dy = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);  // d relu(BN(H))
+        cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
+                                          (const float *)csr->norm_per_nz_t, nullptr, nullptr, nullptr, g->device_data(), f, 0.0f,
+                                          dy->device_out(), f, csr->plan_t, st), "aggregate");
+        size_t wsb = 0;
+        cyg::detail::gx(gnnx_bn_workspace(n, f, &wsb), "BatchNorm");
+        auto dh = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
+        auto dgamma = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
+        auto dbeta = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
+        cyg::detail::gx(gnnx_bn_relu_bwd_f32(h->device_data(), f, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
+                                             var->device_data(), eps, gamma->device_data(), has_beta ? beta->device_data() : nullptr, 1,
+                                             dh->device_out(), f, dgamma->device_out(), dbeta->device_out(),
+                                             cyg::detail::workspace(wsb), wsb, st), "BatchNorm");
+        if (h->requires_grad()) h->backward(dh);
+        if (gamma->requires_grad()) gamma->backward(dgamma);
+        if (has_beta && beta->requires_grad()) beta->backward(dbeta);
+    }
+};
 }  // namespace
 
 GCNConv::GCNConv(size_t in_channels, size_t out_channels, float dropout)
@@ -668,6 +750,15 @@ tptr<float> GCNConv::forward(Data &&input)
         }
         auto out = (*get_module("lin"))(input.x());
         if (!hot_path_only) {
+            auto *bn = dynamic_cast<nn::BatchNorm *>(get_module("bnorm").get());
+            if (bn && bn->uses_batch_stats() && !std::getenv("GNNCPP_NO_PROLOGUE_FUSION")) {
+                auto op = std::make_unique<BnReluAggregateOp>();
+                op->eps = bn->_eps;
+                auto res = op->forward(_cache_adj, out, _cache_norm, get_parameter("bias"), bn->get_parameter("gammas"),
+                                       bn->_affine ? bn->get_parameter("betas") : nullptr);
+                if (res->requires_grad()) res->grad_fn = std::move(op);
+                return res;
+            }
             out = (*get_module("bnorm"))(out);
             out = (*get_module("relu"))(out);
         }

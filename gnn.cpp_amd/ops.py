@@ -120,12 +120,22 @@ class CsrGraph:
 
 
 def spmm(rowptr, colidx, X, out=None, vals=None, colscale=None, rowscale=None, bias=None, beta=0.0, plan=None,
-         n_rows=None):
-    """gnnx_spmm_csr_f32: Y = beta*Y + rowscale (.) (A . (colscale (.) X)) + bias."""
+         n_rows=None, bn=None, relu_in=False, relu_out=False):
+    """gnnx_spmm_csr_f32: Y = beta*Y + rowscale (.) (A . (colscale (.) X)) + bias.
+    bn=(mean, var, gamma|None, beta|None, eps) / relu_in / relu_out: gnnx_spmm_csr_fused_f32 (BatchNorm / ReLU applied to
+    every gathered row, ReLU on the stored row)."""
     n_rows = int(rowptr.numel() - 1) if n_rows is None else n_rows
     n_cols, F = X.shape
     if out is None:
         out = torch.empty((n_rows, F), dtype=torch.float32, device=X.device)
+    if bn is not None or relu_in or relu_out:
+        mean, var, gamma, bbeta, eps = bn if bn is not None else (None, None, None, None, 0.0)
+        addr = lambda t: None if t is None else _ptr(t).value  # noqa: E731
+        fu = capi.SpmmFusion(addr(mean), addr(var), addr(gamma), addr(bbeta), float(eps), int(relu_in), int(relu_out))
+        capi.call("gnnx_spmm_csr_fused_f32", n_rows, n_cols, F, _ptr(rowptr), _ptr(colidx), _ptr(vals), _ptr(colscale),
+                  _ptr(rowscale), _ptr(bias), _ptr(X), _ld(X), float(beta), _ptr(out), _ld(out), C.byref(fu),
+                  plan.h if plan is not None else None, _stream())
+        return out
     capi.call("gnnx_spmm_csr_f32", n_rows, n_cols, F, _ptr(rowptr), _ptr(colidx), _ptr(vals), _ptr(colscale),
               _ptr(rowscale), _ptr(bias), _ptr(X), _ld(X), float(beta), _ptr(out), _ld(out),
               plan.h if plan is not None else None, _stream())
@@ -235,7 +245,8 @@ def bn_relu_fwd(X, mean=None, var=None, gamma=None, beta=None, eps=1e-5, relu=Tr
     return out
 
 
-def bn_relu_bwd(X, Y, dY, mean=None, var=None, gamma=None, eps=1e-5, relu=True):
+def bn_relu_bwd(X, Y, dY, mean=None, var=None, gamma=None, eps=1e-5, relu=True, beta=None):
+    """Y=None with relu: the forward output was never stored (fused forward); its sign is recomputed from X."""
     N, F = X.shape
     dX = torch.empty_like(X)
     dgamma = torch.empty(F, dtype=torch.float32, device=X.device) if mean is not None else None
@@ -244,8 +255,8 @@ def bn_relu_bwd(X, Y, dY, mean=None, var=None, gamma=None, eps=1e-5, relu=True):
     capi.call("gnnx_bn_workspace", N, F, C.byref(wsb))
     ws = _workspace(wsb.value, X.device, "bn")
     capi.call("gnnx_bn_relu_bwd_f32", _ptr(X), _ld(X), _ptr(Y), _ld(Y) if Y is not None else 0, _ptr(dY), _ld(dY), N, F, _ptr(mean),
-              _ptr(var), float(eps), _ptr(gamma), int(relu), _ptr(dX), _ld(dX), _ptr(dgamma), _ptr(dbeta), _ptr(ws), wsb.value,
-              _stream())
+              _ptr(var), float(eps), _ptr(gamma), _ptr(beta), int(relu), _ptr(dX), _ld(dX), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+              wsb.value, _stream())
     return dX, dgamma, dbeta
 
 
@@ -269,9 +280,11 @@ def linear_fwd(X, W, out=None):
     return gemm(X, W, transB=True, out=out)
 
 
-def aggregate_fwd(g, H, bias=None, out=None, use_plan=True):
-    """out = norm (.) (A . H) (+ bias)  (graph.cpp:204-212, :188)."""
-    return spmm(g.rowptr, g.colidx, H, out=out, rowscale=g.norm, bias=bias, plan=g.plan if use_plan else None)
+def aggregate_fwd(g, H, bias=None, out=None, use_plan=True, bn=None, relu_in=False, relu_out=False):
+    """out = norm (.) (A . H) (+ bias)  (graph.cpp:204-212, :188).  bn / relu_in: GCNConv's BatchNorm + ReLU between transform
+    and aggregation (graph.cpp:174-175) folded into the gather; relu_out: the ReLU in front of the next layer."""
+    return spmm(g.rowptr, g.colidx, H, out=out, rowscale=g.norm, bias=bias, plan=g.plan if use_plan else None, bn=bn,
+                relu_in=relu_in, relu_out=relu_out)
 
 
 def aggregate_bwd(g, G, out=None, beta=0.0, use_plan=True):
@@ -359,9 +372,9 @@ class GcnStack:
         L = len(self.W)
         for l in range(L):
             H = linear_fwd(h, self.W[l])
-            Z = aggregate_fwd(self.g, H, self.b[l])
-            Y = bn_relu_fwd(Z, relu=True) if l + 1 < L else Z
-            saved.append((h, Z, Y))
+            # the ReLU between layers rides in the aggregation's epilogue: only relu(Z) is stored (its sign is the mask)
+            Y = aggregate_fwd(self.g, H, self.b[l], relu_out=l + 1 < L)
+            saved.append((h, Y))
             h = Y
         self._saved = saved
         return h
@@ -369,9 +382,9 @@ class GcnStack:
     def backward(self, dOut):
         G = dOut
         for l in reversed(range(len(self.W))):
-            h, Z, Y = self._saved[l]
+            h, Y = self._saved[l]
             if l + 1 < len(self.W):
-                G, _, _ = bn_relu_bwd(Z, Y, G, relu=True)
+                G, _, _ = bn_relu_bwd(Y, Y, G, relu=True)
             colsum(G, out=self.db[l])
             dH = aggregate_bwd(self.g, G)
             G, _ = linear_bwd(dH, h, self.W[l], dW=self.dW[l])

@@ -139,6 +139,27 @@ int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int3
                       const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx, float beta,
                       float *d_Y, int64_t ldy, const gnnx_spmm_plan *plan, void *stream);
 
+/* The same SpMM with the modules that GCNConv::forward runs either side of the aggregation folded in, so the
+ * normalised / rectified activations never make their own trip through HBM:
+ *   prologue, applied to every gathered row of X before it is added (forward mode only: vals = colscale = NULL):
+ *     bn_mean/bn_var != NULL : x <- ((x - mean) / (var + eps)^0.5) * gamma + beta   (nn.cpp:285-330 BatchNorm::forward with
+ *                              the batch statistics of gnnx_bn_stats_f32; gamma / beta NULL = 1 / 0)
+ *     relu_in  != 0          : x <- where(x > 0, x, 0)                              (nn.cpp:229-237, graph.cpp:174-175)
+ *   epilogue: relu_out != 0  : Y <- where(Y > 0, Y, 0) after rowscale / bias / beta (the ReLU between two stacked layers).
+ * Separately rounded ops in the order of gnnx_bn_relu_fwd_f32: fused and unfused results are the same bits.
+ * fusion == NULL is gnnx_spmm_csr_f32. */
+typedef struct gnnx_spmm_fusion {
+    const float *bn_mean, *bn_var, *bn_gamma, *bn_beta; /* [F] device pointers, or NULL */
+    float bn_eps;
+    int relu_in;
+    int relu_out;
+} gnnx_spmm_fusion;
+int gnnx_spmm_csr_fused_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
+                            const int32_t *d_colidx, const float *d_vals, const float *d_colscale,
+                            const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx, float beta,
+                            float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan,
+                            void *stream);
+
 /* ------------------------------------------------------------------ hot path: transform ---------- */
 /*
  * fp32 GEMM on the MFMA units (v_mfma_f32_32x32x2_f32, exact f32) -- replaces functional::matmul for the
@@ -215,7 +236,9 @@ int gnnx_transpose_f32(const float *d_X, int64_t ldx, int64_t n_rows, int64_t n_
  * stats : d_mean[F], d_var[F] (biased variance).   fwd: d_mean/d_var may both be NULL (ReLU only); gamma / beta may be NULL.
  * bwd   : mathematically correct gradients (the reference's own drop fan-in contributions, operation.h:82-86):
  *         g = dY (.) (Y > 0);  dbeta = colsum g;  dgamma = colsum g (.) xhat;  dX = gamma/sigma (.) (g - dbeta/N - xhat (.) dgamma/N).
- *         d_Y (the forward output) is only read when relu != 0.  Workspace: gnnx_bn_workspace() bytes.
+ *         d_Y (the forward output) is only read when relu != 0; d_Y == NULL with relu != 0 redoes the forward arithmetic on
+ *         x (with d_beta) to find the sign -- the backward of a fused forward (gnnx_spmm_csr_fused_f32), where the rectified
+ *         activations were never stored.  d_beta is read for that only.  Workspace: gnnx_bn_workspace() bytes.
  */
 int gnnx_bn_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes);
 int gnnx_bn_stats_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, float *d_mean, float *d_var,
@@ -223,9 +246,9 @@ int gnnx_bn_stats_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_f
 int gnnx_bn_relu_fwd_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var,
                          float eps, const float *d_gamma, const float *d_beta, int relu, float *d_Y, int64_t ldy, void *stream);
 int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd, int64_t n_rows,
-                         int32_t n_feat, const float *d_mean, const float *d_var, float eps, const float *d_gamma, int relu,
-                         float *d_dX, int64_t ldo, float *d_dgamma, float *d_dbeta, void *d_workspace, size_t workspace_bytes,
-                         void *stream);
+                         int32_t n_feat, const float *d_mean, const float *d_var, float eps, const float *d_gamma, const float *d_beta,
+                         int relu, float *d_dX, int64_t ldo, float *d_dgamma, float *d_dbeta, void *d_workspace,
+                         size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ next row: loss + optimiser ---- */
 /*

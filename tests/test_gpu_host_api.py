@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 DRIVER = os.path.join(ROOT, "tests", "cpp", "dropin_driver")
 
 
-def run_driver(d, unfused=False):
+def run_driver(d, unfused=False, no_prologue_fusion=False):
     assert os.path.exists(DRIVER), "build it with __graft_entry__.build()"
     with tempfile.TemporaryDirectory() as td:
         cpath = os.path.join(td, "case.bin")
@@ -31,6 +31,8 @@ def run_driver(d, unfused=False):
         env = dict(os.environ)
         if unfused:
             env["GNNCPP_UNFUSED"] = "1"  # op-by-op MatMul/Mul/Add instead of the fused aggregation op
+        if no_prologue_fusion:
+            env["GNNCPP_NO_PROLOGUE_FUSION"] = "1"  # BatchNorm and ReLU as their own kernels in front of the aggregation
         r = subprocess.run([DRIVER, cpath, td, "full"], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         n, fin, fout = d["n"], d["fin"], d["fout"]
@@ -47,8 +49,10 @@ def run_driver(d, unfused=False):
 def test_fused_and_op_by_op_paths_give_the_same_bits(name):
     d = load_case(name)
     a, b = run_driver(d, unfused=False), run_driver(d, unfused=True)
+    c = run_driver(d, no_prologue_fusion=True)
     for k in ("ei2", "s", "norm", "H", "agg", "out", "dX", "dW", "dbias", "out_full", "Hbn", "Hrelu", "loss"):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+        assert np.array_equal(a[k], c[k], equal_nan=True), k + " (BatchNorm+ReLU folded into the gather vs separate kernels)"
 
 
 @pytest.mark.parametrize("name", CASES)

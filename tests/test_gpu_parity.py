@@ -731,3 +731,48 @@ def test_rowsum_walks_up_like_functional_sum(env):
     Xw = synth.uniform_pm1(904, (77, 300))  # wider than a wavefront: lane slices, then left to right
     got = host(ops.rowsum(dev(env, Xw)))
     assert np.abs(got.astype(np.float64) - Xw.astype(np.float64).sum(1)).max() <= 1e-5 * np.abs(Xw).sum(1).max()
+
+
+# ---- fusion: BatchNorm / ReLU folded into the aggregation (gnnx_spmm_csr_fused_f32) ----------------
+@pytest.mark.parametrize("n,e,F,chunk", [(3000, 40000, 256, 0), (3000, 40000, 256, 64), (2000, 30000, 100, 0), (1500, 20000, 16, 0),
+                                         (1500, 20000, 7, 0), (4000, 60000, 128, 32), (900, 9000, 50, 16)])
+def test_fused_prologue_epilogue_same_bits_as_separate_kernels(env, n, e, F, chunk):
+    """relu(bn(H)) gathered on the fly == bn_relu_fwd into a buffer, then the plain aggregation: same ops in the same
+    order, so the same bits -- every kernel variant (row / streaming, vector / scalar lanes, with and without hub chunks)."""
+    ops = env["ops"]
+    src, dst = synth.rmat_edges(700 + F, n, e)
+    g = ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), n)
+    if chunk:
+        g.make_plans(chunk, F)
+    H = dev(env, synth.uniform_pm1(701, (n, F)) * 1.7 + 0.2)
+    gamma = dev(env, synth.uniform_pm1(702, (F,)) + 1.5)
+    beta = dev(env, synth.uniform_pm1(703, (F,), scale=0.3))
+    bias = dev(env, synth.uniform_pm1(704, (F,), scale=0.5))
+    mean, var = ops.bn_stats(H)
+    for (gm, bt, relu) in ((gamma, beta, True), (gamma, beta, False), (None, None, True), (gamma, None, True)):
+        sep = ops.aggregate_fwd(g, ops.bn_relu_fwd(H, mean, var, gm, bt, relu=relu), bias)
+        fus = ops.aggregate_fwd(g, H, bias, bn=(mean, var, gm, bt, 1e-5), relu_in=relu)
+        assert same(host(fus), host(sep)), (F, chunk, gm is not None, bt is not None, relu)
+    # ReLU only, as prologue and as epilogue
+    sep = ops.aggregate_fwd(g, ops.bn_relu_fwd(H, relu=True), bias)
+    assert same(host(ops.aggregate_fwd(g, H, bias, relu_in=True)), host(sep))
+    plain = ops.aggregate_fwd(g, H, bias)
+    assert same(host(ops.aggregate_fwd(g, H, bias, relu_out=True)), np.maximum(host(plain), 0))
+    # backward of the fused forward: the ReLU mask is recomputed from H instead of read from a stored output
+    dY = dev(env, synth.uniform_pm1(705, (n, F)))
+    Y = ops.bn_relu_fwd(H, mean, var, gamma, beta, relu=True)
+    a = ops.bn_relu_bwd(H, Y, dY, mean, var, gamma, relu=True, beta=beta)
+    b = ops.bn_relu_bwd(H, None, dY, mean, var, gamma, relu=True, beta=beta)
+    for x, y in zip(a, b):
+        assert same(host(x), host(y))
+    Yr = ops.bn_relu_fwd(H, relu=True)
+    assert same(host(ops.bn_relu_bwd(H, Yr, dY, relu=True)[0]), host(ops.bn_relu_bwd(H, None, dY, relu=True)[0]))
+
+
+def test_fused_prologue_rejects_backward_modes(env):
+    ops, capi = env["ops"], env["capi"]
+    src, dst = synth.rmat_edges(710, 100, 600)
+    g = ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), 100)
+    H = dev(env, synth.uniform_pm1(711, (100, 8)))
+    with pytest.raises(capi.GnnxError):
+        ops.spmm(g.rowptr, g.colidx, H, colscale=g.norm, relu_in=True)
