@@ -72,6 +72,8 @@ _SIGS = {
     "gnnx_event_elapsed_ms": [_vp, _vp, C.POINTER(_f32)],
     "gnnx_csr_from_coo_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_csr_from_coo": [_vp, _vp, _i64, _i32, _u32, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
+    "gnnx_csr_from_coo_weighted_workspace": [_i64, _i32, C.POINTER(_sz)],
+    "gnnx_csr_from_coo_weighted": [_vp, _vp, _vp, _i64, _i32, _u32, C.c_int, _f32, _vp, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
     "gnnx_degree_norm_f32": [_vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "gnnx_spmm_plan_create": [_vp, _i32, _i32, _i32, C.POINTER(_vp), _vp],
     "gnnx_spmm_plan_destroy": [_vp],

@@ -177,6 +177,97 @@ hipError_t plan_workspace(int64_t n_edges, int32_t n_nodes, char *base, CsrWorks
     return hipSuccess;
 }
 
+
+// ---- weighted build (edge_attr): A[r][c] = w by assignment, so of duplicate edges the LAST one in the list wins --------
+// (reference graph.cpp:40).  Keys are sorted together with their position in the list by a stable radix sort; the last
+// element of every run of equal keys is the winner.  GNNX_DIAG_FILL appends one (i, i) key per node behind the list, i.e.
+// a later assignment that overrides any self loop given -- fill_diagonal_(value) of add_self_loops (graph.cpp:72).
+__global__ void pack_keys_weighted_kernel(const int32_t *src, const int32_t *dst, int64_t n_edges, int32_t n_nodes, int diag_mode,
+                                          uint64_t *keys, int32_t *idx, int32_t *bad)
+{
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = n_edges + (diag_mode == GNNX_DIAG_FILL ? n_nodes : 0);
+    if (e >= total) return;
+    uint64_t key;
+    if (e >= n_edges) {
+        const uint32_t i = (uint32_t)(e - n_edges);
+        key = ((uint64_t)i << 32) | i;
+    } else {
+        int32_t r = src[e], c = dst[e];
+        if (r < 0 || c < 0 || r >= n_nodes || c >= n_nodes) {
+            key = kSentinel;
+            atomicOr(bad, 1);
+        } else if (r == c && diag_mode != GNNX_DIAG_KEEP) {
+            key = kSentinel;  // stripped, or replaced by the appended diagonal entry
+        } else {
+            key = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
+        }
+    }
+    keys[e] = key;
+    idx[e] = (int32_t)e;
+}
+
+__global__ void tail_flags_weighted_kernel(const uint64_t *keys, const int32_t *idx, int64_t n, int64_t n_edges, const float *w,
+                                           float diag_value, uint32_t flags, int32_t *flag)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    bool keep = k != kSentinel;
+    if (keep && i + 1 < n && !(flags & GNNX_CSR_KEEP_DUPLICATES)) keep = keys[i + 1] != k;  // last of its run
+    if (keep && (flags & GNNX_CSR_DROP_TRUNCATED_ZERO)) {
+        const int32_t e = idx[i];
+        const float v = e < n_edges ? w[e] : diag_value;
+        keep = (int)v != 0;  // adj_to_edge_list: `if (int(data[i]) != 0)` (graph.cpp:54) -- |w| < 1 vanishes
+    }
+    flag[i] = keep ? 1 : 0;
+}
+
+__global__ void compact_weighted_kernel(const uint64_t *keys, const int32_t *idx, const int32_t *flag, const int32_t *pos, int64_t n,
+                                        int64_t n_edges, const float *w, float diag_value, uint64_t *ukeys, int32_t *colidx,
+                                        float *vals)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint64_t k = keys[i];
+    const int32_t p = pos[i], e = idx[i];
+    ukeys[p] = k;
+    colidx[p] = (int32_t)(k & 0xffffffffu);
+    vals[p] = e < n_edges ? w[e] : diag_value;
+}
+
+struct CsrWorkspaceW {
+    uint64_t *keys_in, *keys_out;
+    int32_t *idx_in, *idx_out, *flag, *pos, *bad;
+    void *prim;
+    size_t prim_bytes;
+    size_t total;
+};
+
+hipError_t plan_workspace_weighted(int64_t n_keys, char *base, CsrWorkspaceW &w)
+{
+    size_t n = (size_t)(n_keys > 0 ? n_keys : 1);
+    size_t sort_bytes = 0, scan_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr,
+                                             (int32_t *)nullptr, n, 0, 64);
+    if (e != hipSuccess) return e;
+    e = rocprim::exclusive_scan(nullptr, scan_bytes, (int32_t *)nullptr, (int32_t *)nullptr, 0, n, rocprim::plus<int32_t>());
+    if (e != hipSuccess) return e;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return base + o; };
+    w.keys_in = (uint64_t *)take(n * 8);
+    w.keys_out = (uint64_t *)take(n * 8);
+    w.idx_in = (int32_t *)take(n * 4);
+    w.idx_out = (int32_t *)take(n * 4);
+    w.flag = (int32_t *)take(n * 4);
+    w.pos = (int32_t *)take(n * 4);
+    w.bad = (int32_t *)take(256);
+    w.prim_bytes = sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+    w.prim = take(w.prim_bytes);
+    w.total = off;
+    return hipSuccess;
+}
+
 }  // namespace
 
 GNNX_API int gnnx_csr_from_coo_workspace(int64_t n_edges, int32_t n_nodes, size_t *bytes)
@@ -228,6 +319,71 @@ GNNX_API int gnnx_csr_from_coo(const int32_t *d_src, const int32_t *d_dst, int64
     int32_t h_last[2] = {0, 0}, h_bad = 0;
     GNNX_HIP_CHECK(hipMemcpyAsync(&h_last[0], w.pos + (n_edges - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GNNX_HIP_CHECK(hipMemcpyAsync(&h_last[1], w.flag + (n_edges - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipMemcpyAsync(&h_bad, w.bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    GNNX_REQUIRE(!h_bad, GNNX_ERR_INDEX_RANGE,
+                 "invalid input, max value in edge_index should be less than the number of nodes from x");
+    int32_t nnz = h_last[0] + h_last[1];
+    dim3 rgrid((uint32_t)ceil_div((int64_t)n_nodes + 1, T));
+    hipLaunchKernelGGL(rowptr_kernel, rgrid, dim3(T), 0, st, w.keys_in, nnz, n_nodes, d_rowptr);
+    GNNX_LAUNCH_CHECK();
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    *nnz_out = nnz;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_csr_from_coo_weighted_workspace(int64_t n_edges, int32_t n_nodes, size_t *bytes)
+{
+    GNNX_REQUIRE(bytes && n_edges >= 0 && n_nodes >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    CsrWorkspaceW w;
+    GNNX_HIP_CHECK(plan_workspace_weighted(n_edges + n_nodes, nullptr, w));
+    *bytes = w.total;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_csr_from_coo_weighted(const int32_t *d_src, const int32_t *d_dst, const float *d_weights, int64_t n_edges,
+                                        int32_t n_nodes, uint32_t flags, int diag_mode, float diag_value, int32_t *d_rowptr,
+                                        int32_t *d_colidx, float *d_vals, int64_t *nnz_out, void *d_workspace, size_t workspace_bytes,
+                                        void *stream)
+{
+    GNNX_REQUIRE(n_edges >= 0 && n_nodes >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    GNNX_REQUIRE(diag_mode == GNNX_DIAG_KEEP || diag_mode == GNNX_DIAG_STRIP || diag_mode == GNNX_DIAG_FILL, GNNX_ERR_INVALID_ARG,
+                 "unknown diag_mode %d", diag_mode);
+    const int64_t n_keys = n_edges + (diag_mode == GNNX_DIAG_FILL ? n_nodes : 0);
+    GNNX_REQUIRE(n_keys < (1ll << 31), GNNX_ERR_UNSUPPORTED, "n_edges (+ n_nodes) must be < 2^31 (int32 CSR offsets)");
+    GNNX_REQUIRE(d_rowptr && nnz_out, GNNX_ERR_INVALID_ARG, "null pointer");
+    hipStream_t st = as_stream(stream);
+    *nnz_out = 0;
+    if (n_keys == 0) {
+        GNNX_HIP_CHECK(hipMemsetAsync(d_rowptr, 0, sizeof(int32_t) * ((size_t)n_nodes + 1), st));
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));
+        return GNNX_OK;
+    }
+    GNNX_REQUIRE((n_edges == 0 || (d_src && d_dst && d_weights)) && d_colidx && d_vals && d_workspace, GNNX_ERR_INVALID_ARG,
+                 "null pointer");
+    CsrWorkspaceW w;
+    GNNX_HIP_CHECK(plan_workspace_weighted(n_edges + n_nodes, (char *)d_workspace, w));
+    GNNX_REQUIRE(workspace_bytes >= w.total, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, w.total);
+    const int T = 256;
+    dim3 egrid((uint32_t)ceil_div(n_keys, T));
+    GNNX_HIP_CHECK(hipMemsetAsync(w.bad, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(pack_keys_weighted_kernel, egrid, dim3(T), 0, st, d_src, d_dst, n_edges, n_nodes, diag_mode, w.keys_in, w.idx_in,
+                       w.bad);
+    GNNX_LAUNCH_CHECK();
+    size_t prim_bytes = w.prim_bytes;
+    // radix sort is stable: inside a run of equal keys the list positions stay ascending
+    GNNX_HIP_CHECK(rocprim::radix_sort_pairs(w.prim, prim_bytes, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (size_t)n_keys, 0, 64, st));
+    hipLaunchKernelGGL(tail_flags_weighted_kernel, egrid, dim3(T), 0, st, w.keys_out, w.idx_out, n_keys, n_edges, d_weights, diag_value,
+                       flags, w.flag);
+    GNNX_LAUNCH_CHECK();
+    prim_bytes = w.prim_bytes;
+    GNNX_HIP_CHECK(rocprim::exclusive_scan(w.prim, prim_bytes, w.flag, w.pos, 0, (size_t)n_keys, rocprim::plus<int32_t>(), st));
+    hipLaunchKernelGGL(compact_weighted_kernel, egrid, dim3(T), 0, st, w.keys_out, w.idx_out, w.flag, w.pos, n_keys, n_edges, d_weights,
+                       diag_value, w.keys_in, d_colidx, d_vals);
+    GNNX_LAUNCH_CHECK();
+    int32_t h_last[2] = {0, 0}, h_bad = 0;
+    GNNX_HIP_CHECK(hipMemcpyAsync(&h_last[0], w.pos + (n_keys - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipMemcpyAsync(&h_last[1], w.flag + (n_keys - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GNNX_HIP_CHECK(hipMemcpyAsync(&h_bad, w.bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GNNX_HIP_CHECK(hipStreamSynchronize(st));
     GNNX_REQUIRE(!h_bad, GNNX_ERR_INDEX_RANGE,

@@ -166,8 +166,9 @@ tptr<T> sum(const tptr<T> &base, int dim, bool keepdim)
             std::vector<size_t> od = keepdim ? std::vector<size_t>{(size_t)c->n, 1} : std::vector<size_t>{(size_t)c->n};
             auto out = impl::new_out(od, false);
             if (base->csr_transposed()) c->ensure_transpose();
-            detail::gx(gnnx_csr_rowsum_f32((const int32_t *)(base->csr_transposed() ? c->rowptr_t : c->rowptr), nullptr, c->n,
-                                           out->device_out(), st), "sum");
+            detail::gx(gnnx_csr_rowsum_f32((const int32_t *)(base->csr_transposed() ? c->rowptr_t : c->rowptr),
+                                           (const float *)(base->csr_transposed() ? c->vals_t : c->vals), c->n, out->device_out(), st),
+                       "sum");
             return out;
         }
         if (rank == 2 && dim == 0) {
@@ -210,8 +211,9 @@ tptr<T> matmul(const tptr<T> &lhs, const tptr<T> &rhs)
             if (tr) c->ensure_transpose();
             auto out = impl::new_out({ls[0], rs[1]}, req);
             detail::gx(gnnx_spmm_csr_f32(c->n, c->n, (int32_t)rs[1], (const int32_t *)(tr ? c->rowptr_t : c->rowptr),
-                                         (const int32_t *)(tr ? c->colidx_t : c->colidx), nullptr, nullptr, nullptr, nullptr,
-                                         rhs->device_data(), (int64_t)rs[1], 0.0f, out->device_out(), (int64_t)rs[1], nullptr, st),
+                                         (const int32_t *)(tr ? c->colidx_t : c->colidx), (const float *)(tr ? c->vals_t : c->vals),
+                                         nullptr, nullptr, nullptr, rhs->device_data(), (int64_t)rs[1], 0.0f, out->device_out(),
+                                         (int64_t)rs[1], nullptr, st),
                        "matmul");
             return out;
         }

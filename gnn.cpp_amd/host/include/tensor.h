@@ -119,6 +119,12 @@ struct Csr {
     void *rowptr = nullptr, *colidx = nullptr;      // A
     void *rowptr_t = nullptr, *colidx_t = nullptr;  // A^T (lazy)
     void *coo_src = nullptr, *coo_dst = nullptr;    // device copies of the edge list
+    // weighted adjacency (edge_attr): per-edge weights of the list, per-entry values of A / A^T (last duplicate wins)
+    void *coo_w = nullptr, *vals = nullptr, *vals_t = nullptr;
+    int diag_mode = GNNX_DIAG_KEEP;                 // fill_diagonal_(0) -> STRIP, fill_diagonal_(v) -> FILL with diag_value
+    float diag_value = 0.0f;
+    bool weighted() const { return coo_w != nullptr; }
+    void make_weighted();                           // attach unit weights (fill_diagonal_(v != 0) on a 0/1 adjacency)
     int64_t n_edges = 0;
     uint32_t flags = GNNX_CSR_KEEP_SELF_LOOPS;       // edge_to_adj_mat keeps the diagonal; fill_diagonal_(0) strips it
     // load-balancing plans of the SpMM (power-law rows), built on demand for a feature width
@@ -501,9 +507,14 @@ public:
     {
         if (rank() != 2 || _dims[0] != _dims[1]) throw std::runtime_error("all dimensions must be of same length and tensor must be 2D");
         if (_csr) {
-            // only the two values the path uses: 0 strips self loops (graph.cpp:72); anything else is off-path
-            if ((float)value != 0.0f) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
-            _csr->flags &= ~GNNX_CSR_KEEP_SELF_LOOPS;
+            if ((float)value == 0.0f) {  // 0 strips self loops (graph.cpp:72): a zero entry adds nothing to any product
+                _csr->flags &= ~GNNX_CSR_KEEP_SELF_LOOPS;
+                _csr->diag_mode = GNNX_DIAG_STRIP;
+            } else {                     // every (i, i) becomes `value`, whether the list had that self loop or not
+                _csr->make_weighted();
+                _csr->diag_mode = GNNX_DIAG_FILL;
+                _csr->diag_value = (float)value;
+            }
             _csr->build();
             return;
         }

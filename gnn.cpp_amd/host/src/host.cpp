@@ -88,7 +88,7 @@ void dev_free(void *ptr, size_t bytes)
 Csr::~Csr()
 {
     drop_plans();
-    for (void *p : {rowptr, colidx, rowptr_t, colidx_t, coo_src, coo_dst, norm_per_nz_t})
+    for (void *p : {rowptr, colidx, rowptr_t, colidx_t, coo_src, coo_dst, norm_per_nz_t, coo_w, vals, vals_t})
         if (p) gnnx_free(p);
 }
 
@@ -125,9 +125,38 @@ static void build_one(const void *src, const void *dst, int64_t n_edges, int32_t
                          workspace(wsb), wsb, current_stream()), "csr");
 }
 
+// weighted: A[r][c] = w, last duplicate wins; capacity n_edges (+ n for a filled diagonal)
+static void build_one_weighted(const void *src, const void *dst, const void *w, int64_t n_edges, int32_t n, uint32_t flags, int diag_mode,
+                               float diag_value, void **rowptr, void **colidx, void **vals, int64_t *nnz)
+{
+    for (void **p : {rowptr, colidx, vals}) {
+        if (*p) gnnx_free(*p);
+        *p = nullptr;
+    }
+    const size_t cap = (size_t)std::max<int64_t>(n_edges + n, 1);
+    gx(gnnx_malloc(rowptr, sizeof(int32_t) * ((size_t)n + 1)), "csr");
+    gx(gnnx_malloc(colidx, sizeof(int32_t) * cap), "csr");
+    gx(gnnx_malloc(vals, sizeof(float) * cap), "csr");
+    size_t wsb = 0;
+    gx(gnnx_csr_from_coo_weighted_workspace(n_edges, n, &wsb), "csr");
+    gx(gnnx_csr_from_coo_weighted((const int32_t *)src, (const int32_t *)dst, (const float *)w, n_edges, n,
+                                  flags & ~GNNX_CSR_KEEP_SELF_LOOPS, diag_mode, diag_value, (int32_t *)*rowptr, (int32_t *)*colidx,
+                                  (float *)*vals, nnz, workspace(wsb), wsb, current_stream()), "csr");
+}
+
+void Csr::make_weighted()
+{
+    if (coo_w) return;
+    gx(gnnx_malloc(&coo_w, sizeof(float) * (size_t)std::max<int64_t>(n_edges, 1)), "csr");
+    gx(gnnx_fill_f32((float *)coo_w, n_edges, 1.0f, current_stream()), "csr");
+}
+
 void Csr::build()
 {
-    build_one(coo_src, coo_dst, n_edges, n, flags, &rowptr, &colidx, &nnz);
+    if (weighted())
+        build_one_weighted(coo_src, coo_dst, coo_w, n_edges, n, flags, diag_mode, diag_value, &rowptr, &colidx, &vals, &nnz);
+    else
+        build_one(coo_src, coo_dst, n_edges, n, flags, &rowptr, &colidx, &nnz);
     nnz_t = -1;  // transpose and plans are stale
     drop_plans();
     if (norm_per_nz_t) gnnx_free(norm_per_nz_t);
@@ -137,7 +166,10 @@ void Csr::build()
 void Csr::ensure_transpose()
 {
     if (nnz_t >= 0) return;
-    build_one(coo_dst, coo_src, n_edges, n, flags, &rowptr_t, &colidx_t, &nnz_t);
+    if (weighted())
+        build_one_weighted(coo_dst, coo_src, coo_w, n_edges, n, flags, diag_mode, diag_value, &rowptr_t, &colidx_t, &vals_t, &nnz_t);
+    else
+        build_one(coo_dst, coo_src, n_edges, n, flags, &rowptr_t, &colidx_t, &nnz_t);
 }
 
 }  // namespace detail
@@ -491,7 +523,6 @@ tptr<float> edge_to_adj_mat(const tensor<int> &edge_index, tensor<float> *edge_a
     if (edge_attr != nullptr) {
         if (e != edge_attr->shape()[0])
             throw std::runtime_error("invalid inputs, number of edges in edge_index must be equal to size of edge_attr");
-        throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);  // weighted adjacency: SURVEY 8(f) rank 4 (kernel supports vals; API row pending)
     }
     size_t n = n_nodes;
     if (n == 0) n = (size_t)std::get<0>(ei.max())->item() + 1;
@@ -503,6 +534,10 @@ tptr<float> edge_to_adj_mat(const tensor<int> &edge_index, tensor<float> *edge_a
     detail::gx(gnnx_malloc(&c->coo_dst, e * sizeof(int32_t)), "adj");
     detail::gx(gnnx_memcpy_d2d(c->coo_src, d, e * sizeof(int32_t), detail::current_stream()), "adj");
     detail::gx(gnnx_memcpy_d2d(c->coo_dst, d + e, e * sizeof(int32_t), detail::current_stream()), "adj");
+    if (edge_attr != nullptr) {  // A[r][c] = w (graph.cpp:38-40)
+        detail::gx(gnnx_malloc(&c->coo_w, e * sizeof(float)), "adj");
+        detail::gx(gnnx_memcpy_d2d(c->coo_w, edge_attr->device_data(), e * sizeof(float), detail::current_stream()), "adj");
+    }
     c->build();
     return std::make_shared<tensor<float>>(c, false);
 }
@@ -514,17 +549,27 @@ std::tuple<tptr<int>, tptr<float>> adj_to_edge_list(tensor<float> &adj_mat)
     auto c = adj_mat.csr();
     const size_t nnz = (size_t)c->nnz;
     std::vector<int32_t> rp((size_t)c->n + 1), ci(std::max<size_t>(nnz, 1));
+    std::vector<float> wv(std::max<size_t>(nnz, 1), 1.0f);
     detail::gx(gnnx_memcpy_d2h(rp.data(), c->rowptr, rp.size() * sizeof(int32_t), detail::current_stream()), "edge list");
     if (nnz) detail::gx(gnnx_memcpy_d2h(ci.data(), c->colidx, nnz * sizeof(int32_t), detail::current_stream()), "edge list");
-    if (nnz == 0) throw std::runtime_error(ERROR_INVALID_DIMS);  // the reference cannot represent an empty [2,0] tensor either
-    auto *v = new std::valarray<int>(2 * nnz);
+    if (nnz && c->vals) detail::gx(gnnx_memcpy_d2h(wv.data(), c->vals, nnz * sizeof(float), detail::current_stream()), "edge list");
+    // the reference keeps the entries with `int(value) != 0` (graph.cpp:54): weights of magnitude below 1 vanish here
+    size_t kept = 0;
+    for (size_t p = 0; p < nnz; p++) kept += (int)wv[p] != 0;
+    if (kept == 0) throw std::runtime_error(ERROR_INVALID_DIMS);  // the reference cannot represent an empty [2,0] tensor either
+    auto *v = new std::valarray<int>(2 * kept);
+    auto *a = new std::valarray<float>(kept);
+    size_t k = 0;
     for (int32_t r = 0; r < c->n; r++)
         for (int32_t p = rp[r]; p < rp[r + 1]; p++) {
-            (*v)[p] = r;
-            (*v)[nnz + p] = ci[p];
+            if ((int)wv[p] == 0) continue;
+            (*v)[k] = r;
+            (*v)[kept + k] = ci[p];
+            (*a)[k] = wv[p];
+            k++;
         }
-    auto edge_index = std::make_shared<tensor<int>>(std::vector<size_t>{2, nnz}, v, false);
-    auto edge_attr = std::make_shared<tensor<float>>(std::vector<size_t>{nnz}, 1.0f, false);
+    auto edge_index = std::make_shared<tensor<int>>(std::vector<size_t>{2, kept}, v, false);
+    auto edge_attr = std::make_shared<tensor<float>>(std::vector<size_t>{kept}, a, false);
     return {edge_index, edge_attr};
 }
 

@@ -119,6 +119,34 @@ class CsrGraph:
         return self.plan, self.plan_t
 
 
+DIAG_KEEP, DIAG_STRIP, DIAG_FILL = 0, 1, 2
+CSR_KEEP_DUPLICATES, CSR_DROP_TRUNCATED_ZERO = 2, 4
+
+
+def csr_from_coo_weighted(src, dst, w, n_nodes, diag_mode=DIAG_KEEP, diag_value=0.0, flags=0):
+    """Weighted adjacency A[r][c] = w, last duplicate wins (edge_attr, reference graph.cpp:21-75) -> (rowptr, colidx, vals)."""
+    E = int(src.numel())
+    dev = src.device
+    cap = max(E + n_nodes, 1)
+    rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    colidx = torch.empty(cap, dtype=torch.int32, device=dev)
+    vals = torch.empty(cap, dtype=torch.float32, device=dev)
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_csr_from_coo_weighted_workspace", E, n_nodes, C.byref(wsb))
+    ws = torch.empty(max(wsb.value, 1), dtype=torch.uint8, device=dev)
+    nnz = C.c_int64(0)
+    capi.call("gnnx_csr_from_coo_weighted", _ptr(src), _ptr(dst), _ptr(w), E, n_nodes, int(flags), int(diag_mode), float(diag_value),
+              _ptr(rowptr), _ptr(colidx), _ptr(vals), C.byref(nnz), _ptr(ws), ws.numel(), _stream())
+    return rowptr, colidx[: nnz.value].clone(), vals[: nnz.value].clone()
+
+
+def csr_rowsum(rowptr, vals=None):
+    n = int(rowptr.numel() - 1)
+    out = torch.empty(n, dtype=torch.float32, device=rowptr.device)
+    capi.call("gnnx_csr_rowsum_f32", _ptr(rowptr), _ptr(vals), n, _ptr(out), _stream())
+    return out
+
+
 def spmm(rowptr, colidx, X, out=None, vals=None, colscale=None, rowscale=None, bias=None, beta=0.0, plan=None,
          n_rows=None, bn=None, relu_in=False, relu_out=False):
     """gnnx_spmm_csr_f32: Y = beta*Y + rowscale (.) (A . (colscale (.) X)) + bias.

@@ -94,6 +94,22 @@ int gnnx_csr_from_coo(const int32_t *d_src, const int32_t *d_dst, int64_t n_edge
                       int32_t *d_rowptr, int32_t *d_colidx, int64_t *nnz_out, void *d_workspace,
                       size_t workspace_bytes, void *stream);
 
+/* Weighted adjacency (edge_attr, reference graph.h:35): A[r][c] = w by assignment, so of duplicate (r, c) pairs the LAST one
+ * in the list wins (edge_to_adj_mat, graph.cpp:38-40).  diag_mode:
+ *   GNNX_DIAG_KEEP   self loops stay as given                         (edge_to_adj_mat alone)
+ *   GNNX_DIAG_STRIP  self loops are removed                           (add_self_loops(..., fillValue 0), graph.cpp:72)
+ *   GNNX_DIAG_FILL   every (i, i) becomes diag_value, given or not    (add_self_loops(..., fillValue v))
+ * flags: GNNX_CSR_KEEP_DUPLICATES as above; GNNX_CSR_DROP_TRUNCATED_ZERO drops entries whose value truncates to the integer
+ * 0 -- adj_to_edge_list's `int(data[i]) != 0` test (graph.cpp:54), through which |w| < 1 vanishes on the
+ * add_self_loops round trip; without it explicit zeros stay as entries (they add +-0 in a product, like the dense matrix).
+ * Output: rowptr[N+1], colidx[nnz], vals[nnz] sorted by (row, column); capacity n_edges (+ n_nodes with GNNX_DIAG_FILL). */
+enum { GNNX_DIAG_KEEP = 0, GNNX_DIAG_STRIP = 1, GNNX_DIAG_FILL = 2 };
+#define GNNX_CSR_DROP_TRUNCATED_ZERO 4u
+int gnnx_csr_from_coo_weighted_workspace(int64_t n_edges, int32_t n_nodes, size_t *bytes);
+int gnnx_csr_from_coo_weighted(const int32_t *d_src, const int32_t *d_dst, const float *d_weights, int64_t n_edges, int32_t n_nodes,
+                               uint32_t flags, int diag_mode, float diag_value, int32_t *d_rowptr, int32_t *d_colidx, float *d_vals,
+                               int64_t *nnz_out, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /*
  * Degree / symmetric-normalisation block of GCNConv::forward (reference graph.cpp:177-185):
  *   deg_i = 1 + sum_j A_ij        (adj_mat->sum(-1,true) + 1;  the "+1" stays although self loops were removed)

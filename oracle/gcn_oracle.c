@@ -82,6 +82,87 @@ API int64_t gcn_oracle_coo_to_csr(const int32_t *src, const int32_t *dst, int64_
     return nnz;
 }
 
+/* Weighted adjacency (edge_attr): graph.cpp:21-44 edge_to_adj_mat writes A[r][c] = w edge by edge, so the LAST duplicate
+ * wins; add_self_loops (graph.cpp:68-75) then overwrites the diagonal with fillValue and adj_to_edge_list (graph.cpp:46-67)
+ * scans row-major keeping entries with int(value) != 0.
+ *   diag_mode 0: diagonal as given; 1: diagonal removed; 2: every (i,i) = diag_value.
+ *   drop_truncated_zero: apply adj_to_edge_list's int() filter (otherwise explicit zeros are kept as entries).
+ * Capacity of colidx / vals: E + N.  Returns nnz or -1 on an out-of-range index. */
+typedef struct { uint64_t key; int64_t pos; } key_pos_t;
+static int cmp_key_pos(const void *a, const void *b)
+{
+    const key_pos_t *x = (const key_pos_t *)a, *y = (const key_pos_t *)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos ? 1 : 0);
+}
+API int64_t gcn_oracle_coo_to_csr_weighted(const int32_t *src, const int32_t *dst, const float *w, int64_t E, int32_t N,
+                                           int diag_mode, float diag_value, int drop_truncated_zero, int64_t *rowptr,
+                                           int32_t *colidx, float *vals)
+{
+    int64_t cap = E + N + 1;
+    key_pos_t *kp = (key_pos_t *)malloc(sizeof(key_pos_t) * (size_t)cap);
+    int64_t m = 0;
+    for (int64_t e = 0; e < E; e++) {
+        int32_t r = src[e], c = dst[e];
+        if (r < 0 || c < 0 || r >= N || c >= N) { free(kp); return -1; }
+        if (r == c && diag_mode != 0) continue;
+        kp[m].key = ((uint64_t)(uint32_t)r << 32) | (uint32_t)c;
+        kp[m].pos = e;
+        m++;
+    }
+    if (diag_mode == 2)
+        for (int32_t i = 0; i < N; i++) {
+            kp[m].key = ((uint64_t)(uint32_t)i << 32) | (uint32_t)i;
+            kp[m].pos = E + i;
+            m++;
+        }
+    qsort(kp, (size_t)m, sizeof(key_pos_t), cmp_key_pos);
+    memset(rowptr, 0, sizeof(int64_t) * ((size_t)N + 1));
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < m; i++) {
+        if (i + 1 < m && kp[i + 1].key == kp[i].key) continue; /* a later assignment overwrites this one */
+        float v = kp[i].pos < E ? w[kp[i].pos] : diag_value;
+        if (drop_truncated_zero && (int)v == 0) continue;
+        colidx[nnz] = (int32_t)(kp[i].key & 0xffffffffu);
+        vals[nnz] = v;
+        nnz++;
+        rowptr[(kp[i].key >> 32) + 1]++;
+    }
+    for (int32_t i = 0; i < N; i++) rowptr[i + 1] += rowptr[i];
+    free(kp);
+    return nnz;
+}
+
+/* adj->mm(x) on a weighted adjacency (functional.h:433-439): out[i][f] = sum over DESCENDING column c of fl(A[i][c] * x[c][f]),
+ * products and sums rounded separately; absent entries contribute +-0. */
+API void gcn_oracle_spmm_vals(const int64_t *rowptr, const int32_t *colidx, const float *vals, int32_t N, int32_t F, const float *X,
+                              float *out)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int32_t i = 0; i < N; i++) {
+        float *o = out + (int64_t)i * F;
+        for (int32_t f = 0; f < F; f++) o[f] = 0.0f;
+        for (int64_t p = rowptr[i + 1] - 1; p >= rowptr[i]; p--) {
+            const float *x = X + (int64_t)colidx[p] * F;
+            const float v = vals[p];
+            for (int32_t f = 0; f < F; f++) {
+                float t = v * x[f];
+                o[f] = o[f] + t;
+            }
+        }
+    }
+}
+
+/* adj->sum(-1) on a weighted adjacency: functional::sum walks UP (valarray::sum), zeros included */
+API void gcn_oracle_rowsum_vals(const int64_t *rowptr, const float *vals, int32_t N, float *out)
+{
+    for (int32_t i = 0; i < N; i++) {
+        float acc = 0.0f;
+        for (int64_t p = rowptr[i]; p < rowptr[i + 1]; p++) acc = acc + vals[p];
+        out[i] = acc;
+    }
+}
+
 /* CSR of A^T (columns ascending inside each row): what MatMul::_backward's dense transpose of A
  * (operation.h:524-527) turns into when A is never materialised. */
 API void gcn_oracle_csr_transpose(const int64_t *rowptr, const int32_t *colidx, int32_t N,

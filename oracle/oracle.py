@@ -15,6 +15,7 @@ _lib = None
 
 __all__ = ["build", "coo_to_csr", "csr_transpose", "degree_norm", "linear_fwd", "aggregate_fwd",
            "aggregate_bwd", "colsum", "linear_bwd", "dense_aggregate", "set_threads", "max_threads",
+           "coo_to_csr_weighted", "spmm_vals", "rowsum_vals",
            "powf_table", "bn_relu_fwd", "cross_entropy", "gcn_layer_fwd", "gcn_layer_bwd", "ref_driver_path"]
 
 
@@ -67,6 +68,44 @@ def coo_to_csr(src, dst, n_nodes):
     if nnz < 0:
         raise RuntimeError("edge index out of range")
     return rowptr, colidx[:nnz].copy()
+
+
+def coo_to_csr_weighted(src, dst, w, n_nodes, diag_mode=0, diag_value=0.0, drop_truncated_zero=False):
+    """(rowptr, colidx, vals) of the weighted adjacency; diag_mode 0 keep / 1 strip / 2 fill (see gcn_oracle.c)."""
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    dst = np.ascontiguousarray(dst, dtype=np.int32)
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    E = src.shape[0]
+    rowptr = np.zeros(n_nodes + 1, dtype=np.int64)
+    colidx = np.zeros(E + n_nodes + 1, dtype=np.int32)
+    vals = np.zeros(E + n_nodes + 1, dtype=np.float32)
+    fn = _L().gcn_oracle_coo_to_csr_weighted
+    fn.restype = C.c_int64
+    nnz = fn(_p(src), _p(dst), _p(w), C.c_int64(E), C.c_int32(n_nodes), C.c_int(diag_mode), C.c_float(diag_value),
+             C.c_int(int(drop_truncated_zero)), _p(rowptr), _p(colidx), _p(vals))
+    if nnz < 0:
+        raise RuntimeError("edge index out of range")
+    return rowptr, colidx[:nnz].copy(), vals[:nnz].copy()
+
+
+def spmm_vals(rowptr, colidx, vals, X):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    colidx = np.ascontiguousarray(colidx, dtype=np.int32)
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    n = rowptr.shape[0] - 1
+    out = np.empty((n, X.shape[1]), dtype=np.float32)
+    _L().gcn_oracle_spmm_vals(_p(rowptr), _p(colidx), _p(vals), C.c_int32(n), C.c_int32(X.shape[1]), _p(X), _p(out))
+    return out
+
+
+def rowsum_vals(rowptr, vals):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    vals = np.ascontiguousarray(vals, dtype=np.float32)
+    n = rowptr.shape[0] - 1
+    out = np.empty(n, dtype=np.float32)
+    _L().gcn_oracle_rowsum_vals(_p(rowptr), _p(vals), C.c_int32(n), _p(out))
+    return out
 
 
 def csr_transpose(rowptr, colidx, n_nodes):

@@ -13,8 +13,10 @@
 // usage: ref_driver <case.bin> <outdir> [flags]
 //   case.bin : int32 N,E,Fin,Fout | int32 src[E] | int32 dst[E] | f32 X[N*Fin] | f32 W[Fout*Fin]
 //              | f32 bias[Fout] | f32 G[N*Fout]
+//              [| f32 w[E]  with the "weighted" flag]
 //   flags    : "full"  also run the whole GCNConv layer (with BatchNorm+ReLU) forward
 //              "nobwd" skip backward
+//              "weighted" also exercise the edge_attr forms of the graph functions (graph.cpp:21-75) on weights w
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -56,10 +58,11 @@ static void dump_va(const string &dir, const string &name, const valarray<T> &v)
 int main(int argc, char **argv)
 {
     if (argc < 3) { fprintf(stderr, "usage: ref_driver case.bin outdir [full] [nobwd]\n"); return 2; }
-    bool full = false, nobwd = false;
+    bool full = false, nobwd = false, weighted = false;
     for (int i = 3; i < argc; i++) {
         if (!strcmp(argv[i], "full")) full = true;
         if (!strcmp(argv[i], "nobwd")) nobwd = true;
+        if (!strcmp(argv[i], "weighted")) weighted = true;
     }
     string outdir = argv[2];
     FILE *f = fopen(argv[1], "rb");
@@ -72,6 +75,8 @@ int main(int argc, char **argv)
     bool ok = fread(src.data(), 4, E, f) == E && fread(dst.data(), 4, E, f) == E &&
               fread(X.data(), 4, X.size(), f) == X.size() && fread(W.data(), 4, W.size(), f) == W.size() &&
               fread(B.data(), 4, B.size(), f) == B.size() && fread(G.data(), 4, G.size(), f) == G.size();
+    vector<float> Wt(weighted ? E : 0);
+    if (ok && weighted) ok = fread(Wt.data(), 4, E, f) == E;
     fclose(f);
     if (!ok) { fprintf(stderr, "short case file\n"); return 2; }
 
@@ -152,6 +157,25 @@ int main(int argc, char **argv)
         auto target = make_shared<tensor<int>>(td, new valarray<int>(tgt.data(), N), false);
         auto loss = nn::cross_entropy_loss(out_full, target);
         dump_va(outdir, "loss.f32", *loss->data());
+    }
+
+    // ---- weighted adjacency: edge_attr through edge_to_adj_mat / sum / mm / add_self_loops   graph.cpp:21-75
+    if (weighted) {
+        vector<size_t> ed = {E};
+        auto ea = make_shared<tensor<float>>(ed, new valarray<float>(Wt.data(), E), false);
+        auto adjw = graph::edge_to_adj_mat(*ei, ea.get(), N);          // A[r][c] = w, last duplicate wins, diagonal kept
+        auto degw = adjw->sum(-1, true);
+        vector<size_t> hd = {N, Fout};
+        auto hc = make_shared<tensor<float>>(hd, new valarray<float>(*H->data()), false);
+        auto mmw = adjw->mm(hc);
+        dump_va(outdir, "w_deg.f32", *degw->data());
+        dump_va(outdir, "w_mm.f32", *mmw->data());
+        auto [ei_f, ea_f] = graph::add_self_loops(*ei, ea.get(), 2.5f, (int)N);  // diagonal := 2.5, then int(w) != 0 filter
+        dump_va(outdir, "w_fill_ei.i32", *ei_f->data());
+        dump_va(outdir, "w_fill_ea.f32", *ea_f->data());
+        auto [ei_z, ea_z] = graph::add_self_loops(*ei, ea.get(), 0.0f, (int)N);  // diagonal := 0 (dropped by the filter)
+        dump_va(outdir, "w_strip_ei.i32", *ei_z->data());
+        dump_va(outdir, "w_strip_ea.f32", *ea_z->data());
     }
 
     printf("{\"N\": %zu, \"E\": %zu, \"nnz\": %zu, \"Fin\": %zu, \"Fout\": %zu, \"t_selfloops\": %.6f, "

@@ -28,16 +28,24 @@ def run_driver(d, unfused=False, no_prologue_fusion=False):
                 np.ascontiguousarray(d[k], dtype=np.int32).tofile(f)
             for k in ("X", "W", "bias", "G"):
                 np.ascontiguousarray(d[k], dtype=np.float32).tofile(f)
+            if "w" in d:
+                np.ascontiguousarray(d["w"], dtype=np.float32).tofile(f)
         env = dict(os.environ)
         if unfused:
             env["GNNCPP_UNFUSED"] = "1"  # op-by-op MatMul/Mul/Add instead of the fused aggregation op
         if no_prologue_fusion:
             env["GNNCPP_NO_PROLOGUE_FUSION"] = "1"  # BatchNorm and ReLU as their own kernels in front of the aggregation
-        r = subprocess.run([DRIVER, cpath, td, "full"], capture_output=True, text=True, timeout=300, env=env)
+        r = subprocess.run([DRIVER, cpath, td, "full"] + (["weighted"] if "w" in d else []), capture_output=True, text=True,
+                           timeout=300, env=env)
         assert r.returncode == 0, r.stdout + r.stderr
         n, fin, fout = d["n"], d["fin"], d["fout"]
         rd = lambda nm, dt: np.fromfile(os.path.join(td, nm), dtype=dt)  # noqa: E731
-        return dict(ei2=rd("ei2.i32", np.int32).reshape(2, -1), s=rd("s.f32", np.float32), norm=rd("norm.f32", np.float32),
+        extra = {}
+        if "w" in d:
+            extra = dict(w_deg=rd("w_deg.f32", np.float32), w_mm=rd("w_mm.f32", np.float32).reshape(n, fout),
+                         w_fill_ei=rd("w_fill_ei.i32", np.int32).reshape(2, -1), w_fill_ea=rd("w_fill_ea.f32", np.float32),
+                         w_strip_ei=rd("w_strip_ei.i32", np.int32).reshape(2, -1), w_strip_ea=rd("w_strip_ea.f32", np.float32))
+        return dict(**extra, ei2=rd("ei2.i32", np.int32).reshape(2, -1), s=rd("s.f32", np.float32), norm=rd("norm.f32", np.float32),
                     H=rd("H.f32", np.float32).reshape(n, fout), agg=rd("agg.f32", np.float32).reshape(n, fout),
                     out=rd("out.f32", np.float32).reshape(n, fout), dX=rd("dX.f32", np.float32).reshape(n, fin),
                     dW=rd("dW.f32", np.float32).reshape(fout, fin), dbias=rd("dbias.f32", np.float32),
@@ -100,3 +108,18 @@ def test_operator_classes_like_the_reference_operation_tests():
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("name", ["weighted6", "weighted_rmat64"])
+def test_edge_attr_forms_of_the_graph_functions(name):
+    """edge_to_adj_mat(ei, edge_attr, N) -> sum(-1) / mm(x), add_self_loops(ei, edge_attr, fill, N): the same driver calls,
+    on the HIP backend, against what the reference returned (last duplicate wins, diagonal fill, int() filter)."""
+    d = load_case(name)
+    got = run_driver(d)
+    assert same(got["w_deg"], d["ref_w_deg"])
+    rp, ci, va = oracle.coo_to_csr_weighted(d["src"], d["dst"], d["w"], d["n"])
+    assert same(got["w_mm"], oracle.spmm_vals(rp, ci, va, got["H"]))   # bit-exact given the H this run's GEMM produced
+    assert_close(got["w_mm"], d["ref_w_mm"], "weighted adj->mm")
+    for key in ("w_fill", "w_strip"):
+        assert np.array_equal(got[key + "_ei"], d["ref_" + key + "_ei"]), key
+        assert same(got[key + "_ea"], d["ref_" + key + "_ea"]), key

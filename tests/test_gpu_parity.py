@@ -776,3 +776,41 @@ def test_fused_prologue_rejects_backward_modes(env):
     H = dev(env, synth.uniform_pm1(711, (100, 8)))
     with pytest.raises(capi.GnnxError):
         ops.spmm(g.rowptr, g.colidx, H, colscale=g.norm, relu_in=True)
+
+
+# ---- weighted adjacency (edge_attr): gnnx_csr_from_coo_weighted + per-entry values in the SpMM ----
+@pytest.mark.parametrize("name", ["weighted6", "weighted_rmat64"])
+def test_weighted_adjacency_vs_reference_golden(env, name):
+    ops = env["ops"]
+    d = load_case(name)
+    n = d["n"]
+    src, dst, w = dev(env, d["src"]), dev(env, d["dst"]), dev(env, d["w"])
+    rp, ci, va = ops.csr_from_coo_weighted(src, dst, w, n)
+    orp, oci, ova = oracle.coo_to_csr_weighted(d["src"], d["dst"], d["w"], n)
+    assert np.array_equal(host(rp), orp) and np.array_equal(host(ci), oci) and same(host(va), ova)
+    assert same(host(ops.csr_rowsum(rp, va)), d["ref_w_deg"])                       # adj->sum(-1)
+    assert same(host(ops.spmm(rp, ci, dev(env, d["ref_H"]), vals=va)), d["ref_w_mm"])  # adj->mm(x), the reference's own bits
+    for mode, fill, key in ((ops.DIAG_FILL, 2.5, "w_fill"), (ops.DIAG_STRIP, 0.0, "w_strip")):
+        rp, ci, va = ops.csr_from_coo_weighted(src, dst, w, n, diag_mode=mode, diag_value=fill, flags=ops.CSR_DROP_TRUNCATED_ZERO)
+        rows = np.repeat(np.arange(n, dtype=np.int32), np.diff(host(rp)))
+        assert np.array_equal(rows, d["ref_" + key + "_ei"][0]) and np.array_equal(host(ci), d["ref_" + key + "_ei"][1]), key
+        assert same(host(va), d["ref_" + key + "_ea"]), key
+
+
+@pytest.mark.parametrize("n,e,F", [(5000, 80000, 64), (20000, 400000, 256), (3000, 20000, 7)])
+def test_weighted_adjacency_vs_oracle_seeded(env, n, e, F):
+    """Bigger seeded graphs with many duplicate edges: the winner of every duplicate run must be the LAST edge of the list."""
+    ops = env["ops"]
+    src, dst = synth.rmat_edges(800 + F, n, e)
+    w = synth.uniform_pm1(801, (e,), scale=3.0)
+    X = synth.uniform_pm1(802, (n, F))
+    for mode, fill, flags in ((ops.DIAG_KEEP, 0.0, 0), (ops.DIAG_FILL, -1.5, ops.CSR_DROP_TRUNCATED_ZERO), (ops.DIAG_STRIP, 0.0, 0)):
+        rp, ci, va = ops.csr_from_coo_weighted(dev(env, src), dev(env, dst), dev(env, w), n, diag_mode=mode, diag_value=fill, flags=flags)
+        orp, oci, ova = oracle.coo_to_csr_weighted(src, dst, w, n, diag_mode=mode, diag_value=fill,
+                                                   drop_truncated_zero=bool(flags & ops.CSR_DROP_TRUNCATED_ZERO))
+        assert np.array_equal(host(rp), orp) and np.array_equal(host(ci), oci) and same(host(va), ova), mode
+        assert same(host(ops.spmm(rp, ci, dev(env, X), vals=va)), oracle.spmm_vals(orp, oci, ova, X)), mode
+    with pytest.raises(env["capi"].GnnxError):
+        bad = src.copy()
+        bad[3] = n
+        ops.csr_from_coo_weighted(dev(env, bad), dev(env, dst), dev(env, w), n)
