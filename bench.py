@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--sym", action="store_true",
                     help="N=1: Mode SYM, the textbook D^-1/2 A D^-1/2 aggregation of the north_star (per-edge scale) instead of the "
                          "reference's factorised norm (Mode REF, the parity-graded default); same kernel, +4 B/edge of traffic")
+    ap.add_argument("--bf16-features", action="store_true",
+                    help="N=1: opt-in bf16 FEATURE STORAGE for the two aggregations (f32 accumulate); halves the gather bytes but "
+                         "rounds features to 8 bits -- outside the 1e-5 parity bar, never the default")
     ap.add_argument("--hip-graph", action="store_true",
                     help="N=1: capture one step (6 kernel launches + their small helpers) into a hipGraph and replay it in the "
                          "timed loop -- for launch-bound sizes such as the Cora-sized config")
@@ -129,6 +132,7 @@ def main():
         runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk)
         runner.workload = args.workload
         runner.sym = args.sym
+        runner.bf16_features = args.bf16_features
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
         runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm)
@@ -206,7 +210,8 @@ def main():
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 else f"1-D vertex shard x{world}, halo all-to-all-v",
-                       "plan_chunk": args.chunk, "hip_graph": graph is not None, "mode": "SYM" if args.sym else "REF"},
+                       "plan_chunk": args.chunk, "hip_graph": graph is not None, "mode": "SYM" if args.sym else "REF",
+                       "feature_storage": "bf16 for the aggregations (opt-in, NOT the parity path)" if args.bf16_features else "f32"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,
@@ -265,6 +270,23 @@ class SingleGpu:
                 fn()
 
         sym = getattr(self, "sym", False)
+        if getattr(self, "bf16_features", False):
+            # opt-in bf16 feature storage: the aggregation gathers 2-byte features (not the parity path)
+            if not hasattr(self, "Hb"):
+                self.Hb = torch.empty(self.H.shape, dtype=torch.bfloat16, device=self.H.device)
+                self.Gb = torch.empty(self.G.shape, dtype=torch.bfloat16, device=self.G.device)
+                self.names = ["gemm_xwT", "to_bf16_H", "spmm_fwd", "colsum", "to_bf16_G", "spmm_bwd", "gemm_dX", "gemm_dW"]
+            run(lambda: ops.linear_fwd(self.X, self.W, out=self.H))
+            run(lambda: ops.to_bf16(self.H, out=self.Hb))
+            run(lambda: ops.aggregate_fwd(g, self.Hb, self.bias, out=self.out))
+            run(lambda: ops.colsum(self.G, out=self.dbias))
+            run(lambda: ops.to_bf16(self.G, out=self.Gb))
+            run(lambda: ops.aggregate_bwd(g, self.Gb, out=self.dH))
+            run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
+            run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+            if timed:
+                self.ev.append(evs)
+            return
         run(lambda: ops.linear_fwd(self.X, self.W, out=self.H))
         run(lambda: ops.aggregate_fwd_sym(g, self.H, self.bias, out=self.out) if sym else ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
         run(lambda: ops.colsum(self.G, out=self.dbias))
@@ -283,6 +305,8 @@ class SingleGpu:
     def roofline(self):
         ms = self.kernel_times()["spmm_fwd"]
         B = spmm_bytes(self.n, self.n, self.g.nnz, self.F, bias=True)
+        if getattr(self, "bf16_features", False):
+            B -= 2 * self.F * self.g.nnz  # 2-byte features in the gather
         achieved = B / (ms * 1e-3) / 1e9
         tr = profiled_traffic(self.workload, "spmm_stream_kernel<64, 4, 8, 0") if self.F == 256 else None
         return {"bound": "hbm", "kernel": "spmm_stream_kernel<64,4,8,0,64> (forward aggregation)", "achieved": achieved,

@@ -233,6 +233,39 @@ __global__ __launch_bounds__(256) void rowsum_kernel(const float *X, int64_t ldx
     }
 }
 
+
+// f32 -> bf16 (round to nearest even; a plain cast so that hipcc emits v_cvt_pk_bf16_f32, which keeps NaNs NaNs): the opt-in
+// bf16 feature storage in front of gnnx_spmm_csr_bf16_f32.  4 elements per thread.
+__global__ __launch_bounds__(256) void to_bf16_kernel(const float *X, int64_t ldx, int64_t n_rows, int32_t n_cols, uint16_t *Y,
+                                                       int64_t ldy)
+{
+    const int32_t quads = n_cols / 4;
+    const int64_t total = n_rows * quads;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / quads;
+        const int32_t q = (int32_t)(i - r * quads);
+        const float4 v = *reinterpret_cast<const float4 *>(X + r * ldx + 4 * q);
+        union { __bf16 h[4]; uint2 u; } o;
+        o.h[0] = (__bf16)v.x;
+        o.h[1] = (__bf16)v.y;
+        o.h[2] = (__bf16)v.z;
+        o.h[3] = (__bf16)v.w;
+        *reinterpret_cast<uint2 *>(Y + r * ldy + 4 * q) = o.u;
+    }
+}
+__global__ __launch_bounds__(256) void to_bf16_scalar_kernel(const float *X, int64_t ldx, int64_t n_rows, int32_t n_cols, uint16_t *Y,
+                                                              int64_t ldy)
+{
+    const int64_t total = n_rows * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / n_cols;
+        const int32_t c = (int32_t)(i - r * n_cols);
+        union { __bf16 h; uint16_t u; } o;
+        o.h = (__bf16)X[r * ldx + c];
+        Y[r * ldy + c] = o.u;
+    }
+}
+
 // ---- halo pack / unpack: one G-lane group per row, 16 B per lane ---------------------------------------
 template <int VEC, bool SCATTER_ADD>
 __global__ __launch_bounds__(256) void rows_kernel(const float *in, int64_t ldi, const int32_t *idx, int64_t n_idx,
@@ -392,6 +425,21 @@ GNNX_API int gnnx_rowsum_f32(const float *d_X, int64_t ldx, int64_t n_rows, int3
     GNNX_REQUIRE(d_X && d_out && ldx >= n_cols, GNNX_ERR_INVALID_ARG, "null pointer or ldx < n_cols");
     hipLaunchKernelGGL(rowsum_kernel, dim3((uint32_t)ceil_div(n_rows, 4)), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_cols,
                        d_out);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_f32_to_bf16(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_cols, uint16_t *d_Y, int64_t ldy, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0 || n_cols == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_X && d_Y && ldx >= n_cols && ldy >= n_cols, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_cols");
+    const bool vec = n_cols % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(d_X) & 15u) == 0 &&
+                     (reinterpret_cast<uintptr_t>(d_Y) & 7u) == 0;
+    int64_t blocks = ceil_div(vec ? n_rows * (n_cols / 4) : n_rows * n_cols, 256);
+    if (blocks > 16384) blocks = 16384;
+    if (vec) hipLaunchKernelGGL(to_bf16_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_cols, d_Y, ldy);
+    else hipLaunchKernelGGL(to_bf16_scalar_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_cols, d_Y, ldy);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }

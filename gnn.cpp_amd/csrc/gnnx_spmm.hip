@@ -72,6 +72,7 @@ struct SpmmArgs {
     int32_t n_blocks;
     // fusion (gnnx_spmm_csr_fused_f32): ReLU on the stored row; BatchNorm / ReLU applied to every gathered row of X
     int32_t relu_out;
+    int32_t x_bf16;          // X holds bf16 (gnnx_spmm_csr_bf16_f32)
     const float *pro_mean, *pro_var, *pro_gamma, *pro_beta;
     float pro_eps;
 };
@@ -82,6 +83,24 @@ template <> struct Vec<1> { using type = float; };
 
 __device__ __forceinline__ float4 ld_vec(const float4 *p) { return *p; }
 __device__ __forceinline__ float ld_vec(const float *p) { return *p; }
+
+// A neighbour row's slice for this lane: VEC features stored as f32, or as bf16 (opt-in feature storage, half the gather
+// bytes; widened exactly -- a bf16 is the top half of an f32 -- and accumulated in f32 like the f32 rows).
+typedef uint16_t bf16_t;
+template <int VEC> __device__ __forceinline__ typename Vec<VEC>::type ld_x(const float *p)
+{
+    return ld_vec(reinterpret_cast<const typename Vec<VEC>::type *>(p));
+}
+template <int VEC> __device__ __forceinline__ typename Vec<VEC>::type ld_x(const bf16_t *p)
+{
+    if constexpr (VEC == 4) {
+        const uint2 h = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(__uint_as_float(h.x << 16), __uint_as_float(h.x & 0xffff0000u), __uint_as_float(h.y << 16),
+                           __uint_as_float(h.y & 0xffff0000u));
+    } else {
+        return __uint_as_float((uint32_t)*p << 16);
+    }
+}
 
 // Separately rounded ops: hipcc contracts a*b+c into an fma by default; the reference rounds the product
 // and the sum separately (x86-64 baseline, no FMA), so spell the roundings out.
@@ -172,9 +191,9 @@ __device__ __forceinline__ int32_t bcast(int32_t v, int src, int gbase)
 // One batch of B neighbour rows: all B loads are issued before the first add (B rows in flight per group),
 // adds strictly in order k, k+1, ... (= descending column).  No load is predicated: hipcc turns a
 // conditional load into branch + s_waitcnt vmcnt(0) per element, which serialises the gather.
-template <int G, int VEC, int B, int MODE>
+template <int G, int VEC, int B, int MODE, class XT>
 __device__ __forceinline__ void gather_batch(typename Vec<VEC>::type &acc, int k, int32_t myc, float mysc, float myval,
-                                             int gbase, const float *xf, const SpmmArgs &a, const ProConst<VEC> &pc)
+                                             int gbase, const XT *xf, const SpmmArgs &a, const ProConst<VEC> &pc)
 {
     using V = typename Vec<VEC>::type;
     int32_t c[B];
@@ -182,7 +201,7 @@ __device__ __forceinline__ void gather_batch(typename Vec<VEC>::type &acc, int k
 #pragma unroll
     for (int u = 0; u < B; u++) c[u] = bcast<G>(myc, k + u, gbase);
 #pragma unroll
-    for (int u = 0; u < B; u++) v[u] = ld_vec(reinterpret_cast<const V *>(xf + (int64_t)c[u] * a.ldx));
+    for (int u = 0; u < B; u++) v[u] = ld_x<VEC>(xf + (int64_t)c[u] * a.ldx);
 #pragma unroll
     for (int u = 0; u < B; u++) {
         V t = v[u];
@@ -197,8 +216,8 @@ __device__ __forceinline__ void gather_batch(typename Vec<VEC>::type &acc, int k
 // starting from 0 is the same thing except for the sign of a zero).
 // Indices are fetched G at a time with ONE coalesced vector load per group (lane li takes the li-th
 // neighbour from the top), together with their colscale / vals, then handed out by bcast().
-template <int G, int VEC, int U, int MODE>
-__device__ __forceinline__ typename Vec<VEC>::type gather_range(int32_t b, int32_t e, const float *xf, int li,
+template <int G, int VEC, int U, int MODE, class XT>
+__device__ __forceinline__ typename Vec<VEC>::type gather_range(int32_t b, int32_t e, const XT *xf, int li,
                                                                 const SpmmArgs &a, const ProConst<VEC> &pc)
 {
     using V = typename Vec<VEC>::type;
@@ -256,7 +275,7 @@ __device__ __forceinline__ void epilogue_store_pre(typename Vec<VEC>::type acc, 
 }
 
 // grid.x = n_item_blocks + n_row_blocks ; grid.y = feature tiles of G*VEC features.
-template <int G, int VEC, int U, int MODE>
+template <int G, int VEC, int U, int MODE, class XT>
 __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_blocks)
 {
     constexpr int GROUPS = 256 / G;
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_bl
     if constexpr (G == 64) grp = __builtin_amdgcn_readfirstlane(grp);
     const int32_t f0 = (blockIdx.y * G + li) * VEC;
     const bool active = f0 + VEC <= a.n_feat;
-    const float *xf = a.X + (active ? f0 : 0);  // lanes past n_feat read feature 0 and never store
+    const XT *xf = reinterpret_cast<const XT *>(a.X) + (active ? f0 : 0);  // lanes past n_feat read feature 0 and never store
     const ProConst<VEC> pc = pro_load<VEC, MODE>(a, f0, active);
 
     if ((int32_t)blockIdx.x < n_item_blocks) {
@@ -313,11 +332,11 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_bl
 // stream independent blocks under the EXEC mask.
 template <int G> struct StreamCfg { static constexpr int R = G / 2; };
 
-template <int G, int VEC, int B, int MODE>
+template <int G, int VEC, int B, int MODE, class XT>
 struct Stream {
     using V = typename Vec<VEC>::type;
     const SpmmArgs &a;
-    const float *xf;
+    const XT *xf;
     int li, gbase, f0;
     bool active;
     int32_t r0;      // first row of the block
@@ -361,7 +380,7 @@ struct Stream {
 #pragma unroll
         for (int u = 0; u < B; u++) c[u] = bcast<G>(ch.c, k0 + u, gbase);
 #pragma unroll
-        for (int u = 0; u < B; u++) b.v[u] = ld_vec(reinterpret_cast<const V *>(xf + (int64_t)c[u] * a.ldx));
+        for (int u = 0; u < B; u++) b.v[u] = ld_x<VEC>(xf + (int64_t)c[u] * a.ldx);
         if constexpr (MODE == 1 || MODE == 2) {
 #pragma unroll
             for (int u = 0; u < B; u++) b.sc[u] = __int_as_float(bcast<G>(__float_as_int(ch.sc), k0 + u, gbase));
@@ -436,7 +455,7 @@ struct Stream {
     }
 };
 
-template <int G, int VEC, int B, int MODE, int TPB>
+template <int G, int VEC, int B, int MODE, int TPB, class XT>
 __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_item_blocks)
 {
     constexpr int GROUPS = TPB / G;
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     if constexpr (G == 64) grp = __builtin_amdgcn_readfirstlane(grp);
     const int32_t f0 = (blockIdx.y * G + li) * VEC;
     const bool active = f0 + VEC <= a.n_feat;
-    const float *xf = a.X + (active ? f0 : 0);
+    const XT *xf = reinterpret_cast<const XT *>(a.X) + (active ? f0 : 0);
     const ProConst<VEC> pc = pro_load<VEC, MODE>(a, f0, active);
 
     if ((int32_t)blockIdx.x < n_item_blocks) {  // chunk item of a hub row -> partial slab (same as spmm_kernel)
@@ -485,7 +504,7 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     zero(bias_v);
     if (a.bias && active) bias_v = ld_vec(reinterpret_cast<const typename Vec<VEC>::type *>(a.bias + f0));
     const float rs_l = a.rowscale ? a.rowscale[r0 + (li < nr ? li : nr - 1)] : 1.f;
-    Stream<G, VEC, B, MODE> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)], rs_l, bias_v, pc};
+    Stream<G, VEC, B, MODE, XT> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)], rs_l, bias_v, pc};
 
     uint64_t hub = 0;  // bit l: local row l is a hub (left to the chunk items)
     if (a.split_threshold > 0) {
@@ -726,14 +745,22 @@ __global__ void plan_block_fill_kernel(const int32_t *flag, const int32_t *pos, 
 template <int G, int VEC, int U, int TPB>
 void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32_t n_item_blocks)
 {
-#define GNNX_STREAM(M) hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, M, TPB>), grid, dim3(TPB), 0, st, a, n_item_blocks)
+#define GNNX_STREAM(M, XT) hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, M, TPB, XT>), grid, dim3(TPB), 0, st, a, n_item_blocks)
+    if (a.x_bf16) {  // bf16 feature rows: the three plain modes (a prologue goes with f32 rows)
+        switch (mode) {
+        case 0: GNNX_STREAM(0, bf16_t); break;
+        case 1: GNNX_STREAM(1, bf16_t); break;
+        default: GNNX_STREAM(2, bf16_t); break;
+        }
+        return;
+    }
     switch (mode) {
-    case 0: GNNX_STREAM(0); break;
-    case 1: GNNX_STREAM(1); break;
-    case 2: GNNX_STREAM(2); break;
-    case 3: GNNX_STREAM(3); break;
-    case 4: GNNX_STREAM(4); break;
-    default: GNNX_STREAM(5); break;
+    case 0: GNNX_STREAM(0, float); break;
+    case 1: GNNX_STREAM(1, float); break;
+    case 2: GNNX_STREAM(2, float); break;
+    case 3: GNNX_STREAM(3, float); break;
+    case 4: GNNX_STREAM(4, float); break;
+    default: GNNX_STREAM(5, float); break;
     }
 #undef GNNX_STREAM
 }
@@ -741,14 +768,22 @@ void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32
 template <int G, int VEC, int U>
 void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32_t n_item_blocks)
 {
-#define GNNX_ROWS(M) hipLaunchKernelGGL((spmm_kernel<G, VEC, U, M>), grid, dim3(256), 0, st, a, n_item_blocks)
+#define GNNX_ROWS(M, XT) hipLaunchKernelGGL((spmm_kernel<G, VEC, U, M, XT>), grid, dim3(256), 0, st, a, n_item_blocks)
+    if (a.x_bf16) {
+        switch (mode) {
+        case 0: GNNX_ROWS(0, bf16_t); break;
+        case 1: GNNX_ROWS(1, bf16_t); break;
+        default: GNNX_ROWS(2, bf16_t); break;
+        }
+        return;
+    }
     switch (mode) {
-    case 0: GNNX_ROWS(0); break;
-    case 1: GNNX_ROWS(1); break;
-    case 2: GNNX_ROWS(2); break;
-    case 3: GNNX_ROWS(3); break;
-    case 4: GNNX_ROWS(4); break;
-    default: GNNX_ROWS(5); break;
+    case 0: GNNX_ROWS(0, float); break;
+    case 1: GNNX_ROWS(1, float); break;
+    case 2: GNNX_ROWS(2, float); break;
+    case 3: GNNX_ROWS(3, float); break;
+    case 4: GNNX_ROWS(4, float); break;
+    default: GNNX_ROWS(5, float); break;
     }
 #undef GNNX_ROWS
 }
@@ -768,7 +803,7 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     bool stream = false;
     if constexpr (G >= 8) stream = use_stream_kernel(G);
     if constexpr (G == 64 && VEC == 4) {
-        if (use_lds_variant() && a.n_feat == 256 && mode == 0 && !a.relu_out) {  // measurement variant, forward mode only
+        if (use_lds_variant() && a.n_feat == 256 && mode == 0 && !a.relu_out && !a.x_bf16) {  // measurement variant, forward mode only
             grid.x = (uint32_t)(a.n_items + (a.block_starts ? a.n_blocks : ceil_div(a.n_rows, StreamCfg<64>::R)));
             grid.y = 1;
             hipLaunchKernelGGL((spmm_lds_kernel<16>), grid, dim3(64), 0, st, a, (int32_t)a.n_items);
@@ -896,7 +931,7 @@ GNNX_API int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_split_ro
 namespace {
 int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr, const int32_t *d_colidx, const float *d_vals,
               const float *d_colscale, const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx, float beta,
-              float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan, void *stream)
+              float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan, void *stream, bool x_bf16 = false)
 {
     GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
     if (n_rows == 0 || n_feat == 0) return GNNX_OK;
@@ -904,6 +939,7 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
     GNNX_REQUIRE(ldx >= n_feat && ldy >= n_feat, GNNX_ERR_SHAPE, "leading dimension smaller than n_feat");
     GNNX_REQUIRE(beta == 0.f || beta == 1.f, GNNX_ERR_UNSUPPORTED, "beta must be 0 or 1");
     GNNX_REQUIRE(d_X != d_Y, GNNX_ERR_INVALID_ARG, "X and Y alias");
+    GNNX_REQUIRE(!x_bf16 || !fusion, GNNX_ERR_UNSUPPORTED, "bf16 feature rows take no fusion");
     if (plan) {
         GNNX_REQUIRE(plan->n_rows == n_rows, GNNX_ERR_SHAPE, "plan was built for %d rows, got %d", plan->n_rows, n_rows);
         GNNX_REQUIRE(plan->n_split_rows == 0 || n_feat <= plan->max_feat, GNNX_ERR_SHAPE,
@@ -924,6 +960,7 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         a.pro_beta = fusion->bn_beta;
         a.pro_eps = fusion->bn_eps;
     }
+    a.x_bf16 = x_bf16;
     a.n_rows = n_rows;
     a.n_feat = n_feat;
     a.rowptr = d_rowptr;
@@ -950,7 +987,7 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
     }
     hipStream_t st = as_stream(stream);
     auto aligned16 = [](const void *p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
-    const bool vec4 = (n_feat % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(d_X) && aligned16(d_Y) &&
+    const bool vec4 = (n_feat % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (x_bf16 ? (reinterpret_cast<uintptr_t>(d_X) & 7u) == 0 : aligned16(d_X)) && aligned16(d_Y) &&
                       aligned16(d_bias) && aligned16(a.pro_mean) && aligned16(a.pro_var) && aligned16(a.pro_gamma) &&
                       aligned16(a.pro_beta);
     if (vec4) {
@@ -986,4 +1023,13 @@ GNNX_API int gnnx_spmm_csr_fused_f32(int32_t n_rows, int32_t n_cols, int32_t n_f
 {
     return spmm_impl(n_rows, n_cols, n_feat, d_rowptr, d_colidx, d_vals, d_colscale, d_rowscale, d_bias, d_X, ldx, beta, d_Y, ldy,
                      fusion, plan, stream);
+}
+
+GNNX_API int gnnx_spmm_csr_bf16_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
+                                    const int32_t *d_colidx, const float *d_vals, const float *d_colscale,
+                                    const float *d_rowscale, const float *d_bias, const uint16_t *d_X_bf16, int64_t ldx, float beta,
+                                    float *d_Y, int64_t ldy, const gnnx_spmm_plan *plan, void *stream)
+{
+    return spmm_impl(n_rows, n_cols, n_feat, d_rowptr, d_colidx, d_vals, d_colscale, d_rowscale, d_bias,
+                     reinterpret_cast<const float *>(d_X_bf16), ldx, beta, d_Y, ldy, nullptr, plan, stream, true);
 }

@@ -119,6 +119,13 @@ class CsrGraph:
         return self.plan, self.plan_t
 
 
+def to_bf16(X, out=None):
+    """f32 -> bf16 feature storage (torch.bfloat16 tensor, same shape) for spmm(..., X bf16)."""
+    out = torch.empty(X.shape, dtype=torch.bfloat16, device=X.device) if out is None else out
+    capi.call("gnnx_f32_to_bf16", _ptr(X), _ld(X), X.shape[0], X.shape[1], _ptr(out), _ld(out), _stream())
+    return out
+
+
 DIAG_KEEP, DIAG_STRIP, DIAG_FILL = 0, 1, 2
 CSR_KEEP_DUPLICATES, CSR_DROP_TRUNCATED_ZERO = 2, 4
 
@@ -156,6 +163,11 @@ def spmm(rowptr, colidx, X, out=None, vals=None, colscale=None, rowscale=None, b
     n_cols, F = X.shape
     if out is None:
         out = torch.empty((n_rows, F), dtype=torch.float32, device=X.device)
+    if X.dtype == torch.bfloat16:  # opt-in bf16 feature storage: half the gather bytes, f32 accumulation
+        capi.call("gnnx_spmm_csr_bf16_f32", n_rows, n_cols, F, _ptr(rowptr), _ptr(colidx), _ptr(vals), _ptr(colscale),
+                  _ptr(rowscale), _ptr(bias), _ptr(X), _ld(X), float(beta), _ptr(out), _ld(out),
+                  plan.h if plan is not None else None, _stream())
+        return out
     if bn is not None or relu_in or relu_out:
         mean, var, gamma, bbeta, eps = bn if bn is not None else (None, None, None, None, 0.0)
         addr = lambda t: None if t is None else _ptr(t).value  # noqa: E731

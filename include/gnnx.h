@@ -176,6 +176,17 @@ int gnnx_spmm_csr_fused_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, cons
                             float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan,
                             void *stream);
 
+/* Opt-in bf16 FEATURE STORAGE: the same SpMM gathering rows of X stored as bf16 -- 2 bytes per
+ * feature instead of 4, i.e. about half the algorithmic bytes of the aggregation -- widened exactly to f32 in registers and
+ * accumulated in f32 in the same order.  NOT the parity path: rounding X to bf16 (gnnx_f32_to_bf16, round to nearest even)
+ * costs up to 2^-8 relative per element, far outside the 1e-5 bar; if X is exactly representable in bf16 the result is the f32
+ * path's, bit for bit.  No fusion with this entry.  ldx in bf16 elements. */
+int gnnx_f32_to_bf16(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_cols, uint16_t *d_Y_bf16, int64_t ldy, void *stream);
+int gnnx_spmm_csr_bf16_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr, const int32_t *d_colidx,
+                           const float *d_vals, const float *d_colscale, const float *d_rowscale, const float *d_bias,
+                           const uint16_t *d_X_bf16, int64_t ldx, float beta, float *d_Y, int64_t ldy,
+                           const gnnx_spmm_plan *plan, void *stream);
+
 /* ------------------------------------------------------------------ hot path: transform ---------- */
 /*
  * fp32 GEMM on the MFMA units (v_mfma_f32_32x32x2_f32, exact f32) -- replaces functional::matmul for the

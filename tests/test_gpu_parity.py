@@ -814,3 +814,33 @@ def test_weighted_adjacency_vs_oracle_seeded(env, n, e, F):
         bad = src.copy()
         bad[3] = n
         ops.csr_from_coo_weighted(dev(env, bad), dev(env, dst), dev(env, w), n)
+
+
+# ---- opt-in bf16 feature storage (gnnx_f32_to_bf16 + gnnx_spmm_csr_bf16_f32) -- not the parity path
+@pytest.mark.parametrize("n,e,F,chunk", [(4000, 60000, 256, 0), (4000, 60000, 256, 64), (3000, 30000, 100, 0), (2000, 20000, 7, 0)])
+def test_bf16_feature_storage(env, n, e, F, chunk):
+    ops, torch = env["ops"], env["torch"]
+    src, dst = synth.rmat_edges(850 + F, n, e)
+    g = ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), n)
+    if chunk:
+        g.make_plans(chunk, F)
+    X = synth.uniform_pm1(851, (n, F))
+    X[0, :3] = [np.nan, np.inf, -np.inf]
+    Xd = dev(env, X)
+    Xb = ops.to_bf16(Xd)
+    # the conversion is round-to-nearest-even and keeps NaN / Inf: same bits as torch's own cast
+    assert torch.equal(Xb.view(torch.int16), Xd.to(torch.bfloat16).view(torch.int16))
+    X[0, :3] = 0
+    Xd = dev(env, X)
+    Xb = ops.to_bf16(Xd)
+    bias = dev(env, synth.uniform_pm1(852, (F,), scale=0.5))
+    # (1) widening is exact: on features that ARE bf16 numbers the bf16 path is the f32 path, bit for bit (fwd and bwd modes)
+    Xr = Xb.float().contiguous()
+    assert same(host(ops.aggregate_fwd(g, Xb, bias)), host(ops.aggregate_fwd(g, Xr, bias)))
+    assert same(host(ops.aggregate_bwd(g, Xb)), host(ops.aggregate_bwd(g, Xr)))
+    # (2) against the f32 features: one bf16 rounding (at most 2^-8 relative) per gathered element, nothing else
+    full = host(ops.aggregate_fwd(g, Xd, bias)).astype(np.float64)
+    got = host(ops.aggregate_fwd(g, Xb, bias)).astype(np.float64)
+    rp, ci = oracle.coo_to_csr(src, dst, n)
+    absum = oracle.aggregate_fwd(rp, ci, np.abs(X), host(g.norm), None).astype(np.float64)  # norm_i * sum_j |x_j|
+    assert np.all(np.abs(got - full) <= 2.0 ** -8 * absum * 1.001 + 1e-6)
