@@ -29,7 +29,8 @@ def short(name):
 
 
 def one(pattern):
-    f = glob.glob(pattern)
+    # rocprofv3 nests its output one directory deep (<dir>/<host>/<pid>_*.csv) unless -o names the files
+    f = glob.glob(pattern) or glob.glob(pattern.replace(os.sep + "*" + os.sep, os.sep, 1))
     if not f:
         sys.exit(f"no file matches {pattern}")
     return f[0]
