@@ -96,7 +96,9 @@ def main():
     ap.add_argument("--native-comm", action="store_true",
                     help="N>1: halo all-to-all-v and all-reduce through the C-ABI (gnnx_halo_exchange_f32) instead of torch.distributed")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank (rehearsal)")
-    ap.add_argument("--cpu-sample-nodes", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-nodes", type=int, default=2_500_000,
+                    help="nodes of the bounded CPU-baseline sample (same generator and average degree): about 12 s on all host "
+                         "threads + about 10 s for the single-thread leg on a tenth of it")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
