@@ -243,6 +243,125 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmArgs g)
         }
 }
 
+// ---- streaming variant for tall products (X.W^T, dH.W on millions of rows) -------------------------------------------
+// A 10M x 256 x 256 product is 39k output tiles of only K / BK = 8 K-tiles each: with one output tile per workgroup the
+// exposed first loads and the C store cost ~10 % (ablation build).  Here a RESIDENT workgroup walks the
+// M-tiles blockIdx.y, + gridDim.y, ... of its column and the K-tile stream runs ACROSS them: while the last K-tile of output
+// tile t is multiplied, the first K-tile of the next one is already on its way HBM -> registers -> LDS, and the C store of
+// tile t (fire-and-forget) drains under the MFMAs of tile t + 1.  Only whole tiles: M-tiles inside [0, m_tiles), K % BK == 0,
+// N % BN == 0, 16-byte aligned operands, beta == 0 (the host sends the ragged remainder to gemm_kernel).  Addresses are a
+// wave-uniform 64-bit base + a per-lane 32-bit offset fixed for the whole launch, so the walk costs no vector registers.
+template <class C, bool B_KC>
+__global__ __launch_bounds__(C::NT) void gemm_stream_kernel(GemmArgs g, int64_t m_tiles)
+{
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NT = C::NT, TM = C::TM, TN = C::TN, LDA = C::LDA, LDB = C::LDB;
+    extern __shared__ float lds_raw[];  // [2][BK*LDA] A tiles, then [2][BK*LDB] B tiles
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int64_t n0 = (int64_t)blockIdx.x * BN;
+
+    // per-lane element offsets of this thread's float4 slots inside an operand tile (A is K-contiguous: [BM rows][BK k])
+    uint32_t offa[C::A_VECS], offb[C::B_VECS];
+#pragma unroll
+    for (int i = 0; i < C::A_VECS; i++) {
+        const int idx = tid + i * NT;
+        offa[i] = (uint32_t)((idx / (BK / 4)) * g.lda + (idx % (BK / 4)) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < C::B_VECS; i++) {
+        const int idx = tid + i * NT;
+        if constexpr (B_KC) offb[i] = (uint32_t)((idx / (BK / 4)) * g.ldb + (idx % (BK / 4)) * 4);  // [BN rows][BK k]
+        else offb[i] = (uint32_t)((idx / (BN / 4)) * g.ldb + (idx % (BN / 4)) * 4);               // [BK k][BN cols]
+    }
+    const float *bcol = g.B + (B_KC ? n0 * g.ldb : n0);
+    const int64_t bstep = B_KC ? 1 : g.ldb;  // elements per unit of k
+    const uint32_t offc = (uint32_t)((wm * (BM / C::WM) + 4 * (lane >> 5)) * g.ldc + wn * (BN / C::WN) + (lane & 31));
+
+    float ra[C::A_VECS * 4], rb[C::B_VECS * 4];
+    auto load = [&](int64_t mt, int64_t k0) {
+        const float *abase = g.A + mt * BM * g.lda + k0;
+        const float *bbase = bcol + k0 * bstep;
+#pragma unroll
+        for (int i = 0; i < C::A_VECS; i++) {
+            const float4 v = *reinterpret_cast<const float4 *>(abase + offa[i]);
+            ra[4 * i + 0] = v.x; ra[4 * i + 1] = v.y; ra[4 * i + 2] = v.z; ra[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < C::B_VECS; i++) {
+            const float4 v = *reinterpret_cast<const float4 *>(bbase + offb[i]);
+            rb[4 * i + 0] = v.x; rb[4 * i + 1] = v.y; rb[4 * i + 2] = v.z; rb[4 * i + 3] = v.w;
+        }
+    };
+    auto stash = [&](int b) {  // registers -> LDS buffer b (whole tiles: no masks)
+        store_tile_impl<true, false, BM, BK, NT, C::A_VECS, LDA>(lds_raw + b * BK * LDA, ra, tid, 0, 0, 0, 0);
+        store_tile_impl<B_KC, false, BN, BK, NT, C::B_VECS, LDB>(lds_raw + 2 * BK * LDA + b * BK * LDB, rb, tid, 0, 0, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+    constexpr int STORE_AT = (BK * 3 / 4) & ~1;
+    int buf = 0;
+    int64_t mt = blockIdx.y;
+    if (mt < m_tiles) {
+        load(mt, 0);
+        stash(0);
+    }
+    __syncthreads();
+    for (; mt < m_tiles; mt += gridDim.y) {
+        const int64_t mt_next = mt + gridDim.y;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+        for (int64_t k0 = 0; k0 < g.K; k0 += BK) {
+            const bool last_k = k0 + BK >= g.K;
+            const bool more = !last_k || mt_next < m_tiles;
+            if (more) load(last_k ? mt_next : mt, last_k ? 0 : k0 + BK);  // in flight during the MFMAs below
+            const float *As = lds_raw + buf * BK * LDA + wm * (BM / C::WM) + (lane & 31) + (lane >> 5) * LDA;
+            const float *Bs = lds_raw + 2 * BK * LDA + buf * BK * LDB + wn * (BN / C::WN) + (lane & 31) + (lane >> 5) * LDB;
+            float a[2][TM], b[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) a[0][i] = As[32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; j++) b[0][j] = Bs[32 * j];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+                if (kk + 2 < BK) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++) a[nxt][i] = As[(kk + 2) * LDA + 32 * i];
+#pragma unroll
+                    for (int j = 0; j < TN; j++) b[nxt][j] = Bs[(kk + 2) * LDB + 32 * j];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk == STORE_AT && more) {
+                    stash(buf ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+        // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+        float *cbase = g.C + mt * BM * g.ldc + n0;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    (cbase + (int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * g.ldc + j * 32)[offc] = g.alpha * acc[i][j][r];
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *slab, int splits, int64_t M, int64_t N, float alpha,
                                                             float beta, float *C, int64_t ldc)
 {
@@ -382,6 +501,50 @@ int launch(const GemmArgs &g, int splits, bool va, bool vb, hipStream_t st)
     }
 }
 
+
+template <class C, bool B_KC>
+int launch_stream_cfg(const GemmArgs &g, int64_t m_tiles, int64_t gy, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(float) * 2 * C::BK * (C::LDA + C::LDB);
+    static bool attr_set = false;
+    if (!attr_set) {
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_stream_kernel<C, B_KC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((uint32_t)(g.N / C::BN), (uint32_t)gy, 1);
+    hipLaunchKernelGGL((gemm_stream_kernel<C, B_KC>), grid, dim3(C::NT), lds, st, g, m_tiles);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+// *rows_done = number of leading rows of C written by the streaming kernel (0: shape not eligible).
+int launch_stream(const GemmArgs &g, bool b_kc, int waves_per_slot, hipStream_t st, int64_t *rows_done)
+{
+    *rows_done = 0;
+    const int tile = pick_tile(g.M, g.N);
+    if (tile != kTall32 && tile != kSquare) return GNNX_OK;
+    // measured at 10M rows (scripts/exp_gemm.py, same box, GNNX_GEMM_STREAM=0/1): dH.W 256-wide 10.69 -> 10.22 ms, 128-wide
+    // 3.28 -> 3.15 ms; X.W^T 128-wide 3.29 -> 3.17 ms; X.W^T 256-wide 10.51 -> 10.65 ms (no gain: stays on the generic kernel)
+    if (b_kc && tile == kTall32 && waves_per_slot < 3) return GNNX_OK;
+    const TileDims t = tile_dims(g.M, g.N);
+    if (g.K % t.bk != 0 || g.N % t.bn != 0) return GNNX_OK;
+    const int64_t m_tiles = g.M / t.bm, cols = g.N / t.bn;
+    const int64_t slots = (int64_t)kNumCU * (tile == kTall32 ? 1 : 2);
+    if (m_tiles * cols < 4 * slots) return GNNX_OK;  // too few tiles for residency to matter
+    // per-lane 32-bit offsets must cover one operand / output tile
+    if ((int64_t)t.bm * g.lda >= (1ll << 30) || (int64_t)(b_kc ? t.bn : t.bk) * g.ldb >= (1ll << 30) || (int64_t)t.bm * g.ldc >= (1ll << 30))
+        return GNNX_OK;
+    int64_t gy = ceil_div(slots * waves_per_slot, cols);
+    if (gy > m_tiles) gy = m_tiles;
+    int rc;
+    if (tile == kTall32) rc = b_kc ? launch_stream_cfg<CfgTall32, true>(g, m_tiles, gy, st) : launch_stream_cfg<CfgTall32, false>(g, m_tiles, gy, st);
+    else rc = b_kc ? launch_stream_cfg<CfgDefault, true>(g, m_tiles, gy, st) : launch_stream_cfg<CfgDefault, false>(g, m_tiles, gy, st);
+    if (rc != GNNX_OK) return rc;
+    *rows_done = m_tiles * t.bm;
+    return GNNX_OK;
+}
+
 }  // namespace
 
 GNNX_API int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_sink, double *flops_out, void *stream)
@@ -434,6 +597,17 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
         GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu",
                      workspace_bytes, need);
         g.slab = static_cast<float *>(d_workspace);
+    }
+    // tall products with whole tiles: the resident streaming kernel takes the whole M-tiles, the generic kernel the rest
+    static const int stream_env = [] { const char *e = getenv("GNNX_GEMM_STREAM"); return e ? atoi(e) : 1; }();
+    if (stream_env > 0 && a_kc && splits == 1 && beta == 0.f && va && vb && K > 0) {
+        int64_t rows = 0;  // leading rows of C written by the streaming kernel
+        const int src = launch_stream(g, b_kc, stream_env, st, &rows);
+        if (src != GNNX_OK) return src;
+        if (rows == M) return GNNX_OK;
+        g.A += rows * lda;
+        g.C += rows * ldc;
+        g.M = M - rows;
     }
     int rc;
     if (a_kc && b_kc) rc = launch<true, true>(g, splits, va, vb, st);

@@ -844,3 +844,31 @@ def test_bf16_feature_storage(env, n, e, F, chunk):
     rp, ci = oracle.coo_to_csr(src, dst, n)
     absum = oracle.aggregate_fwd(rp, ci, np.abs(X), host(g.norm), None).astype(np.float64)  # norm_i * sum_j |x_j|
     assert np.all(np.abs(got - full) <= 2.0 ** -8 * absum * 1.001 + 1e-6)
+
+
+# ---- the resident streaming GEMM kernel (tall products with whole tiles; the ragged remainder goes to the generic kernel) --
+@pytest.mark.parametrize("M,N,K", [(300077, 256, 256), (2 * 131072 + 1, 128, 128), (262144 + 255, 256, 64), (600000, 512, 32)])
+def test_gemm_streaming_kernel_tall_products(env, M, N, K):
+    """X.W^T and dH.W on hundreds of thousands of rows take gemm_stream_kernel for the whole 256-row (128-row) tiles and
+    gemm_kernel for the rest: every row -- first tile, tile seams, the ragged tail -- against float64, and bit-identical to
+    the same rows computed as a SHORT product (which takes the generic kernel only): both are the same fmaf chain over k."""
+    ops, torch = env["ops"], env["torch"]
+    X = ops.uniform_pm1(950, (M, K), device=env["dev"])
+    W = ops.uniform_pm1(951, (N, K), scale=K ** -0.5, device=env["dev"])     # [N, K]  (X.W^T: NT)
+    Wn = W.t().contiguous()                                                  # [K, N]  (dH.W form: NN)
+    H = ops.gemm(X, W, transB=True)
+    H2 = ops.gemm(X, Wn)
+    rows = np.unique(np.concatenate([np.arange(0, 600), np.arange(M - 700, M), np.random.default_rng(1).integers(0, M, 3000),
+                                     np.arange(255 * 1000 - 5, 255 * 1000 + 300)]))
+    rows = rows[(rows >= 0) & (rows < M)]
+    ridx = torch.from_numpy(rows).to(env["dev"])
+    ref = X[ridx].double() @ W.double().t()
+    for got in (H, H2):
+        err = (got[ridx].double() - ref).abs().max().item()
+        assert err <= 1e-5 * max(1.0, ref.abs().max().item()), err
+    # same bits as the generic kernel on a short slice (rows [s, s+1000) straddle tile seams)
+    for s in (0, 255 * 1000, M - 1000):
+        short = ops.gemm(X[s:s + 1000].contiguous(), W, transB=True)
+        assert torch.equal(short, H[s:s + 1000])
+        short2 = ops.gemm(X[s:s + 1000].contiguous(), Wn)
+        assert torch.equal(short2, H2[s:s + 1000])
