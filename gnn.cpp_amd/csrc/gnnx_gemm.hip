@@ -44,7 +44,12 @@ struct Cfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
     static constexpr int NT = 64 * WM * WN;                     // threads
     static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;  // MFMA tiles per wavefront
-    static constexpr int LDA = BM + 2, LDB = BN + 2;  // LDS row strides (words): 4*LD % 32 == 8 => <= 2-way write conflicts
+    // LDS row strides (words).  A K-contiguous operand is transposed on the way in (b32 writes): stride % 32 == 2 keeps those
+    // at <= 2-way conflicts.  A k-major operand goes in as it is: stride % 4 == 0 makes its 4 consecutive words one 16-byte
+    // ds_write_b128.  Fragment reads are 32 consecutive words per half-wave either way.
+    static constexpr int ld_a(bool kc) { return kc ? BM + 2 : BM + 4; }
+    static constexpr int ld_b(bool kc) { return kc ? BN + 2 : BN + 4; }
+    static constexpr size_t lds_bytes(bool a_kc, bool b_kc) { return sizeof(float) * 2 * BK * (ld_a(a_kc) + ld_b(b_kc)); }
     static constexpr int A_VECS = BM * BK / 4 / NT;   // float4 per thread per tile
     static constexpr int B_VECS = BN * BK / 4 / NT;
     static_assert(A_VECS >= 1 && B_VECS >= 1, "tile too small for the thread count");
@@ -115,11 +120,17 @@ __device__ __forceinline__ void store_tile_impl(float *lds, const float (&reg)[N
             }
         } else {
             const int k = idx / (ROWS / 4), r = (idx % (ROWS / 4)) * 4;
+            float v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                float v = reg[4 * i + j];
-                if constexpr (MASK) v = (k0 + k < kmax && r0 + r + j < rmax) ? v : 0.f;
-                lds[k * LD + r + j] = v;
+                v[j] = reg[4 * i + j];
+                if constexpr (MASK) v[j] = (k0 + k < kmax && r0 + r + j < rmax) ? v[j] : 0.f;
+            }
+            if constexpr (LD % 4 == 0) {  // one ds_write_b128
+                *reinterpret_cast<float4 *>(lds + k * LD + r) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) lds[k * LD + r + j] = v[j];
             }
         }
     }
@@ -136,8 +147,9 @@ __device__ __forceinline__ void store_tile(float *lds, const float (&reg)[NV * 4
 template <class C, bool A_KC, bool B_KC, bool VEC_A, bool VEC_B>
 __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmArgs g)
 {
-    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NT = C::NT, TM = C::TM, TN = C::TN, LDA = C::LDA, LDB = C::LDB;
-    extern __shared__ float lds_raw[];  // [2][BK*LDA] A tiles, then [2][BK*LDB] B tiles
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NT = C::NT, TM = C::TM, TN = C::TN;
+    constexpr int LDA = C::ld_a(A_KC), LDB = C::ld_b(B_KC);
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][BK*LDA] A tiles, then [2][BK*LDB] B tiles
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
@@ -254,8 +266,9 @@ __global__ __launch_bounds__(C::NT) void gemm_kernel(GemmArgs g)
 template <class C, bool B_KC>
 __global__ __launch_bounds__(C::NT) void gemm_stream_kernel(GemmArgs g, int64_t m_tiles)
 {
-    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NT = C::NT, TM = C::TM, TN = C::TN, LDA = C::LDA, LDB = C::LDB;
-    extern __shared__ float lds_raw[];  // [2][BK*LDA] A tiles, then [2][BK*LDB] B tiles
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NT = C::NT, TM = C::TM, TN = C::TN;
+    constexpr int LDA = C::ld_a(true), LDB = C::ld_b(B_KC);
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][BK*LDA] A tiles, then [2][BK*LDB] B tiles
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN;
@@ -467,7 +480,7 @@ template <class C, bool A_KC, bool B_KC, bool VA, bool VB>
 int launch_one(const GemmArgs &g, int splits, hipStream_t st)
 {
     dim3 grid((uint32_t)ceil_div(g.N, C::BN), (uint32_t)ceil_div(g.M, C::BM), (uint32_t)splits);
-    constexpr size_t lds = sizeof(float) * 2 * C::BK * (C::LDA + C::LDB);
+    constexpr size_t lds = C::lds_bytes(A_KC, B_KC);
     static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in, once per kernel instantiation
     if (!attr_set) {
         GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<C, A_KC, B_KC, VA, VB>),
@@ -505,7 +518,7 @@ int launch(const GemmArgs &g, int splits, bool va, bool vb, hipStream_t st)
 template <class C, bool B_KC>
 int launch_stream_cfg(const GemmArgs &g, int64_t m_tiles, int64_t gy, hipStream_t st)
 {
-    constexpr size_t lds = sizeof(float) * 2 * C::BK * (C::LDA + C::LDB);
+    constexpr size_t lds = C::lds_bytes(true, B_KC);
     static bool attr_set = false;
     if (!attr_set) {
         GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_stream_kernel<C, B_KC>),
