@@ -110,6 +110,8 @@ struct Store {
         host_ok = true;
         dev_ok = false;
     }
+    // never written since it was created: logically all zeros (zero_grad() allocates nothing)
+    bool untouched() const { return !host_ok && !dev_ok; }
 };
 
 // CSR adjacency living on the device (+ the COO it came from, so that A^T can be built on demand).
@@ -290,7 +292,7 @@ public:
     // backend-side constructors
     struct device_tag {};
     // op results: never leaves, so no gradient buffer is attached (backward() only accumulates into leaves)
-    tensor(device_tag, std::vector<size_t> dims, bool requires_grad) : _dims(dims), _requires_grad(requires_grad)
+    tensor(device_tag, std::vector<size_t> dims, bool requires_grad) : _dims(dims), _requires_grad(requires_grad), _backend_temp(true)
     {
         CHECK_VALID_DIMS(dims);
         _st = std::make_shared<detail::Store<T>>(numel_of(dims));
@@ -394,10 +396,30 @@ public:
         if (incoming_gradient == nullptr && numel() != 1) throw std::runtime_error(ERROR_NON_SCALAR_BACKPROP);
         if (incoming_gradient == nullptr) incoming_gradient = std::make_shared<tensor<float>>(_dims, 1.0f, false);
         if (incoming_gradient->numel() != numel()) throw std::runtime_error(ERROR_GRAD_MISMATCH);
-        if (_grad && !grad_fn)  // `_grad += G`; only leaves keep it (a non-leaf's grad() is refused anyway)
-            detail::gx(gnnx_axpy_f32((int64_t)numel(), 1.0f, incoming_gradient->device_data(), _grad->d(),
-                                     detail::current_stream()), "grad accumulate");
-        if (_grad && !grad_fn) _grad->host_ok = false;
+        if (_grad && !grad_fn) {  // `_grad += G`; only leaves keep it (a non-leaf's grad() is refused anyway)
+            if (_grad->untouched()) {
+                // first gradient into a zeroed buffer: 0 + G is G.  A temporary made by a backend op that nobody else holds
+                // (the calling op's local + this parameter) simply BECOMES the gradient buffer -- no memset, no N x F
+                // read-modify-write; anything else is copied once.
+                if constexpr (std::is_same_v<T, float>) {
+                    auto &g = *incoming_gradient;
+                    if (g._backend_temp && !g._tview && !g._csr && incoming_gradient.use_count() <= 2 && g._st.use_count() == 1 &&
+                        g._st->n == numel() && g._st->dev_ok) {
+                        _grad = g._st;
+                    } else {
+                        detail::gx(gnnx_memcpy_d2d(_grad->d_out(), g.device_data(), numel() * sizeof(float), detail::current_stream()),
+                                   "grad accumulate");
+                    }
+                } else {
+                    detail::gx(gnnx_memcpy_d2d(_grad->d_out(), incoming_gradient->device_data(), numel() * sizeof(float),
+                                               detail::current_stream()), "grad accumulate");
+                }
+            } else {
+                detail::gx(gnnx_axpy_f32((int64_t)numel(), 1.0f, incoming_gradient->device_data(), _grad->d(),
+                                         detail::current_stream()), "grad accumulate");
+            }
+            _grad->host_ok = false;
+        }
         if (grad_fn) grad_fn->backward(incoming_gradient);
     }
 
@@ -611,6 +633,7 @@ private:
     bool _requires_grad = false;
     bool _tview = false;
     bool _csr_t = false;
+    bool _backend_temp = false;  // created by a backend op (device_tag): its storage may be adopted as a leaf's gradient
     std::shared_ptr<detail::Store<T>> _st;
     std::shared_ptr<detail::Store<float>> _grad;
     std::shared_ptr<detail::Csr> _csr;

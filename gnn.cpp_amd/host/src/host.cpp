@@ -654,8 +654,7 @@ public:
         const int32_t f = (int32_t)shp[1];
         void *st = cyg::detail::current_stream();
         if (has_bias && bias->requires_grad()) {
-            auto db = g->clone(false);
-            db->sum_to_size(bias->shape());
+            auto db = cyg::functional::sum(g, 0, bias->rank() == 2);  // dbias = column sums of G, straight from G (no N x F clone)
             bias->backward(db);
         }
         if (x->requires_grad()) {
@@ -727,8 +726,7 @@ public:
         const int32_t f = (int32_t)shp[1];
         void *st = cyg::detail::current_stream();
         if (bias->requires_grad()) {
-            auto db = g->clone(false);
-            db->sum_to_size(bias->shape());
+            auto db = cyg::functional::sum(g, 0, bias->rank() == 2);  // dbias = column sums of G, straight from G (no N x F clone)
             bias->backward(db);
         }
         if (!(h->requires_grad() || gamma->requires_grad() || (has_beta && beta->requires_grad()))) return;

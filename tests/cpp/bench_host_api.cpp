@@ -63,9 +63,17 @@ int main(int argc, char **argv)
     gnnx_device_sync();
     double t_first = now_s() - t0;
 
+    for (int s = 0; s < 3; s++) {  // warm-up: clocks, allocator pool, plans (the first call above idles the GPU behind uploads)
+        layer.zero_grad();
+        x->zero_grad();
+        auto o = layer(data);
+        o->backward(g);
+    }
+    gnnx_device_sync();
     t0 = now_s();
     for (int s = 0; s < steps; s++) {
         layer.zero_grad();
+        x->zero_grad();  // the input's gradient too, like the parameters': every step starts from zeroed grads
         auto o = layer(data);
         o->backward(g);
     }
