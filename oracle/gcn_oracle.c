@@ -316,22 +316,42 @@ API void gcn_oracle_linear_bwd(const float *dH, const float *X, const float *W, 
         }
     }
     if (dW) {
-#pragma omp parallel for schedule(static)
-        for (int32_t o = 0; o < Fout; o++) {
-            float *d = dW + (int64_t)o * Fin;
-            if (N == 0) {
-                for (int32_t k = 0; k < Fin; k++) d[k] = 0.0f;
-                continue;
+        /* dW[o][k] = sum_{i DESCENDING} fl(X[i][k] * dH[i][o]).  Every output element keeps that order; the loop nest is
+         * blocked (OB outputs x KB inputs per task, i innermost over the block) so that X is streamed Fout/OB times instead
+         * of Fout times and the accumulators stay in L1 -- same bits, a host baseline that is not bound by re-reading X. */
+        enum { OB = 8, KB = 64 };
+        const int32_t n_ob = (Fout + OB - 1) / OB, n_kb = (Fin + KB - 1) / KB;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+        for (int32_t ob = 0; ob < n_ob; ob++)
+            for (int32_t kb = 0; kb < n_kb; kb++) {
+                const int32_t o0 = ob * OB, o1 = o0 + OB < Fout ? o0 + OB : Fout;
+                const int32_t k0 = kb * KB, k1 = k0 + KB < Fin ? k0 + KB : Fin;
+                float acc[OB][KB];
+                if (N == 0) {
+                    for (int32_t o = o0; o < o1; o++)
+                        for (int32_t k = k0; k < k1; k++) dW[(int64_t)o * Fin + k] = 0.0f;
+                    continue;
+                }
+                {
+                    const float *x = X + (N - 1) * Fin;
+                    const float *g = dH + (N - 1) * Fout;
+                    for (int32_t o = o0; o < o1; o++) {
+                        const float gv = g[o];
+                        for (int32_t k = k0; k < k1; k++) acc[o - o0][k - k0] = x[k] * gv;
+                    }
+                }
+                for (int64_t i = N - 2; i >= 0; i--) {
+                    const float *x = X + i * Fin;
+                    const float *g = dH + i * Fout;
+                    for (int32_t o = o0; o < o1; o++) {
+                        const float gv = g[o];
+                        float *a = acc[o - o0];
+                        for (int32_t k = k0; k < k1; k++) a[k - k0] += x[k] * gv;
+                    }
+                }
+                for (int32_t o = o0; o < o1; o++)
+                    for (int32_t k = k0; k < k1; k++) dW[(int64_t)o * Fin + k] = acc[o - o0][k - k0];
             }
-            float gv = dH[(N - 1) * Fout + o];
-            const float *x = X + (N - 1) * Fin;
-            for (int32_t k = 0; k < Fin; k++) d[k] = x[k] * gv;
-            for (int64_t i = N - 2; i >= 0; i--) {
-                gv = dH[i * Fout + o];
-                x = X + i * Fin;
-                for (int32_t k = 0; k < Fin; k++) d[k] += x[k] * gv;
-            }
-        }
     }
 }
 
