@@ -196,6 +196,74 @@ API void gcn_oracle_degree_norm(const int64_t *rowptr, const int32_t *colidx, in
     }
 }
 
+/* Hot inner loops, compiled for several x86 vector widths and picked at load time (GCC function multi-versioning): the
+ * arithmetic per element is the same one rounded multiply and one rounded add at any width (-ffp-contract=off: no FMA),
+ * so the result does not depend on which clone runs; the host baseline just should not be an SSE2-only number. */
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#define CLONES __attribute__((target_clones("avx512f", "avx2", "default"), noinline))
+#else
+#define CLONES __attribute__((noinline))
+#endif
+
+/* h[0..n) = sum over k DESCENDING of fl(x[k] * Wt[k][0..n))  (one output row of a GEMM, reference order per element) */
+CLONES static void row_times_matrix(const float *x, const float *Wt, int32_t K, int32_t n, float *h)
+{
+    enum { S = 64 };  /* outputs per strip: the strip's accumulators live in vector registers across the whole k loop */
+    int32_t o0 = 0;
+    for (; o0 + S <= n; o0 += S) {
+        float acc[S];
+        const float *w = Wt + (int64_t)(K - 1) * n + o0;
+        float xv = x[K - 1];
+        for (int32_t o = 0; o < S; o++) acc[o] = xv * w[o];
+        for (int32_t k = K - 2; k >= 0; k--) {
+            w = Wt + (int64_t)k * n + o0;
+            xv = x[k];
+            for (int32_t o = 0; o < S; o++) acc[o] += xv * w[o];
+        }
+        for (int32_t o = 0; o < S; o++) h[o0 + o] = acc[o];
+    }
+    if (o0 < n) {  /* ragged tail, same order */
+        const int32_t m = n - o0;
+        const float *w = Wt + (int64_t)(K - 1) * n + o0;
+        float xv = x[K - 1];
+        for (int32_t o = 0; o < m; o++) h[o0 + o] = xv * w[o];
+        for (int32_t k = K - 2; k >= 0; k--) {
+            w = Wt + (int64_t)k * n + o0;
+            xv = x[k];
+            for (int32_t o = 0; o < m; o++) h[o0 + o] += xv * w[o];
+        }
+    }
+}
+
+/* dW[o0..o1)[k0..k1) = sum over i DESCENDING of fl(X[i][k] * dH[i][o]); accumulators of the block stay in L1 */
+enum { DW_OB = 8, DW_KB = 64 };
+CLONES static void dw_block(const float *X, const float *dH, int64_t N, int32_t Fin, int32_t Fout, int32_t o0, int32_t o1, int32_t k0,
+                            int32_t k1, float *dW)
+{
+    float acc[DW_OB][DW_KB];
+    const int32_t kn = k1 - k0;
+    {
+        const float *x = X + (N - 1) * Fin + k0;
+        const float *g = dH + (N - 1) * Fout;
+        for (int32_t o = o0; o < o1; o++) {
+            const float gv = g[o];
+            float *a = acc[o - o0];
+            for (int32_t k = 0; k < kn; k++) a[k] = x[k] * gv;
+        }
+    }
+    for (int64_t i = N - 2; i >= 0; i--) {
+        const float *x = X + i * Fin + k0;
+        const float *g = dH + i * Fout;
+        for (int32_t o = o0; o < o1; o++) {
+            const float gv = g[o];
+            float *a = acc[o - o0];
+            for (int32_t k = 0; k < kn; k++) a[k] += x[k] * gv;
+        }
+    }
+    for (int32_t o = o0; o < o1; o++)
+        for (int32_t k = 0; k < kn; k++) dW[(int64_t)o * Fin + k0 + k] = acc[o - o0][k];
+}
+
 /* nn.cpp:205-211 via functional.h:433-439:  H[i,o] = sum_{k desc} fl(X[i,k] * W[o,k]).
  * Loop nest: k outermost-descending per row with W pre-transposed, so the inner loop runs over o contiguously
  * (vectorisable) while every output element still sees its products in the reference's order. */
@@ -212,14 +280,7 @@ API void gcn_oracle_linear_fwd(const float *X, const float *W, int64_t N, int32_
             for (int32_t o = 0; o < Fout; o++) h[o] = 0.0f;
             continue;
         }
-        const float *w = Wt + (int64_t)(Fin - 1) * Fout;
-        float xv = x[Fin - 1];
-        for (int32_t o = 0; o < Fout; o++) h[o] = xv * w[o];
-        for (int32_t k = Fin - 2; k >= 0; k--) {
-            w = Wt + (int64_t)k * Fout;
-            xv = x[k];
-            for (int32_t o = 0; o < Fout; o++) h[o] += xv * w[o];
-        }
+        row_times_matrix(x, Wt, Fin, Fout, h);
     }
     free(Wt);
 }
@@ -305,52 +366,25 @@ API void gcn_oracle_linear_bwd(const float *dH, const float *X, const float *W, 
                 for (int32_t k = 0; k < Fin; k++) d[k] = 0.0f;
                 continue;
             }
-            const float *w = W + (int64_t)(Fout - 1) * Fin;
-            float gv = g[Fout - 1];
-            for (int32_t k = 0; k < Fin; k++) d[k] = gv * w[k];
-            for (int32_t o = Fout - 2; o >= 0; o--) {
-                w = W + (int64_t)o * Fin;
-                gv = g[o];
-                for (int32_t k = 0; k < Fin; k++) d[k] += gv * w[k];
-            }
+            row_times_matrix(g, W, Fout, Fin, d);  /* dX[i][k] = sum_{o desc} fl(dH[i][o] * W[o][k]) */
         }
     }
     if (dW) {
         /* dW[o][k] = sum_{i DESCENDING} fl(X[i][k] * dH[i][o]).  Every output element keeps that order; the loop nest is
          * blocked (OB outputs x KB inputs per task, i innermost over the block) so that X is streamed Fout/OB times instead
          * of Fout times and the accumulators stay in L1 -- same bits, a host baseline that is not bound by re-reading X. */
-        enum { OB = 8, KB = 64 };
-        const int32_t n_ob = (Fout + OB - 1) / OB, n_kb = (Fin + KB - 1) / KB;
+        const int32_t n_ob = (Fout + DW_OB - 1) / DW_OB, n_kb = (Fin + DW_KB - 1) / DW_KB;
 #pragma omp parallel for schedule(dynamic, 1) collapse(2)
         for (int32_t ob = 0; ob < n_ob; ob++)
             for (int32_t kb = 0; kb < n_kb; kb++) {
-                const int32_t o0 = ob * OB, o1 = o0 + OB < Fout ? o0 + OB : Fout;
-                const int32_t k0 = kb * KB, k1 = k0 + KB < Fin ? k0 + KB : Fin;
-                float acc[OB][KB];
+                const int32_t o0 = ob * DW_OB, o1 = o0 + DW_OB < Fout ? o0 + DW_OB : Fout;
+                const int32_t k0 = kb * DW_KB, k1 = k0 + DW_KB < Fin ? k0 + DW_KB : Fin;
                 if (N == 0) {
                     for (int32_t o = o0; o < o1; o++)
                         for (int32_t k = k0; k < k1; k++) dW[(int64_t)o * Fin + k] = 0.0f;
                     continue;
                 }
-                {
-                    const float *x = X + (N - 1) * Fin;
-                    const float *g = dH + (N - 1) * Fout;
-                    for (int32_t o = o0; o < o1; o++) {
-                        const float gv = g[o];
-                        for (int32_t k = k0; k < k1; k++) acc[o - o0][k - k0] = x[k] * gv;
-                    }
-                }
-                for (int64_t i = N - 2; i >= 0; i--) {
-                    const float *x = X + i * Fin;
-                    const float *g = dH + i * Fout;
-                    for (int32_t o = o0; o < o1; o++) {
-                        const float gv = g[o];
-                        float *a = acc[o - o0];
-                        for (int32_t k = k0; k < k1; k++) a[k - k0] += x[k] * gv;
-                    }
-                }
-                for (int32_t o = o0; o < o1; o++)
-                    for (int32_t k = k0; k < k1; k++) dW[(int64_t)o * Fin + k] = acc[o - o0][k - k0];
+                dw_block(X, dH, N, Fin, Fout, o0, o1, k0, k1, dW);
             }
     }
 }
