@@ -872,3 +872,42 @@ def test_gemm_streaming_kernel_tall_products(env, M, N, K):
         assert torch.equal(short, H[s:s + 1000])
         short2 = ops.gemm(X[s:s + 1000].contiguous(), Wn)
         assert torch.equal(short2, H2[s:s + 1000])
+
+
+def test_leading_dimensions_wider_than_the_matrices(env):
+    """Every hot entry point takes leading dimensions: operands that are column slices of wider buffers (ld > width) must give
+    the same bits as packed copies -- streaming GEMM + its ragged tail, fused / bf16 / plain SpMM."""
+    ops, torch = env["ops"], env["torch"]
+    dev_ = env["dev"]
+    M, K, N = 300077, 128, 256
+    Xw = ops.uniform_pm1(970, (M, K + 64), device=dev_)
+    X = Xw[:, 32:32 + K]                                  # lda = K + 64, 16-byte aligned start
+    W = ops.uniform_pm1(971, (N, K), scale=K ** -0.5, device=dev_)
+    Cw = torch.zeros((M, N + 128), dtype=torch.float32, device=dev_)
+    Cv = Cw[:, 64:64 + N]
+    ops.gemm(X, W, transB=True, out=Cv)
+    ref = ops.gemm(X.contiguous(), W, transB=True)
+    assert torch.equal(Cv, ref)
+    assert float(Cw[:, :64].abs().max()) == 0.0 and float(Cw[:, 64 + N:].abs().max()) == 0.0   # nothing written outside the view
+    ops.gemm(X, W.t().contiguous(), out=Cv)               # the k-major-B form
+    assert torch.equal(Cv, ref)
+    # aggregation reading a column slice and writing a column slice
+    n, e, F = 6000, 90000, 128
+    src, dst = synth.rmat_edges(972, n, e)
+    g = ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), n)
+    g.make_plans(64, F)
+    Hw = ops.uniform_pm1(973, (n, F + 32), device=dev_)
+    H = Hw[:, 16:16 + F]
+    Hc = H.contiguous()
+    bias = ops.uniform_pm1(974, (F,), scale=0.5, device=dev_)
+    Ow = torch.full((n, F + 64), 7.0, dtype=torch.float32, device=dev_)
+    Ov = Ow[:, 32:32 + F]
+    mean, var = ops.bn_stats(Hc)
+    for kw in ({}, {"relu_out": True}, {"bn": (mean, var, None, None, 1e-5), "relu_in": True}):
+        ops.aggregate_fwd(g, H, bias, out=Ov, **kw)
+        assert torch.equal(Ov, ops.aggregate_fwd(g, Hc, bias, **kw)), kw
+        assert float((Ow[:, :32] - 7.0).abs().max()) == 0.0 and float((Ow[:, 32 + F:] - 7.0).abs().max()) == 0.0
+    Hb = torch.zeros((n, F + 32), dtype=torch.bfloat16, device=dev_)
+    ops.to_bf16(H, out=Hb[:, 8:8 + F])
+    assert torch.equal(ops.aggregate_fwd(g, Hb[:, 8:8 + F], bias), ops.aggregate_fwd(g, ops.to_bf16(Hc), bias))
+    assert torch.equal(ops.aggregate_bwd(g, H), ops.aggregate_bwd(g, Hc))
