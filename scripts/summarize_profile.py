@@ -60,7 +60,7 @@ def main():
         fetch, write = counters(sys.argv[3], "FETCH_SIZE"), counters(sys.argv[4], "WRITE_SIZE")
         res = {}
         for k in sorted(set(fetch) | set(write)):
-            if not re.search(r"spmm|gemm_kernel|colsum_stage1|splitk|rows_kernel", k):
+            if not re.search(r"spmm|gemm_kernel|gemm_stream_kernel|colsum_stage1|splitk|rows_kernel", k):
                 continue
             fb, wb = fetch.get(k, 0.0), write.get(k, 0.0)
             res[k] = {"fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb}
