@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--bf16-features", action="store_true",
                     help="N=1: opt-in bf16 FEATURE STORAGE for the two aggregations (f32 accumulate); halves the gather bytes but "
                          "rounds features to 8 bits -- outside the 1e-5 parity bar, never the default")
+    ap.add_argument("--split-gemm", action="store_true",
+                    help="N=1: OPT-IN split-precision GEMM for X.W^T and dH.W (bf16 matrix cores, exact 3-way operand split, f32 "
+                         "accumulation: f32-level accuracy but not the reference's arithmetic) -- never the default")
     ap.add_argument("--hip-graph", action="store_true",
                     help="N=1: capture one step (6 kernel launches + their small helpers) into a hipGraph and replay it in the "
                          "timed loop -- for launch-bound sizes such as the Cora-sized config")
@@ -135,6 +138,7 @@ def main():
         runner.workload = args.workload
         runner.sym = args.sym
         runner.bf16_features = args.bf16_features
+        runner.split_gemm = args.split_gemm
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
         runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm)
@@ -213,7 +217,8 @@ def main():
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 else f"1-D vertex shard x{world}, halo all-to-all-v",
                        "plan_chunk": args.chunk, "hip_graph": graph is not None, "mode": "SYM" if args.sym else "REF",
-                       "feature_storage": "bf16 for the aggregations (opt-in, NOT the parity path)" if args.bf16_features else "f32"},
+                       "feature_storage": "bf16 for the aggregations (opt-in, NOT the parity path)" if args.bf16_features else "f32",
+                       "gemm": "split-bf16 x6 for X.W^T and dH.W (opt-in, NOT the parity path)" if args.split_gemm else "f32 MFMA"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,
@@ -289,11 +294,12 @@ class SingleGpu:
             if timed:
                 self.ev.append(evs)
             return
-        run(lambda: ops.linear_fwd(self.X, self.W, out=self.H))
+        split = getattr(self, "split_gemm", False)
+        run(lambda: ops.gemm_split(self.X, self.W, transB=True, out=self.H) if split else ops.linear_fwd(self.X, self.W, out=self.H))
         run(lambda: ops.aggregate_fwd_sym(g, self.H, self.bias, out=self.out) if sym else ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
         run(lambda: ops.colsum(self.G, out=self.dbias))
         run(lambda: ops.aggregate_bwd_sym(g, self.G, out=self.dH) if sym else ops.aggregate_bwd(g, self.G, out=self.dH))
-        run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
+        run(lambda: ops.gemm_split(self.dH, self.W, transB=False, out=self.dX) if split else ops.gemm(self.dH, self.W, out=self.dX))
         run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
         if timed:
             self.ev.append(evs)

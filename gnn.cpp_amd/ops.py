@@ -199,6 +199,20 @@ def gemm(A, B, transA=False, transB=False, out=None, alpha=1.0, beta=0.0):
     return out
 
 
+def gemm_split(A, B, transB=False, out=None):
+    """OPT-IN split-precision GEMM (gnnx_gemm_split_bf16_f32): A[M,K] . op(B) on the bf16 matrix cores from exact 3-way bf16
+    splits of the f32 operands, f32 accumulation; f32-level accuracy, not the reference's arithmetic."""
+    M, K = A.shape
+    N = B.shape[0] if transB else B.shape[1]
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device) if out is None else out
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_gemm_split_workspace", M, N, K, C.byref(wsb))
+    ws = _workspace(wsb.value, A.device, "gemm_split")
+    capi.call("gnnx_gemm_split_bf16_f32", int(transB), M, N, K, _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(out), _ld(out), _ptr(ws),
+              wsb.value, _stream())
+    return out
+
+
 def colsum(G, out=None, beta=0.0):
     N, F = G.shape
     if out is None:

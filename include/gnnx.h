@@ -206,6 +206,16 @@ int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float
                   int64_t lda, const float *d_B, int64_t ldb, float beta, float *d_C, int64_t ldc,
                   void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* OPT-IN split-precision GEMM -- never the default, not used by any parity-graded call.  C[M,N] = A[M,K] . op(B)
+ * (transB: B is [N,K], else [K,N]) on the bf16 matrix cores: every f32 operand is split exactly into three bf16 pieces
+ * (8 + 8 + 8 significand bits) and the six piece products with i + j <= 2 are accumulated in f32, smallest first -- f32-level
+ * accuracy (error within a small factor of the f32 FMA chain's, far inside the 1e-5 bar; tests compare both with float64) at
+ * several times the f32 MFMA rate, but not the reference's arithmetic.  Needs K % 16 == 0, N % 128 == 0, A 16-byte aligned
+ * with lda % 4 == 0; workspace gnnx_gemm_split_workspace() bytes (the split copy of B). */
+int gnnx_gemm_split_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes);
+int gnnx_gemm_split_bf16_f32(int transB, int64_t M, int64_t N, int64_t K, const float *d_A, int64_t lda, const float *d_B,
+                             int64_t ldb, float *d_C, int64_t ldc, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* Calibration aid for the roofline: a register-only v_mfma_f32_32x32x2_f32 loop (no memory traffic).  *flops_out is
  * the number of flops the launch performs; time it with events to get the fp32 matrix rate this chip sustains at the
  * clock it holds under load. */

@@ -911,3 +911,38 @@ def test_leading_dimensions_wider_than_the_matrices(env):
     ops.to_bf16(H, out=Hb[:, 8:8 + F])
     assert torch.equal(ops.aggregate_fwd(g, Hb[:, 8:8 + F], bias), ops.aggregate_fwd(g, ops.to_bf16(Hc), bias))
     assert torch.equal(ops.aggregate_bwd(g, H), ops.aggregate_bwd(g, Hc))
+
+
+# ---- OPT-IN split-precision GEMM (gnnx_gemm_split_bf16_f32): bf16 matrix cores, exact 3-way operand split, f32 accumulate ----
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (1000, 256, 256), (4097, 128, 128), (5000, 256, 1024), (70001, 384, 32)])
+def test_split_gemm_accuracy_is_f32_level(env, M, N, K):
+    """Not the parity path (different arithmetic from the reference's f32 products) -- but its error against float64 must be
+    no worse than 1.5x the f32 MFMA GEMM's (measured: smaller, the bf16 MFMA adds 16 products per instruction), and it must
+    pass the very same 1e-5 bar as the default path; X.W^T and the k-major-B form give the same bits."""
+    ops, torch = env["ops"], env["torch"]
+    X = ops.uniform_pm1(980, (M, K), device=env["dev"])
+    W = ops.uniform_pm1(981, (N, K), scale=K ** -0.5, device=env["dev"])
+    ref = X.double() @ W.double().t()
+    f32 = ops.gemm(X, W, transB=True)
+    nt = ops.gemm_split(X, W, transB=True)
+    nn = ops.gemm_split(X, W.t().contiguous(), transB=False)
+    assert torch.equal(nt, nn)
+    e_split = (nt.double() - ref).abs()
+    e_f32 = (f32.double() - ref).abs()
+    assert e_split.max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    assert e_split.pow(2).mean().sqrt().item() <= 1.5 * e_f32.pow(2).mean().sqrt().item() + 1e-9
+    # operands that ARE bf16 numbers need one piece only: the result then equals the exact product sum rounded per MFMA
+    Xb, Wb = X.bfloat16().float(), W.bfloat16().float()
+    got = ops.gemm_split(Xb, Wb, transB=True)
+    refb = Xb.double() @ Wb.double().t()
+    assert (got.double() - refb).abs().max().item() <= 4e-7 * max(1.0, refb.abs().max().item()) * max(1, K // 256)
+
+
+def test_split_gemm_rejects_shapes_it_does_not_cover(env):
+    ops, capi = env["ops"], env["capi"]
+    X = ops.uniform_pm1(982, (100, 40), device=env["dev"])
+    W = ops.uniform_pm1(983, (128, 40), device=env["dev"])
+    with pytest.raises(capi.GnnxError):
+        ops.gemm_split(X, W, transB=True)          # K % 16 != 0
+    with pytest.raises(capi.GnnxError):
+        ops.gemm_split(ops.uniform_pm1(984, (100, 64), device=env["dev"]), ops.uniform_pm1(985, (100, 64), device=env["dev"]), transB=True)  # N % 128
