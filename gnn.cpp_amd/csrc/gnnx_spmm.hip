@@ -124,6 +124,9 @@ __device__ __forceinline__ float4 relu_v(float4 v) { return make_float4(relu1(v.
 // Prologue on a gathered row (MODE 3..5): the modules GCNConv::forward runs between transform and aggregation
 // (graph.cpp:174-175) folded into the gather, so the normalised / rectified H is never written to HBM.  Same separately
 // rounded op order as gnnx_bn_relu_fwd_f32 (sub, div, mul, add, where): fused and unfused results are the same bits.
+constexpr bool has_sc(int MODE) { return MODE == 1 || MODE == 6; }    // per-column scale (colscale)
+constexpr bool has_val(int MODE) { return MODE == 2 || MODE == 6; }   // per-entry value (vals)
+constexpr bool has_pro(int MODE) { return MODE >= 3 && MODE <= 5; }   // prologue on the gathered row
 constexpr bool pro_bn(int MODE) { return MODE == 4 || MODE == 5; }
 constexpr bool pro_relu(int MODE) { return MODE == 3 || MODE == 5; }
 template <int VEC> struct ProConst { typename Vec<VEC>::type mean, sd, gamma, beta; };
@@ -176,7 +179,8 @@ __device__ __forceinline__ ProConst<VEC> pro_load(const ARGS &a, int32_t f0, boo
 }
 
 // MODE 0: plain gather-add (forward).  MODE 1: gathered row scaled by colscale[c] (backward: norm (.) G).
-// MODE 2: general (vals and/or colscale).  MODE 3 / 4 / 5: forward with a ReLU / BatchNorm / BatchNorm+ReLU prologue.
+// MODE 2: per-entry values (vals).  MODE 6: vals and colscale.  MODE 3 / 4 / 5: forward with a ReLU / BatchNorm /
+// BatchNorm+ReLU prologue.
 //
 // Broadcast lane `src` (index inside the G-lane row group) of v to the whole group.  At G == 64 the source
 // lane is wave-uniform => v_readlane into an SGPR, so the neighbour row's base address is scalar and the
@@ -205,9 +209,9 @@ __device__ __forceinline__ void gather_batch(typename Vec<VEC>::type &acc, int k
 #pragma unroll
     for (int u = 0; u < B; u++) {
         V t = v[u];
-        if constexpr (MODE >= 3) t = pro_apply<MODE>(t, pc);
-        if constexpr (MODE == 1 || MODE == 2) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(mysc), k + u, gbase)));
-        if constexpr (MODE == 2) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(myval), k + u, gbase)));
+        if constexpr (has_pro(MODE)) t = pro_apply<MODE>(t, pc);
+        if constexpr (has_sc(MODE)) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(mysc), k + u, gbase)));
+        if constexpr (has_val(MODE)) t = mul_rn(t, __int_as_float(bcast<G>(__float_as_int(myval), k + u, gbase)));
         acc = add_rn(acc, t);
     }
 }
@@ -230,11 +234,8 @@ __device__ __forceinline__ typename Vec<VEC>::type gather_range(int32_t b, int32
         q = q >= b ? q : b;
         const int32_t myc = a.colidx[q];
         float mysc = 1.f, myval = 1.f;
-        if constexpr (MODE == 1) mysc = a.colscale[myc];
-        if constexpr (MODE == 2) {
-            if (a.colscale) mysc = a.colscale[myc];
-            if (a.vals) myval = a.vals[q];
-        }
+        if constexpr (has_sc(MODE)) mysc = a.colscale[myc];
+        if constexpr (has_val(MODE)) myval = a.vals[q];
         const int n = (hi - b) < G ? (hi - b) : G;
         int k = 0;
         for (; k + UE <= n; k += UE) gather_batch<G, VEC, UE, MODE>(acc, k, myc, mysc, myval, gbase, xf, a, pc);
@@ -364,11 +365,8 @@ struct Stream {
         ch.c = a.colidx[q];
         ch.sc = 1.f;
         ch.val = 1.f;
-        if constexpr (MODE == 1) ch.sc = a.colscale[ch.c];
-        if constexpr (MODE == 2) {
-            if (a.colscale) ch.sc = a.colscale[ch.c];
-            if (a.vals) ch.val = a.vals[q];
-        }
+        if constexpr (has_sc(MODE)) ch.sc = a.colscale[ch.c];
+        if constexpr (has_val(MODE)) ch.val = a.vals[q];
         return ch;
     }
 
@@ -381,11 +379,11 @@ struct Stream {
         for (int u = 0; u < B; u++) c[u] = bcast<G>(ch.c, k0 + u, gbase);
 #pragma unroll
         for (int u = 0; u < B; u++) b.v[u] = ld_x<VEC>(xf + (int64_t)c[u] * a.ldx);
-        if constexpr (MODE == 1 || MODE == 2) {
+        if constexpr (has_sc(MODE)) {
 #pragma unroll
             for (int u = 0; u < B; u++) b.sc[u] = __int_as_float(bcast<G>(__float_as_int(ch.sc), k0 + u, gbase));
         }
-        if constexpr (MODE == 2) {
+        if constexpr (has_val(MODE)) {
 #pragma unroll
             for (int u = 0; u < B; u++) b.val[u] = __int_as_float(bcast<G>(__float_as_int(ch.val), k0 + u, gbase));
         }
@@ -405,9 +403,9 @@ struct Stream {
                     rs = rp(r);
                 }
                 V t = b.v[u];
-                if constexpr (MODE >= 3) t = pro_apply<MODE>(t, pc);
-                if constexpr (MODE == 1 || MODE == 2) t = mul_rn(t, b.sc[u]);
-                if constexpr (MODE == 2) t = mul_rn(t, b.val[u]);
+                if constexpr (has_pro(MODE)) t = pro_apply<MODE>(t, pc);
+                if constexpr (has_sc(MODE)) t = mul_rn(t, b.sc[u]);
+                if constexpr (has_val(MODE)) t = mul_rn(t, b.val[u]);
                 acc = add_rn(acc, t);
             }
         }
@@ -750,7 +748,8 @@ void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32
         switch (mode) {
         case 0: GNNX_STREAM(0, bf16_t); break;
         case 1: GNNX_STREAM(1, bf16_t); break;
-        default: GNNX_STREAM(2, bf16_t); break;
+        case 2: GNNX_STREAM(2, bf16_t); break;
+        default: GNNX_STREAM(6, bf16_t); break;
         }
         return;
     }
@@ -760,7 +759,8 @@ void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32
     case 2: GNNX_STREAM(2, float); break;
     case 3: GNNX_STREAM(3, float); break;
     case 4: GNNX_STREAM(4, float); break;
-    default: GNNX_STREAM(5, float); break;
+    case 5: GNNX_STREAM(5, float); break;
+    default: GNNX_STREAM(6, float); break;
     }
 #undef GNNX_STREAM
 }
@@ -773,7 +773,8 @@ void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32_t
         switch (mode) {
         case 0: GNNX_ROWS(0, bf16_t); break;
         case 1: GNNX_ROWS(1, bf16_t); break;
-        default: GNNX_ROWS(2, bf16_t); break;
+        case 2: GNNX_ROWS(2, bf16_t); break;
+        default: GNNX_ROWS(6, bf16_t); break;
         }
         return;
     }
@@ -783,7 +784,8 @@ void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32_t
     case 2: GNNX_ROWS(2, float); break;
     case 3: GNNX_ROWS(3, float); break;
     case 4: GNNX_ROWS(4, float); break;
-    default: GNNX_ROWS(5, float); break;
+    case 5: GNNX_ROWS(5, float); break;
+    default: GNNX_ROWS(6, float); break;
     }
 #undef GNNX_ROWS
 }
@@ -798,8 +800,9 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     dim3 grid;
     int32_t n_item_blocks = (int32_t)ceil_div(a.n_items, GROUPS);
     grid.y = (uint32_t)ceil_div(a.n_feat, feat_per_tile);
-    // kernel MODE: 0 forward, 1 colscale (backward), 2 general (vals), 3/4/5 forward with ReLU / BN / BN+ReLU prologue
-    const int mode = a.vals != nullptr ? 2 : (a.colscale ? 1 : (pro ? 2 + pro : 0));
+    // kernel MODE: 0 forward, 1 colscale, 2 vals (the backward: norm streamed per entry), 6 vals + colscale, 3/4/5 forward with
+    // a ReLU / BN / BN+ReLU prologue
+    const int mode = a.vals != nullptr ? (a.colscale ? 6 : 2) : (a.colscale ? 1 : (pro ? 2 + pro : 0));
     bool stream = false;
     if constexpr (G >= 8) stream = use_stream_kernel(G);
     if constexpr (G == 64 && VEC == 4) {
