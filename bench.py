@@ -99,6 +99,12 @@ def main():
     ap.add_argument("--native-comm", action="store_true",
                     help="N>1: halo all-to-all-v and all-reduce through the C-ABI (gnnx_halo_exchange_f32) instead of torch.distributed")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank (rehearsal)")
+    ap.add_argument("--schedule", default="overlap", choices=["overlap", "sequential"],
+                    help="N>1: overlap = both halo exchanges asynchronous, each chain's compute under the other's exchange (same "
+                         "bits); sequential = GEMM -> exchange -> SpMM ... on one stream")
+    ap.add_argument("--partition", default="deal", choices=["deal", "contiguous"],
+                    help="N>1: deal = degree-sorted snake deal (equal rows / non-zeros / per-link volume); contiguous = ranges of "
+                         "original ids balanced on degree (round 1)")
     ap.add_argument("--cpu-sample-nodes", type=int, default=2_500_000,
                     help="nodes of the bounded CPU-baseline sample (same generator and average degree): about 12 s on all host "
                          "threads + about 10 s for the single-thread leg on a tenth of it")
@@ -108,8 +114,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # started as plain `python bench.py --gpus N`: start the ranks ourselves -- a FRESH child process running
+            # torch.distributed.run, before anything in this process has touched the GPU -- and pass its JSON line and
+            # exit code through
+            import subprocess
+            port = os.environ.get("MASTER_PORT", "29533")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                   "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+            env = dict(os.environ)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            sys.exit(subprocess.call(cmd, env=env))
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the product path has no CPU fallback")
@@ -141,7 +156,8 @@ def main():
         runner.split_gemm = args.split_gemm
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
-        runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm)
+        runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm,
+                                    schedule=args.schedule, partition=args.partition)
     torch.cuda.synchronize()
     t_build = time.time() - t_build0
 
@@ -215,7 +231,8 @@ def main():
                        "features": F, "layer": f"{F}->{F}",
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
-                       "parallelism": "single" if world == 1 else f"1-D vertex shard x{world}, halo all-to-all-v",
+                       "parallelism": "single" if world == 1 and not args.force_sharded else
+                       f"1-D vertex shard x{world} ({args.partition}), halo all-to-all-v, schedule {args.schedule}",
                        "plan_chunk": args.chunk, "hip_graph": graph is not None, "mode": "SYM" if args.sym else "REF",
                        "feature_storage": "bf16 for the aggregations (opt-in, NOT the parity path)" if args.bf16_features else "f32",
                        "gemm": "split-bf16 x6 for X.W^T and dH.W (opt-in, NOT the parity path)" if args.split_gemm else "f32 MFMA"},

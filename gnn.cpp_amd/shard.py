@@ -1,14 +1,23 @@
 """1-D vertex (row) partition of the GCN aggregation over the GPUs of one node + halo exchange.
 
 What shards: rows of A are independent; the only coupling is reading neighbour
-rows of H owned elsewhere.  Rank p owns the contiguous vertex range [cut[p], cut[p+1]) (cuts balance
-out-degree + in-degree), holds
-  * CSR of its rows of A   and CSR of its rows of A^T (built from the edges whose src / dst it owns),
-    columns renumbered to [local rows | halo rows] WITHOUT reordering the entries of a row: the kernel adds
-    neighbours in storage order, which stays the reference's descending-global-column order, so the
-    sharded result is bit-identical to the single-GPU one;
-  * halo lists: the sorted global ids of remote columns it reads (forward: out-neighbours, backward:
-    in-neighbours), grouped by owner because ranges are contiguous;
+rows of H owned elsewhere.
+
+Partition (`deal_partition`).  Vertices are sorted by weight (out-degree + in-degree + a per-row term for
+the dense work) and DEALT to the ranks in snake order (0..P-1, P-1..0, ...): every rank gets n/P +- 1
+rows, the same degree mix, hence the same GEMM rows, the same non-zeros and -- what the xGMI links care about
+-- statistically the same send volume to every peer.  (Contiguous ranges on an R-MAT graph gave one rank 3.6 M
+tail rows and another 75 k hub rows, 52 k .. 451 k rows per link; see scripts/exp_halo.py.)  Inside a rank the
+rows keep their ascending original order.  The partition is expressed as a relabelling `nid[v]`
+(new id: rank p owns the contiguous new-id range [cuts[p], cuts[p+1])); world = 1 is the identity.
+
+Rank p holds
+  * CSR of its rows of A and CSR of its rows of A^T (built from the edges whose src / dst it owns).  The entries of a
+    row are sorted by ORIGINAL column id -- the kernel adds neighbours in storage order, so the order stays the
+    reference's descending-original-column order and the sharded result is bit-identical to the single-GPU one --
+    and only then renumbered, value by value, to [local rows | halo rows];
+  * halo lists: the sorted new ids of remote columns it reads (forward: out-neighbours, backward:
+    in-neighbours), grouped by owner because new-id ranges are contiguous;
   * send lists: for every peer, which of its own rows that peer reads (exchanged once, at plan time).
 Per aggregation there is ONE exchange step: pack rows by send list (gnnx_gather_rows_f32) -> all-to-all-v
 (torch.distributed all_to_all_single with split sizes = grouped ncclSend/ncclRecv on RCCL; every pair of
@@ -16,8 +25,16 @@ GPUs has its own xGMI link) straight into the [halo] tail of the feature buffer 
 [local | halo].  Backward pulls too (rows of G for in-neighbours through the transposed CSR): no
 scatter-add, no atomics, deterministic.  dW / dbias are summed with a small all-reduce.
 
+Schedule (`ShardedBench.step`).  X and the upstream gradient G are both inputs of the layer step, and the forward
+chain (X.W^T -> exchange H -> aggregate) and the backward chain (exchange G -> aggregate^T -> dH.W, dH^T.X) share
+nothing but the links.  "overlap" issues both exchanges asynchronously on the communication stream and runs each
+chain's compute under the other chain's exchange; every SpMM still runs over the complete [local | halo] buffer, so
+the results are the same bits as in "sequential" (GEMM -> exchange -> SpMM -> ... on one stream).
+
 This module is host-side index logic (torch tensor ops, device-agnostic so that the gloo/CPU tests drive
-exactly this code) plus the exchange; all arithmetic goes through the C-ABI (ops.py).
+exactly this code) plus the exchange; all arithmetic goes through the C-ABI (ops.py).  The same plan exists
+behind the C-ABI (gnnx_partition_deal / gnnx_halo_plan_*, include/gnnx.h) for the C++ host; the two are compared
+array for array in tests/test_gpu_sharded_loopback.py.
 """
 import torch
 
@@ -35,18 +52,60 @@ def balanced_cuts(weight, world):
     return cuts
 
 
-class HaloSide:
-    """One direction of the exchange (forward: columns of A; backward: columns of A^T)."""
+def deal_partition(weight, world):
+    """Snake-deal the vertices, heaviest first, to `world` ranks.
 
-    def __init__(self, rowptr, colidx_global, lo, hi, cuts):
-        dev = colidx_global.device
+    weight: int64 [n] (>= 0).  Returns (owner int32 [n], nid int32 [n], cuts list[world+1]):
+    position k of the stable descending-weight order (ties: ascending id) goes to rank j = k % world in even rounds
+    k // world and to world-1-j in odd rounds; nid numbers rank p's vertices cuts[p].. in ascending original id.
+    Mirrors gnnx_partition_deal (csrc/gnnx_shard.hip)."""
+    n = int(weight.numel())
+    dev = weight.device
+    if world == 1 or n == 0:
+        return (torch.zeros(n, dtype=torch.int32, device=dev), torch.arange(n, dtype=torch.int32, device=dev),
+                [0] + [n] * world)
+    w = weight.to(torch.int64)
+    key = int(w.max().item()) - w                      # ascending stable sort == descending weight, ties by id
+    order = torch.sort(key, stable=True).indices
+    k = torch.arange(n, dtype=torch.int64, device=dev)
+    j, r = k % world, k // world
+    rank_of_pos = torch.where(r % 2 == 0, j, world - 1 - j).to(torch.int32)
+    owner = torch.empty(n, dtype=torch.int32, device=dev)
+    owner[order] = rank_of_pos
+    counts = torch.bincount(owner.to(torch.int64), minlength=world).tolist()
+    cuts = [0]
+    for c in counts:
+        cuts.append(cuts[-1] + int(c))
+    nid = torch.empty(n, dtype=torch.int32, device=dev)
+    for p in range(world):
+        m = owner == p
+        nid[m] = torch.arange(cuts[p], cuts[p + 1], dtype=torch.int32, device=dev)
+    return owner, nid, cuts
+
+
+def contiguous_partition(weight, world):
+    """The round-1 partition: contiguous original-id ranges of ~equal weight (kept for comparison, scripts/exp_halo.py)."""
+    n = int(weight.numel())
+    dev = weight.device
+    cuts = balanced_cuts(weight, world)
+    nid = torch.arange(n, dtype=torch.int32, device=dev)
+    owner = (torch.searchsorted(torch.tensor(cuts[1:], dtype=torch.int64, device=dev), nid.to(torch.int64), right=True)
+             .clamp_(max=world - 1).to(torch.int32))
+    return owner, nid, cuts
+
+
+class HaloSide:
+    """One direction of the exchange (forward: columns of A; backward: columns of A^T).  Column ids are NEW ids."""
+
+    def __init__(self, rowptr, colidx_nid, lo, hi, cuts):
+        dev = colidx_nid.device
         self.n_local = hi - lo
         self.rowptr = rowptr
-        remote = (colidx_global < lo) | (colidx_global >= hi)
-        halo = torch.unique(colidx_global[remote])  # sorted ascending => grouped by owner
+        remote = (colidx_nid < lo) | (colidx_nid >= hi)
+        halo = torch.unique(colidx_nid[remote])  # sorted ascending => grouped by owner
         self.halo = halo
         self.n_halo = int(halo.numel())
-        col = colidx_global.to(torch.int64)
+        col = colidx_nid.to(torch.int64)
         local_id = col - lo
         halo_id = torch.searchsorted(halo.to(torch.int64), col) + self.n_local
         self.colidx = torch.where(remote, halo_id, local_id).to(torch.int32)  # entry order untouched
@@ -69,11 +128,20 @@ class HaloSide:
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
 
 
-def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None):
+class _Done:
+    """Handle of an exchange that has already completed on the caller's stream."""
+
+    def wait(self):
+        return True
+
+
+def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None, async_op=False):
     """buf: [n_local + n_halo, F]; rows [:n_local] are this rank's; fills rows [n_local:] from the owners.
     pack(src_rows_view, idx, out) gathers rows (gnnx_gather_rows_f32 on GPU).
     native: a NativeComm => the all-to-all-v runs through the C-ABI (gnnx_halo_exchange_f32, RCCL send/recv group)
-    instead of torch.distributed.all_to_all_single (the same RCCL underneath)."""
+    instead of torch.distributed.all_to_all_single (the same RCCL underneath).
+    async_op: return a handle at once; handle.wait() orders the CALLER's current stream behind the exchange (the
+    send buffer must then stay untouched until the wait).  Returns (send_buf, handle)."""
     n_send = int(side.send_idx.numel())
     if send_buf is None or send_buf.shape[0] < n_send:
         send_buf = torch.empty((max(n_send, 1), n_feat), dtype=buf.dtype, device=buf.device)
@@ -82,15 +150,17 @@ def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None):
         pack(buf[: side.n_local], side.send_idx, out)
     recv = buf[side.n_local: side.n_local + side.n_halo]
     if native is not None:
-        native.halo_exchange(out, side.send_counts, recv, side.recv_counts, n_feat)
+        h = native.halo_exchange(out, side.send_counts, recv, side.recv_counts, n_feat, async_op=async_op)
     else:
-        dist.all_to_all_single(recv, out, side.recv_counts, side.send_counts)
-    return send_buf
+        h = dist.all_to_all_single(recv, out, side.recv_counts, side.send_counts, async_op=async_op) if async_op else \
+            dist.all_to_all_single(recv, out, side.recv_counts, side.send_counts)
+    return send_buf, (h if (async_op and h is not None) else _Done())
 
 
 class NativeComm:
     """RCCL communicator owned by the C-ABI (gnnx_comm_*).  The 128-byte id is created on rank 0 and shipped with
-    one torch.distributed broadcast (setup only); the per-step exchange and all-reduce then bypass torch."""
+    one torch.distributed broadcast (setup only); the per-step exchange and all-reduce then bypass torch.
+    Asynchronous exchanges run on a communication stream of their own, ordered against the caller's stream with events."""
 
     def __init__(self, capi, ops, dist, rank, world, dev):
         import ctypes as C
@@ -104,13 +174,30 @@ class NativeComm:
         raw = bytes(t.cpu().numpy().tobytes())
         self.h = C.c_void_p()
         capi.call("gnnx_comm_init", C.byref(self.h), world, rank, C.c_char_p(raw))
+        self.comm_stream = torch.cuda.Stream(device=dev)
 
-    def halo_exchange(self, send, send_counts, recv, recv_counts, n_feat):
+    class _Handle:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+            return True
+
+    def halo_exchange(self, send, send_counts, recv, recv_counts, n_feat, async_op=False):
         C = self.C
         sc = (C.c_int64 * self.world)(*[int(v) for v in send_counts])
         rc = (C.c_int64 * self.world)(*[int(v) for v in recv_counts])
+        if not async_op:
+            self.capi.call("gnnx_halo_exchange_f32", self.h, self.ops._ptr(send) if send.numel() else None, sc,
+                           self.ops._ptr(recv) if recv.numel() else None, rc, int(n_feat), self.ops._stream())
+            return None
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
         self.capi.call("gnnx_halo_exchange_f32", self.h, self.ops._ptr(send) if send.numel() else None, sc,
-                       self.ops._ptr(recv) if recv.numel() else None, rc, int(n_feat), self.ops._stream())
+                       self.ops._ptr(recv) if recv.numel() else None, rc, int(n_feat), C.c_void_p(self.comm_stream.cuda_stream))
+        ev = torch.cuda.Event()
+        ev.record(self.comm_stream)
+        return NativeComm._Handle(ev)
 
     def allreduce(self, t):
         self.capi.call("gnnx_allreduce_sum_f32", self.h, self.ops._ptr(t), t.numel(), self.ops._stream())
@@ -127,40 +214,53 @@ class ShardPlan:
 
     csr_builder(src, dst, n_rows, n_cols_hint) -> (rowptr int32 [n_rows+1], colidx int32 [nnz]) must apply the
     reference's adjacency semantics (dedupe, self-loop strip, (src,dst) order): gnnx_csr_from_coo on the GPU.
-    Rows are LOCAL ids (src - lo), columns stay GLOBAL until HaloSide renumbers them.
+    Rows are LOCAL ids, columns are ORIGINAL ids in the builder (so a row's entries are stored in the reference's order)
+    and are mapped to new ids, then to [local | halo], afterwards.
+    partition: "deal" (default), "contiguous", or a ready (owner, nid, cuts) triple.
     """
 
-    def __init__(self, src, dst, n_nodes, rank, world, dist, csr_builder, cuts=None, row_weight=1):
+    def __init__(self, src, dst, n_nodes, rank, world, dist, csr_builder, partition="deal", row_weight=1):
         dev = src.device
         self.rank, self.world, self.n_nodes = rank, world, n_nodes
-        if cuts is None:
+        if isinstance(partition, str):
             # cost model of a vertex: `row_weight` for the dense work on its row (three GEMM passes, ~6 F^2 flop) plus one
             # unit per incident edge for the two aggregations (4 F bytes each): row_weight ~ 0.08 F on MI355X
             w = torch.bincount(src.to(torch.int64), minlength=n_nodes) + torch.bincount(dst.to(torch.int64), minlength=n_nodes) \
                 + int(row_weight)
-            cuts = balanced_cuts(w, world)
-        self.cuts = cuts
+            partition = (deal_partition if partition == "deal" else contiguous_partition)(w, world)
+        self.owner, self.nid, self.cuts = partition
+        cuts = self.cuts
         lo, hi = cuts[rank], cuts[rank + 1]
         self.lo, self.hi, self.n_local = lo, hi, hi - lo
+        self.verts = torch.nonzero(self.owner == rank).reshape(-1)  # original ids of my rows, ascending == local order
+        nid = self.nid
         # self loops must be dropped on GLOBAL ids (rows are renumbered below), duplicates collapse in the builder
         keep = src != dst
-        mine = keep & (src >= lo) & (src < hi)
-        rp, ci = csr_builder((src[mine] - lo).to(torch.int32), dst[mine].to(torch.int32), self.n_local, n_nodes)
-        self.fwd = HaloSide(rp, ci, lo, hi, cuts)
-        mine_t = keep & (dst >= lo) & (dst < hi)
-        rpt, cit = csr_builder((dst[mine_t] - lo).to(torch.int32), src[mine_t].to(torch.int32), self.n_local, n_nodes)
-        self.bwd = HaloSide(rpt, cit, lo, hi, cuts)
+        mine = keep & (self.owner[src.long()] == rank)
+        rp, ci = csr_builder((nid[src[mine].long()] - lo).to(torch.int32), dst[mine].to(torch.int32), self.n_local, n_nodes)
+        self.fwd = HaloSide(rp, nid[ci.long()], lo, hi, cuts)
+        mine_t = keep & (self.owner[dst.long()] == rank)
+        rpt, cit = csr_builder((nid[dst[mine_t].long()] - lo).to(torch.int32), src[mine_t].to(torch.int32), self.n_local, n_nodes)
+        self.bwd = HaloSide(rpt, nid[cit.long()], lo, hi, cuts)
         self.nnz_local = int(ci.numel())
         if world > 1 and dist is not None:
             self.fwd.exchange_requests(dist, cuts, rank, world)
             self.bwd.exchange_requests(dist, cuts, rank, world)
         elif world > 1:
-            pass  # plan without a process group (tests fill the halo rows themselves)
+            pass  # plan without a process group (tests / scripts fill the halo rows themselves)
         else:
             for s in (self.fwd, self.bwd):
                 s.send_counts = [0]
                 s.send_idx = torch.empty(0, dtype=torch.int32, device=dev)
         self.s_ext = self.norm = self.norm_ext_bwd = None
+
+    def orig_ids(self, new_ids):
+        """Original vertex ids of new ids (e.g. of a HaloSide.halo list)."""
+        if getattr(self, "_inv", None) is None:
+            inv = torch.empty(self.n_nodes, dtype=torch.int64, device=self.nid.device)
+            inv[self.nid.long()] = torch.arange(self.n_nodes, dtype=torch.int64, device=self.nid.device)
+            self._inv = inv
+        return self._inv[new_ids.long()]
 
     def compute_norm(self, dist, degree_norm, pack):
         """s for local rows from local degrees, s of halo columns by one exchange, then norm (graph.cpp:177-185);
@@ -187,12 +287,13 @@ class ShardedBench:
     """bench.py runner for N > 1 ranks: same synthetic graph as the single-GPU workload, sharded."""
 
     def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, native_comm=False,
-                 global_inputs=False):
+                 global_inputs=False, schedule="overlap", partition="deal"):
         import ctypes as C
         self.C = C
         self.native = NativeComm(capi, ops, dist, rank, world, dev) if native_comm else None
         self.ops, self.capi, self.dist, self.F = ops, capi, dist, F
         self.rank, self.world = rank, world
+        self.schedule = schedule
         if abc is None:
             s, d = pkg.synth.uniform_edges(seed, n, e)
             src, dst = torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)
@@ -203,8 +304,10 @@ class ShardedBench:
             rp, ci = ops.CsrGraph.csr_from_coo(s_, d_, max(n_rows, n_cols), flags=1)  # self loops handled on global ids
             return rp[: n_rows + 1].contiguous(), ci
 
-        self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once, row_weight=max(1, round(0.078 * F)))
+        self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once, partition=partition,
+                                  row_weight=max(1, round(0.078 * F)))
         del src, dst
+        p.owner = p.nid = None  # 2 x 4 N bytes the step does not need
         ops._ws_cache.clear()
         torch.cuda.empty_cache()
 
@@ -222,8 +325,8 @@ class ShardedBench:
         self.plan_f = ops.SpmmPlan(p.fwd.rowptr, chunk, F) if chunk > 0 else None
         self.plan_b = ops.SpmmPlan(p.bwd.rowptr, chunk, F) if chunk > 0 else None
         nl = p.n_local
-        if global_inputs:  # rows [lo, hi) of the SAME X / G a single-GPU run generates (tests compare against it)
-            self.X = ops.uniform_pm1(seed + 10, (n, F), device=dev)[p.lo: p.hi].clone()
+        if global_inputs:  # my rows of the SAME X / G a single-GPU run generates (tests compare against it)
+            self.X = ops.uniform_pm1(seed + 10, (n, F), device=dev)[p.verts].clone()
         else:
             self.X = ops.uniform_pm1(seed + 10 + 1000 * rank, (nl, F), device=dev)
         self.W = ops.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5, device=dev)
@@ -231,7 +334,7 @@ class ShardedBench:
         self.Hext = torch.empty((nl + p.fwd.n_halo, F), dtype=torch.float32, device=dev)   # [local | halo]
         self.Gext = torch.empty((nl + p.bwd.n_halo, F), dtype=torch.float32, device=dev)
         if global_inputs:
-            self.Gext[:nl] = ops.uniform_pm1(seed + 12, (n, F), device=dev)[p.lo: p.hi]
+            self.Gext[:nl] = ops.uniform_pm1(seed + 12, (n, F), device=dev)[p.verts]
         else:
             self.Gext[:nl] = ops.uniform_pm1(seed + 12 + 1000 * rank, (nl, F), device=dev)
         self.out = torch.empty((nl, F), dtype=torch.float32, device=dev)
@@ -239,10 +342,29 @@ class ShardedBench:
         self.dX = torch.empty((nl, F), dtype=torch.float32, device=dev)
         self.dW = torch.empty((F, F), dtype=torch.float32, device=dev)
         self.dbias = torch.empty(F, dtype=torch.float32, device=dev)
-        n_send = max(int(p.fwd.send_idx.numel()), int(p.bwd.send_idx.numel()), 1)
-        self.send_buf = torch.empty((n_send, F), dtype=torch.float32, device=dev)
-        self.names = ["gemm_xwT", "halo_fwd", "spmm_fwd", "colsum", "halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW", "allreduce"]
+        # one send buffer per direction: in the overlap schedule both exchanges are in flight at once
+        self.send_f = torch.empty((max(int(p.fwd.send_idx.numel()), 1), F), dtype=torch.float32, device=dev)
+        self.send_b = torch.empty((max(int(p.bwd.send_idx.numel()), 1), F), dtype=torch.float32, device=dev)
+        self.set_schedule(schedule)
         self.ev = []
+
+    def set_schedule(self, schedule):
+        assert schedule in ("overlap", "sequential")
+        self.schedule = schedule
+        if schedule == "sequential":
+            self.names = ["gemm_xwT", "halo_fwd", "spmm_fwd", "colsum", "halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW", "allreduce"]
+        else:
+            self.names = ["pack_send_bwd", "gemm_xwT", "pack_send_fwd", "colsum", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
+                          "wait_halo_fwd", "spmm_fwd", "allreduce"]
+        self.ev = []
+
+    def _reduce_params(self):
+        if self.native is not None:
+            self.native.allreduce(self.dW)
+            self.native.allreduce(self.dbias)
+        else:
+            self.dist.all_reduce(self.dW)
+            self.dist.all_reduce(self.dbias)
 
     def step(self, timed=False):
         ops, p, dist, nl = self.ops, self.plan, self.dist, self.plan.n_local
@@ -253,32 +375,42 @@ class ShardedBench:
             if timed:
                 a, b = self.capi.Event(), self.capi.Event()
                 a.record(stream)
-                fn()
+                r = fn()
                 b.record(stream)
                 evs.append((a, b))
-            else:
-                fn()
+                return r
+            return fn()
 
         Hl, Gl = self.Hext[:nl], self.Gext[:nl]
-        run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
-        run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_buf, self.native))
-        run(lambda: ops.spmm(p.fwd.rowptr, p.fwd.colidx, self.Hext, out=self.out, rowscale=p.norm, bias=self.bias,
-                             plan=self.plan_f, n_rows=nl))
-        run(lambda: ops.colsum(Gl, out=self.dbias))
-        run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_buf, self.native))
-        run(lambda: ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext, out=self.dH, vals=self.norm_nz_bwd, plan=self.plan_b,
-                             n_rows=nl))
-        run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
-        run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
-
-        def reduce_params():
-            if self.native is not None:
-                self.native.allreduce(self.dW)
-                self.native.allreduce(self.dbias)
-            else:
-                dist.all_reduce(self.dW)
-                dist.all_reduce(self.dbias)
-        run(reduce_params)
+        spmm_f = lambda: ops.spmm(p.fwd.rowptr, p.fwd.colidx, self.Hext, out=self.out, rowscale=p.norm, bias=self.bias,  # noqa: E731
+                                  plan=self.plan_f, n_rows=nl)
+        spmm_b = lambda: ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext, out=self.dH, vals=self.norm_nz_bwd,  # noqa: E731
+                                  plan=self.plan_b, n_rows=nl)
+        if self.schedule == "sequential":
+            run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
+            run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native))
+            run(spmm_f)
+            run(lambda: ops.colsum(Gl, out=self.dbias))
+            run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native))
+            run(spmm_b)
+            run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
+            run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+            run(self._reduce_params)
+        else:
+            # backward chain's exchange first: it needs no compute in front of it, and the forward chain's GEMM + pack
+            # then run under it; the backward chain's SpMM + two GEMMs run under the forward exchange; what is left
+            # exposed is one exchange's head and the forward SpMM at the tail.
+            _, hb = run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True))
+            run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
+            _, hf = run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, async_op=True))
+            run(lambda: ops.colsum(Gl, out=self.dbias))
+            run(hb.wait)
+            run(spmm_b)
+            run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
+            run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+            run(hf.wait)
+            run(spmm_f)
+            run(self._reduce_params)
         if timed:
             self.ev.append(evs)
 
@@ -298,4 +430,5 @@ class ShardedBench:
         return {"bound": "hbm", "kernel": "spmm_stream_kernel<64,4,8,0,64> (forward aggregation, slowest rank)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": B, "avg_launch_ms": ms,
-                "halo_rows_fwd": p.fwd.n_halo, "halo_rows_bwd": p.bwd.n_halo, "local_rows": p.n_local}
+                "halo_rows_fwd": p.fwd.n_halo, "halo_rows_bwd": p.bwd.n_halo, "local_rows": p.n_local,
+                "send_rows_per_peer_fwd": p.fwd.send_counts, "schedule": self.schedule}

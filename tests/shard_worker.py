@@ -61,39 +61,48 @@ def main():
     out_ref = oracle.aggregate_fwd(rp, ci, H, norm, bias)
     dH_ref = oracle.aggregate_bwd(rT, cT, G, norm)
 
-    plan = shard.ShardPlan(torch.from_numpy(src), torch.from_numpy(dst), n, rank, world, dist, np_csr)
-    lo, hi, nl = plan.lo, plan.hi, plan.n_local
+    plan = shard.ShardPlan(torch.from_numpy(src), torch.from_numpy(dst), n, rank, world, dist, np_csr,
+                           partition=os.environ.get("PARTITION", "deal"))
+    nl = plan.n_local
+    mine = plan.verts.numpy()  # original ids of this rank's rows, in local order
     assert plan.cuts[0] == 0 and plan.cuts[-1] == n and all(a <= b for a, b in zip(plan.cuts, plan.cuts[1:]))
+    assert len(mine) == nl and np.all(np.diff(mine) > 0)
+    assert np.array_equal(plan.nid.numpy()[mine], np.arange(plan.lo, plan.hi)), "new ids are not rank-contiguous"
+    counts = torch.tensor([nl], dtype=torch.int64)
+    dist.all_reduce(counts)
+    assert int(counts.item()) == n, "the partition does not cover every vertex exactly once"
+    halo_f, halo_b = plan.orig_ids(plan.fwd.halo).numpy(), plan.orig_ids(plan.bwd.halo).numpy()
     plan.compute_norm(dist, degree_norm, pack)
-    assert np.array_equal(plan.norm.numpy(), norm[lo:hi]), "sharded norm differs"
-    assert np.array_equal(plan.s_ext[:nl, 0].numpy(), s[lo:hi])
-    assert np.array_equal(plan.s_ext[nl:, 0].numpy(), s[plan.fwd.halo.numpy()]), "halo s exchange wrong"
+    assert np.array_equal(plan.norm.numpy(), norm[mine]), "sharded norm differs"
+    assert np.array_equal(plan.s_ext[:nl, 0].numpy(), s[mine])
+    assert np.array_equal(plan.s_ext[nl:, 0].numpy(), s[halo_f]), "halo s exchange wrong"
 
     # forward: [local | halo] buffer, one exchange, local aggregation
     f = plan.fwd
     Hext = torch.zeros((nl + f.n_halo, F), dtype=torch.float32)
-    Hext[:nl] = torch.from_numpy(H[lo:hi])
-    shard.exchange_rows(dist, f, Hext, F, pack)
-    assert np.array_equal(Hext[nl:].numpy(), H[f.halo.numpy()]), "forward halo rows wrong"
+    Hext[:nl] = torch.from_numpy(H[mine])
+    _, h = shard.exchange_rows(dist, f, Hext, F, pack, async_op=True)
+    h.wait()
+    assert np.array_equal(Hext[nl:].numpy(), H[halo_f]), "forward halo rows wrong"
     out = oracle.aggregate_fwd(f.rowptr.numpy().astype(np.int64), f.colidx.numpy(), Hext.numpy(), plan.norm.numpy(), bias,
                                n_rows=nl)
-    assert np.array_equal(out, out_ref[lo:hi]), "sharded forward aggregation is not bit-identical"
+    assert np.array_equal(out, out_ref[mine]), "sharded forward aggregation is not bit-identical"
 
     # backward: pull rows of G for in-neighbours through the transposed shard
     b = plan.bwd
     Gext = torch.zeros((nl + b.n_halo, F), dtype=torch.float32)
-    Gext[:nl] = torch.from_numpy(G[lo:hi])
+    Gext[:nl] = torch.from_numpy(G[mine])
     shard.exchange_rows(dist, b, Gext, F, pack)
-    assert np.array_equal(plan.norm_ext_bwd.numpy()[nl:], norm[b.halo.numpy()]), "backward halo norm wrong"
+    assert np.array_equal(plan.norm_ext_bwd.numpy()[nl:], norm[halo_b]), "backward halo norm wrong"
     dH = oracle.aggregate_bwd(b.rowptr.numpy().astype(np.int64), b.colidx.numpy(), Gext.numpy(), plan.norm_ext_bwd.numpy(),
                               n_rows=nl)
-    assert np.array_equal(dH, dH_ref[lo:hi]), "sharded backward aggregation is not bit-identical"
+    assert np.array_equal(dH, dH_ref[mine]), "sharded backward aggregation is not bit-identical"
 
     # nnz bookkeeping and parameter-gradient reduction
     t = torch.tensor([plan.nnz_local], dtype=torch.int64)
     dist.all_reduce(t)
     assert int(t.item()) == len(ci)
-    dbias = torch.from_numpy(G[lo:hi].astype(np.float64).sum(0))
+    dbias = torch.from_numpy(G[mine].astype(np.float64).sum(0))
     dist.all_reduce(dbias)
     assert np.allclose(dbias.numpy(), G.astype(np.float64).sum(0))
     # send lists are consistent: what I send to q is what q receives from me

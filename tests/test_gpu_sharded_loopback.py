@@ -30,7 +30,13 @@ class _RankDist:
     def __init__(self, w, rank):
         self.w, self.rank = w, rank
 
-    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
+    class _Work:
+        def wait(self):
+            return True
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, async_op=False):
+        """async_op: the stand-in completes the exchange before returning (every rank shares one device and one stream,
+        so there is nothing to overlap); the caller's issue order and buffer lifetimes are what is being exercised."""
         w, P = self.w, self.w.world
         if input_split_sizes is None:
             n = inp.shape[0] // P
@@ -50,6 +56,7 @@ class _RankDist:
         import torch
         torch.cuda.synchronize()
         w.bar.wait()
+        return self._Work() if async_op else None
 
     def all_reduce(self, t, op=None):
         import torch
@@ -67,8 +74,9 @@ class _RankDist:
         self.w.bar.wait()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_sharded_step_equals_single_gpu(world):
+@pytest.mark.parametrize("world,schedule,partition", [(2, "overlap", "deal"), (4, "overlap", "deal"), (8, "overlap", "deal"),
+                                                      (4, "sequential", "deal"), (8, "sequential", "contiguous")])
+def test_sharded_step_equals_single_gpu(world, schedule, partition):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("needs a HIP device")
@@ -97,8 +105,10 @@ def test_sharded_step_equals_single_gpu(world):
     def rank_main(rank):
         try:
             torch.cuda.set_device(0)
-            r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 0, global_inputs=True)
+            r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 0, global_inputs=True,
+                                   schedule=schedule, partition=partition)
             r.step()
+            r.step(timed=True)  # a second step reuses every buffer (send buffers, halo tails) while nothing is in flight
             torch.cuda.synchronize()
             runners[rank] = r
         except Exception as ex:  # noqa: BLE001
@@ -114,15 +124,26 @@ def test_sharded_step_equals_single_gpu(world):
     assert not errors, errors[0][1]
     nnz = sum(r.plan.nnz_local for r in runners)
     assert nnz == g.nnz
+    covered = torch.zeros(n, dtype=torch.int32, device=dev)
     for r in runners:
-        lo, hi = r.plan.lo, r.plan.hi
-        assert torch.equal(r.plan.norm, g.norm[lo:hi]), "sharded norm differs"
-        assert torch.equal(r.out, out_ref[lo:hi]), "sharded forward aggregation not bit-identical to single GPU"
-        assert torch.equal(r.dH, dH_ref[lo:hi]), "sharded backward aggregation not bit-identical to single GPU"
-        assert float((r.dX - dX_ref[lo:hi]).abs().max()) <= 1e-5 * max(1.0, float(dX_ref.abs().max()))
+        v = r.plan.verts
+        covered[v] += 1
+        assert v.numel() == r.plan.n_local and bool((v[1:] > v[:-1]).all())
+        assert torch.equal(r.plan.norm, g.norm[v]), "sharded norm differs"
+        assert torch.equal(r.out, out_ref[v]), "sharded forward aggregation not bit-identical to single GPU"
+        assert torch.equal(r.dH, dH_ref[v]), "sharded backward aggregation not bit-identical to single GPU"
+        assert float((r.dX - dX_ref[v]).abs().max()) <= 1e-5 * max(1.0, float(dX_ref.abs().max()))
         # parameters were all-reduced: every rank holds the global sums
         scale = float((dH_ref.abs().t().double() @ X.abs().double()).max())
         assert float((r.dW - dW_ref).abs().max()) <= 1e-5 * max(1.0, scale)
         assert float((r.dbias - dbias_ref).abs().max()) <= 1e-5 * max(1.0, float(G.abs().double().sum(0).max()))
+    assert bool((covered == 1).all()), "the partition does not cover every vertex exactly once"
     cuts = runners[0].plan.cuts
     assert cuts[0] == 0 and cuts[-1] == n and all(r.plan.cuts == cuts for r in runners)
+    if partition == "deal":  # every rank gets the same number of rows (+-1) and about the same non-zeros
+        rows = [r.plan.n_local for r in runners]
+        nz = [r.plan.nnz_local for r in runners]
+        assert max(rows) - min(rows) <= 1
+        assert max(nz) <= 1.1 * (sum(nz) / world)
+        sends = [c for r in runners for q, c in enumerate(r.plan.fwd.send_counts) if q != r.rank]
+        assert max(sends) <= 1.35 * (sum(sends) / len(sends)), "per-link send volume is unbalanced"

@@ -30,6 +30,11 @@ def test_sharded_aggregation_bit_identical(world, port):
     run_world(world, port)
 
 
+def test_sharded_aggregation_bit_identical_contiguous_partition():
+    """The round-1 partition (contiguous original-id ranges) stays available and exact."""
+    run_world(2, 29624, PARTITION="contiguous")
+
+
 def test_sharded_tiny_graph_with_empty_halos():
     """More ranks than structure: 40 nodes, 60 edges over 2 ranks (some peers exchange nothing)."""
     run_world(2, 29623, N=40, E=60, F=5)
@@ -42,3 +47,23 @@ def test_balanced_cuts():
     c = shard.balanced_cuts(w, 4)
     assert c[0] == 0 and c[-1] == 8 and c == sorted(c)
     assert shard.balanced_cuts(torch.zeros(0, dtype=torch.int64), 3) == [0, 0, 0, 0]
+
+
+def test_deal_partition_balances_rows_and_weight():
+    g = torch.Generator().manual_seed(3)
+    w = (torch.rand(10_001, generator=g) ** 8 * 5000).to(torch.int64) + 1  # heavy tail
+    for world in (2, 3, 8):
+        owner, nid, cuts = shard.deal_partition(w, world)
+        counts = torch.bincount(owner.long(), minlength=world)
+        assert int(counts.max() - counts.min()) <= 1 and cuts[-1] == w.numel()
+        loads = torch.zeros(world, dtype=torch.int64).index_add_(0, owner.long(), w)
+        assert float(loads.max()) / float(loads.float().mean()) < 1.02
+        assert sorted(nid.tolist()) == list(range(w.numel()))  # a permutation
+        for p in range(world):  # rank-contiguous new ids, ascending original order inside a rank
+            mine = torch.nonzero(owner == p).reshape(-1)
+            assert nid[mine].tolist() == list(range(cuts[p], cuts[p + 1]))
+    owner, nid, cuts = shard.deal_partition(w, 1)
+    assert nid.tolist() == list(range(w.numel())) and cuts == [0, w.numel()]
+    # ties are dealt by ascending id, heaviest first: weights 5 5 1 1 over 2 ranks -> snake 0 1 1 0
+    owner, _, _ = shard.deal_partition(torch.tensor([1, 5, 1, 5]), 2)
+    assert owner.tolist() == [1, 0, 0, 1]
