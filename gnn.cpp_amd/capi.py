@@ -70,6 +70,7 @@ _SIGS = {
     "gnnx_event_record": [_vp, _vp],
     "gnnx_event_sync": [_vp],
     "gnnx_event_elapsed_ms": [_vp, _vp, C.POINTER(_f32)],
+    "gnnx_stream_wait_event": [_vp, _vp],
     "gnnx_csr_from_coo_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_csr_from_coo": [_vp, _vp, _i64, _i32, _u32, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
     "gnnx_csr_from_coo_weighted_workspace": [_i64, _i32, C.POINTER(_sz)],
@@ -108,7 +109,19 @@ _SIGS = {
     "gnnx_sgd_step_f32": [_vp, _vp, _i64, _f32, _f32, _vp],
     "gnnx_comm_unique_id": [_vp],
     "gnnx_comm_init": [C.POINTER(_vp), C.c_int, C.c_int, _vp],
+    "gnnx_comm_init_local": [C.POINTER(_vp), C.c_int],
+    "gnnx_comm_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "gnnx_comm_destroy": [_vp],
+    "gnnx_vertex_weights": [_vp, _vp, _i64, _i32, _i32, _vp, _vp],
+    "gnnx_partition_deal": [_vp, _i32, C.c_int, _vp, _vp, C.POINTER(_i64), _vp],
+    "gnnx_shard_select_edges": [_vp, _vp, _i64, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, C.POINTER(_i64), _vp],
+    "gnnx_halo_plan_create": [_vp, _i64, _vp, _i32, C.c_int, C.c_int, C.POINTER(_i64), _vp, C.POINTER(_vp), _vp],
+    "gnnx_halo_plan_destroy": [_vp],
+    "gnnx_halo_plan_info": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64),
+                            C.POINTER(_vp), C.POINTER(_vp)],
+    "gnnx_halo_plan_set_send_list": [_vp, _vp, C.POINTER(_i64), _vp],
+    "gnnx_halo_plan_exchange_requests": [_vp, _vp, _vp],
+    "gnnx_halo_exchange_rows_f32": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "gnnx_halo_exchange_f32": [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _i32, _vp],
     "gnnx_allreduce_sum_f32": [_vp, _vp, _i64, _vp],
     "gnnx_gather_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],

@@ -174,3 +174,10 @@ GNNX_API int gnnx_event_elapsed_ms(void *start, void *stop, float *ms)
     GNNX_HIP_CHECK(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
     return GNNX_OK;
 }
+
+GNNX_API int gnnx_stream_wait_event(void *stream, void *event)
+{
+    GNNX_REQUIRE(event, GNNX_ERR_INVALID_ARG, "event is null");
+    GNNX_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return GNNX_OK;
+}

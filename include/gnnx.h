@@ -69,6 +69,7 @@ int gnnx_event_destroy(void *event);
 int gnnx_event_record(void *event, void *stream);
 int gnnx_event_sync(void *event);
 int gnnx_event_elapsed_ms(void *start, void *stop, float *ms);
+int gnnx_stream_wait_event(void *stream, void *event); /* work queued on `stream` after this call waits for `event` */
 
 /* ------------------------------------------------------------------ graph build ------------------ */
 /*
@@ -310,20 +311,74 @@ int gnnx_gather_rows_f32(const float *d_X, int64_t ldx, const int32_t *d_idx, in
 int gnnx_scatter_add_rows_f32(const float *d_in, int64_t ldi, const int32_t *d_idx, int64_t n_idx, int32_t n_feat,
                               float *d_Y, int64_t ldy, void *stream);
 
-/* The exchange itself, natively on RCCL (one process per GPU; librccl is bound with dlopen at first use).
- * Every rank creates the communicator from the same 128-byte id (rank 0 calls gnnx_comm_unique_id and ships it to
- * the others by whatever channel the host program has).  gnnx_halo_exchange_f32 is the all-to-all-v of the halo
- * step: rows for peer p are send_rows[p] consecutive rows of d_send (peer-major, as gnnx_gather_rows_f32 packs them
- * with the peer-major send list), rows from peer p land as recv_rows[p] consecutive rows of d_recv (the [halo] tail of
- * the feature buffer, halo ids being grouped by owner).  One group of ncclSend/ncclRecv pairs: each pair of GPUs
- * uses its own xGMI link.  send_rows / recv_rows are HOST arrays of `world` entries. */
+/* The exchange itself.  Two transports behind one handle:
+ *   RCCL  (gnnx_comm_init): one process per GPU; librccl is bound with dlopen at first use.  Every rank creates the
+ *         communicator from the same 128-byte id (rank 0 calls gnnx_comm_unique_id and ships it to the others by whatever
+ *         channel the host program has).
+ *   local (gnnx_comm_init_local): the `world` ranks are threads of ONE process; handles for all ranks are created by one call
+ *         and handed to the threads.  Collectives rendezvous on host memory and move data with device copies on each rank's
+ *         stream (they synchronise that stream).  Destroying a handle while peers wait in a collective fails their call
+ *         instead of hanging it.
+ * gnnx_halo_exchange_f32 is the all-to-all-v of the halo step: rows for peer p are send_rows[p] consecutive rows of d_send
+ * (peer-major, as gnnx_gather_rows_f32 packs them with the peer-major send list), rows from peer p land as recv_rows[p]
+ * consecutive rows of d_recv (the [halo] tail of the feature buffer, halo ids being grouped by owner).  On RCCL: one group of
+ * ncclSend/ncclRecv pairs, each pair of GPUs uses its own xGMI link; a failed Send/Recv still closes the group before the
+ * error is returned.  send_rows / recv_rows are HOST arrays of `world` entries. */
 typedef struct gnnx_comm gnnx_comm;
 int gnnx_comm_unique_id(void *id_out_128_bytes);
 int gnnx_comm_init(gnnx_comm **comm, int world, int rank, const void *id_128_bytes);
+int gnnx_comm_init_local(gnnx_comm **comms_out /* [world] */, int world);
+int gnnx_comm_info(const gnnx_comm *comm, int *world, int *rank);
 int gnnx_comm_destroy(gnnx_comm *comm);
 int gnnx_halo_exchange_f32(gnnx_comm *comm, const float *d_send, const int64_t *send_rows, float *d_recv, const int64_t *recv_rows,
                            int32_t n_feat, void *stream);
 int gnnx_allreduce_sum_f32(gnnx_comm *comm, float *d_buf, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------ partition + halo plan -------- */
+/*
+ * 1-D vertex partition and the halo plan of a shard, built on the device (SURVEY.md 8(b) `gnnx_halo_plan`, 8(e)).  The
+ * reference is a single process on a dense N x N matrix and has no counterpart; what these calls must preserve is its
+ * SUMMATION ORDER: a row's entries stay sorted by ORIGINAL column id (the CSR build sees original ids) and are renumbered
+ * value by value, so a shard's SpMM adds the same terms in the same order as the unsharded one (bit-identical rows).
+ *
+ *   gnnx_vertex_weights     w[v] = out-degree + in-degree + row_weight (the cost model: one unit per incident edge for the two
+ *                           aggregations, row_weight ~ 0.08 F for the three GEMM passes over the row).  Synchronises.
+ *   gnnx_partition_deal     vertices in stable descending-weight order (ties: ascending id) are dealt to the ranks in snake
+ *                           order (0..P-1, P-1..0, ...): every rank gets n/P +- 1 rows with the same degree mix => equal GEMM
+ *                           rows, non-zeros and per-link halo volume.  d_owner[v] = rank; d_nid[v] = new id, rank p owning the
+ *                           contiguous new-id range [cuts[p], cuts[p+1]) in ascending original id.  cuts: HOST, world+1
+ *                           entries.  world == 1 is the identity.  Synchronises.
+ *   gnnx_shard_select_edges the edges rank `rank` owns (owner[src] == rank; transpose != 0: owner[dst] == rank, roles swapped),
+ *                           self loops dropped on ORIGINAL ids: d_rows = local row id (nid - lo), d_cols = ORIGINAL column id;
+ *                           capacity n_edges each.  Feed them to gnnx_csr_from_coo (n_nodes = max(n_local, n_nodes),
+ *                           GNNX_CSR_KEEP_SELF_LOOPS: a local row id may equal an unrelated original column id).  Synchronises.
+ *   gnnx_halo_plan_create   from the shard's CSR columns (ORIGINAL ids): halo = sorted new ids of the remote columns (grouped by
+ *                           owner), d_colidx_local[p] = column in [local rows | halo rows] numbering (may alias
+ *                           d_colidx_orig), recv_rows[q] = halo rows owned by q.  Synchronises.
+ *   gnnx_halo_plan_exchange_requests  tells every owner which rows this rank reads (all-to-all of counts, then of the halo
+ *                           ids) and stores the peer-major send list; gnnx_halo_plan_set_send_list does the same from ids the
+ *                           host program moved itself (d_want_new_ids: peer-major new ids requested by the peers).
+ *   gnnx_halo_plan_info     any out pointer may be NULL; recv_rows / send_rows: HOST arrays of `world` entries; d_halo_ids /
+ *                           d_send_idx: device pointers owned by the plan.
+ *   gnnx_halo_exchange_rows_f32  the per-aggregation step: pack rows [send list] of d_buf[:n_local] into d_send_buf
+ *                           ([n_send, n_feat]) and exchange into d_buf[n_local:] (d_buf: [n_local + n_halo, n_feat]).
+ */
+typedef struct gnnx_halo_plan gnnx_halo_plan;
+int gnnx_vertex_weights(const int32_t *d_src, const int32_t *d_dst, int64_t n_edges, int32_t n_nodes, int32_t row_weight,
+                        int32_t *d_weight, void *stream);
+int gnnx_partition_deal(const int32_t *d_weight, int32_t n_nodes, int world, int32_t *d_owner, int32_t *d_nid, int64_t *cuts_out,
+                        void *stream);
+int gnnx_shard_select_edges(const int32_t *d_src, const int32_t *d_dst, int64_t n_edges, const int32_t *d_owner, const int32_t *d_nid,
+                            int rank, int64_t lo, int transpose, int32_t *d_rows, int32_t *d_cols, int64_t *n_selected, void *stream);
+int gnnx_halo_plan_create(const int32_t *d_colidx_orig, int64_t nnz, const int32_t *d_nid, int32_t n_nodes, int world, int rank,
+                          const int64_t *cuts, int32_t *d_colidx_local, gnnx_halo_plan **plan, void *stream);
+int gnnx_halo_plan_destroy(gnnx_halo_plan *plan);
+int gnnx_halo_plan_info(const gnnx_halo_plan *plan, int64_t *n_local, int64_t *n_halo, int64_t *n_send, int64_t *recv_rows,
+                        int64_t *send_rows, const int32_t **d_halo_ids, const int32_t **d_send_idx);
+int gnnx_halo_plan_set_send_list(gnnx_halo_plan *plan, const int32_t *d_want_new_ids, const int64_t *send_rows, void *stream);
+int gnnx_halo_plan_exchange_requests(gnnx_halo_plan *plan, gnnx_comm *comm, void *stream);
+int gnnx_halo_exchange_rows_f32(const gnnx_halo_plan *plan, gnnx_comm *comm, float *d_buf, int64_t ldb, int32_t n_feat,
+                                float *d_send_buf, void *stream);
 
 /* ------------------------------------------------------------------ synthetic inputs ------------- */
 /* Counter-based SplitMix64 generators, bit-identical to gnn.cpp_amd/synth.py. */

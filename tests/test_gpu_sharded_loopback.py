@@ -147,3 +147,90 @@ def test_sharded_step_equals_single_gpu(world, schedule, partition):
         assert max(nz) <= 1.1 * (sum(nz) / world)
         sends = [c for r in runners for q, c in enumerate(r.plan.fwd.send_counts) if q != r.rank]
         assert max(sends) <= 1.35 * (sum(sends) / len(sends)), "per-link send volume is unbalanced"
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_cabi_plan_equals_shard_py_plan_and_drives_a_step(world):
+    """The partition + halo plan behind the C-ABI (gnnx_vertex_weights / gnnx_partition_deal / gnnx_shard_select_edges /
+    gnnx_halo_plan_*; what the C++ host builds) equals shard.py's torch plan ARRAY FOR ARRAY, its send lists travel through
+    the in-process communicator (gnnx_comm_init_local + gnnx_halo_plan_exchange_requests), and one forward + backward
+    aggregation exchanged with gnnx_halo_exchange_rows_f32 reproduces the single-GPU rows bit for bit."""
+    import torch
+    ops = importlib.import_module("gnncpp_amd.ops")
+    shard = importlib.import_module("gnncpp_amd.shard")
+    sn = importlib.import_module("gnncpp_amd.shard_native")
+    dev = torch.device("cuda:0")
+    n, e, F, seed = 60_000, 700_000, 32, 9
+    src, dst = ops.rmat_edges(seed, n, e, device=dev)
+    g = ops.CsrGraph.from_coo(src, dst, n)
+    H = ops.uniform_pm1(seed + 1, (n, F), device=dev)
+    G = ops.uniform_pm1(seed + 2, (n, F), device=dev)
+    out_ref = ops.aggregate_fwd(g, H, None, use_plan=False)
+    dH_ref = ops.aggregate_bwd(g, G, use_plan=False)
+    torch.cuda.synchronize()
+    lw = LoopbackWorld(world)
+    comms = sn.local_comms(world)
+    errors, done = [], [None] * world
+
+    def builder(s_, d_, n_rows, n_cols):
+        rp, ci = ops.CsrGraph.csr_from_coo(s_, d_, max(n_rows, n_cols), flags=1)
+        return rp[: n_rows + 1].contiguous(), ci
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            pt = shard.ShardPlan(src, dst, n, rank, world, lw.rank_view(rank), builder, row_weight=3)
+            pn = sn.NativeShardPlan(src, dst, n, rank, world, comms[rank], row_weight=3)
+            assert pn.cuts == pt.cuts
+            assert torch.equal(pn.owner, pt.owner) and torch.equal(pn.nid, pt.nid)
+            for a, b in ((pn.fwd, pt.fwd), (pn.bwd, pt.bwd)):
+                assert a.n_local == b.n_local and a.n_halo == b.n_halo
+                assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.colidx, b.colidx)
+                assert torch.equal(a.halo(dev), b.halo.to(torch.int32))
+                assert a.recv_counts == b.recv_counts and a.send_counts == b.send_counts
+                assert torch.equal(a.send_idx(dev), b.send_idx)
+            nl = pn.n_local
+            v = pt.verts
+            norm = g.norm[v].contiguous()
+            # forward: [local | halo] buffer filled by the native exchange
+            Hext = torch.zeros((nl + pn.fwd.n_halo, F), dtype=torch.float32, device=dev)
+            Hext[:nl] = H[v]
+            sbuf = torch.empty((max(pn.fwd.n_send, pn.bwd.n_send, 1), F), dtype=torch.float32, device=dev)
+            pn.fwd.exchange_rows(comms[rank], Hext, sbuf)
+            assert torch.equal(Hext[nl:], H[pt.orig_ids(pt.fwd.halo)])
+            out = ops.spmm(pn.fwd.rowptr, pn.fwd.colidx, Hext, rowscale=norm, n_rows=nl)
+            assert torch.equal(out, out_ref[v]), "forward aggregation over the C-ABI plan is not bit-identical"
+            # backward: rows of G and the per-column norm for the transposed shard
+            Gext = torch.zeros((nl + pn.bwd.n_halo, F), dtype=torch.float32, device=dev)
+            Gext[:nl] = G[v]
+            pn.bwd.exchange_rows(comms[rank], Gext, sbuf)
+            nb = torch.zeros((nl + pn.bwd.n_halo, 1), dtype=torch.float32, device=dev)
+            nb[:nl, 0] = norm
+            sb1 = torch.empty((max(pn.bwd.n_send, 1), 1), dtype=torch.float32, device=dev)
+            pn.bwd.exchange_rows(comms[rank], nb, sb1)
+            dH = ops.spmm(pn.bwd.rowptr, pn.bwd.colidx, Gext, colscale=nb.reshape(-1).contiguous(), n_rows=nl)
+            assert torch.equal(dH, dH_ref[v]), "backward aggregation over the C-ABI plan is not bit-identical"
+            # the small all-reduce of the local transport: every rank ends with the same rank-ordered sum
+            t = torch.full((1000,), float(rank + 1), dtype=torch.float32, device=dev)
+            capi = importlib.import_module("gnncpp_amd.capi")
+            capi.call("gnnx_allreduce_sum_f32", comms[rank], ops._ptr(t), t.numel(), ops._stream())
+            assert bool((t == world * (world + 1) / 2).all())
+            torch.cuda.synchronize()
+            done[rank] = True
+        except Exception:  # noqa: BLE001
+            import traceback
+            errors.append(traceback.format_exc())
+            lw.bar.abort()
+            sn.comm_destroy(comms[rank])  # peers blocked in a collective get an error instead of hanging
+            comms[rank] = None
+
+    threads = [threading.Thread(target=rank_main, args=(k,)) for k in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    for c in comms:
+        if c is not None:
+            sn.comm_destroy(c)
+    assert not errors, errors[0]
+    assert all(done)
