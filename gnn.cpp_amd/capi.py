@@ -73,6 +73,7 @@ _SIGS = {
     "gnnx_stream_wait_event": [_vp, _vp],
     "gnnx_csr_from_coo_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_csr_from_coo": [_vp, _vp, _i64, _i32, _u32, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
+    "gnnx_equal_i32": [_vp, _vp, _i64, C.POINTER(C.c_int), _vp],
     "gnnx_csr_from_coo_weighted_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_csr_from_coo_weighted": [_vp, _vp, _vp, _i64, _i32, _u32, C.c_int, _f32, _vp, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
     "gnnx_degree_norm_f32": [_vp, _vp, _i32, _vp, _vp, _vp, _vp],
@@ -104,6 +105,11 @@ _SIGS = {
     "gnnx_bn_relu_fwd_f32": [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp],
     "gnnx_bn_relu_bwd_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp,
                              _sz, _vp],
+    "gnnx_bn_partial_f32": [_vp, _i64, _i64, _i32, _vp, _f32, _vp, _vp, _sz, _vp],
+    "gnnx_bn_relu_bwd_sums_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _vp, _vp, _sz,
+                                  _vp],
+    "gnnx_bn_relu_bwd_apply_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _vp, _i64, _vp,
+                                   _i64, _vp, _sz, _vp],
     "gnnx_softmax_ce_workspace": [_i64, C.POINTER(_sz)],
     "gnnx_softmax_ce_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _sz, _vp],
     "gnnx_sgd_step_f32": [_vp, _vp, _i64, _f32, _f32, _vp],

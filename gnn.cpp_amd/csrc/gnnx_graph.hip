@@ -270,6 +270,32 @@ hipError_t plan_workspace_weighted(int64_t n_keys, char *base, CsrWorkspaceW &w)
 
 }  // namespace
 
+__global__ void differ_kernel(const int32_t *a, const int32_t *b, int64_t n, int32_t *differ)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) *differ = 1;  // same value from every writer
+}
+
+GNNX_API int gnnx_equal_i32(const int32_t *d_a, const int32_t *d_b, int64_t n, int *equal_out, void *stream)
+{
+    GNNX_REQUIRE(equal_out && n >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    *equal_out = 1;
+    if (n == 0 || d_a == d_b) return GNNX_OK;
+    GNNX_REQUIRE(d_a && d_b, GNNX_ERR_INVALID_ARG, "null pointer");
+    hipStream_t st = as_stream(stream);
+    int32_t *flag = nullptr;
+    GNNX_HIP_CHECK(hipMallocAsync((void **)&flag, sizeof(int32_t), st));
+    GNNX_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(differ_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, st, d_a, d_b, n, flag);
+    GNNX_LAUNCH_CHECK();
+    int32_t h = 0;
+    GNNX_HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipFreeAsync(flag, st));
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    *equal_out = h ? 0 : 1;
+    return GNNX_OK;
+}
+
 GNNX_API int gnnx_csr_from_coo_workspace(int64_t n_edges, int32_t n_nodes, size_t *bytes)
 {
     GNNX_REQUIRE(bytes && n_edges >= 0 && n_nodes >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
@@ -412,7 +438,8 @@ GNNX_API int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_coli
         GNNX_LAUNCH_CHECK();
     }
     if (d_norm) {
-        GNNX_REQUIRE(d_colidx || true, GNNX_ERR_INVALID_ARG, "colidx is null");
+        // colidx may only be null for a graph without entries: the kernels never dereference it then
+        GNNX_REQUIRE(d_colidx || n_rows == 0, GNNX_ERR_INVALID_ARG, "colidx is null");
         // rows' own s: d_s when written here, else the caller's column-indexed vector is also row-indexed
         const float *s_rows = d_s ? d_s : d_s_cols;
         const float *s_cols = d_s_cols ? d_s_cols : d_s;

@@ -149,10 +149,9 @@ __global__ __launch_bounds__(256) void rstd_kernel(const float *var, float eps, 
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t ldd,
                                                       int64_t n_rows, int32_t n_feat, const float *mean, const float *rstd,
                                                       const float *gamma, const float *dbeta, const float *dgamma, int relu, float *dX,
-                                                      int64_t ldo, const float *var, const float *beta, float eps)
+                                                      int64_t ldo, const float *var, const float *beta, float eps, float inv_n)
 {
     int64_t total = n_rows * n_feat;
-    const float inv_n = 1.0f / (float)n_rows;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         int64_t r = i / n_feat;
         int32_t f = (int32_t)(i - r * n_feat);
@@ -239,38 +238,94 @@ GNNX_API int gnnx_bn_relu_fwd_f32(const float *d_X, int64_t ldx, int64_t n_rows,
     return GNNX_OK;
 }
 
+// cross-shard form of the statistics: out[f] = scale * sum_i x_if (d_mean == NULL) or scale * sum_i (x_if - mean_f)^2; a sharded
+// BatchNorm all-reduces these [F] vectors with scale = 1 / N_global (mean first, then the centred squares against the GLOBAL mean:
+// the same exact two-pass variance as gnnx_bn_stats_f32)
+GNNX_API int gnnx_bn_partial_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const float *d_mean, float scale,
+                                 float *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_feat > 0, GNNX_ERR_INVALID_ARG, "bad sizes");
+    GNNX_REQUIRE(d_out && (n_rows == 0 || d_X) && ldx >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    size_t need = 0;
+    gnnx_bn_workspace(n_rows, n_feat, &need);
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    float *ws = static_cast<float *>(d_workspace);
+    if (d_mean) return reduce(OpSqDev{d_X, ldx, d_mean}, n_rows, n_feat, scale, d_out, nullptr, ws, st);
+    return reduce(OpIdent{d_X, ldx}, n_rows, n_feat, scale, d_out, nullptr, ws, st);
+}
+
+static int bn_bwd_check(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd, int64_t n_rows,
+                        int32_t n_feat, const float *d_mean, const float *d_var, void *d_workspace, size_t workspace_bytes)
+{
+    GNNX_REQUIRE(n_rows > 0 && n_feat > 0, GNNX_ERR_INVALID_ARG, "empty batch");
+    GNNX_REQUIRE(d_X && d_dY && ldx >= n_feat && ldd >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld");
+    GNNX_REQUIRE(!d_Y || ldy >= n_feat, GNNX_ERR_INVALID_ARG, "ldy < n_feat");
+    GNNX_REQUIRE((d_mean == nullptr) == (d_var == nullptr), GNNX_ERR_INVALID_ARG, "mean and var go together");
+    if (d_mean) {
+        size_t need = 0;
+        gnnx_bn_workspace(n_rows, n_feat, &need);
+        GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+    }
+    return GNNX_OK;
+}
+
+// the two halves of gnnx_bn_relu_bwd_f32, separable so that a sharded BatchNorm can all-reduce dgamma / dbeta in between:
+//   sums : d_dbeta = sum_i g_i, d_dgamma = sum_i g_i * xhat_i over THIS call's rows
+//   apply: dX = gamma / sigma * (g - dbeta / n_total - xhat * dgamma / n_total) with the (global) sums and row count handed in
+GNNX_API int gnnx_bn_relu_bwd_sums_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
+                                       int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps,
+                                       const float *d_gamma, const float *d_beta, int relu, float *d_dgamma, float *d_dbeta,
+                                       void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = bn_bwd_check(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, d_var, d_workspace, workspace_bytes);
+    if (rc) return rc;
+    GNNX_REQUIRE(d_mean && d_dgamma && d_dbeta, GNNX_ERR_INVALID_ARG, "statistics and dgamma / dbeta outputs are required");
+    hipStream_t st = as_stream(stream);
+    float *ws = static_cast<float *>(d_workspace);
+    float *rstd = ws + (size_t)2 * n_blocks_for(n_rows) * n_feat;
+    hipLaunchKernelGGL(rstd_kernel, dim3((uint32_t)ceil_div(n_feat, 256)), dim3(256), 0, st, d_var, eps, n_feat, rstd);
+    GNNX_LAUNCH_CHECK();
+    return reduce(OpBnBwd{d_X, d_Y, d_dY, d_mean, rstd, ldx, ldy, ldd, relu, d_var, d_gamma, d_beta, eps}, n_rows, n_feat, 1.0f, d_dbeta,
+                  d_dgamma, ws, st);
+}
+
+GNNX_API int gnnx_bn_relu_bwd_apply_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
+                                        int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps,
+                                        const float *d_gamma, const float *d_beta, int relu, const float *d_dgamma, const float *d_dbeta,
+                                        int64_t n_total, float *d_dX, int64_t ldo, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    int rc = bn_bwd_check(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, d_var, d_workspace, workspace_bytes);
+    if (rc) return rc;
+    GNNX_REQUIRE(d_dX && ldo >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld");
+    GNNX_REQUIRE(!d_mean || (d_dgamma && d_dbeta && n_total >= n_rows), GNNX_ERR_INVALID_ARG, "dgamma / dbeta sums and n_total are required");
+    hipStream_t st = as_stream(stream);
+    int64_t blocks = ceil_div(n_rows * n_feat, 256);
+    if (blocks > 4096) blocks = 4096;
+    const float *rstd = nullptr;
+    if (d_mean) {
+        float *ws = static_cast<float *>(d_workspace);
+        float *r = ws + (size_t)2 * n_blocks_for(n_rows) * n_feat;
+        hipLaunchKernelGGL(rstd_kernel, dim3((uint32_t)ceil_div(n_feat, 256)), dim3(256), 0, st, d_var, eps, n_feat, r);
+        GNNX_LAUNCH_CHECK();
+        rstd = r;
+    }
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, rstd,
+                       d_gamma, d_dbeta, d_dgamma, relu, d_dX, ldo, d_var, d_beta, eps, d_mean ? 1.0f / (float)n_total : 0.f);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
 GNNX_API int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
                                   int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps,
                                   const float *d_gamma, const float *d_beta, int relu, float *d_dX, int64_t ldo, float *d_dgamma,
                                   float *d_dbeta, void *d_workspace, size_t workspace_bytes, void *stream)
 {
-    GNNX_REQUIRE(n_rows > 0 && n_feat > 0, GNNX_ERR_INVALID_ARG, "empty batch");
-    GNNX_REQUIRE(d_X && d_dY && d_dX && ldx >= n_feat && ldd >= n_feat && ldo >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld");
-    GNNX_REQUIRE(!d_Y || ldy >= n_feat, GNNX_ERR_INVALID_ARG, "ldy < n_feat");
-    GNNX_REQUIRE((d_mean == nullptr) == (d_var == nullptr), GNNX_ERR_INVALID_ARG, "mean and var go together");
-    hipStream_t st = as_stream(stream);
-    int64_t blocks = ceil_div(n_rows * n_feat, 256);
-    if (blocks > 4096) blocks = 4096;
-    if (!d_mean) {  // ReLU only
-        hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat,
-                           (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr,
-                           (const float *)nullptr, relu, d_dX, ldo, (const float *)nullptr, (const float *)nullptr, 0.f);
-        GNNX_LAUNCH_CHECK();
-        return GNNX_OK;
+    if (d_mean) {
+        int rc = gnnx_bn_relu_bwd_sums_f32(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, d_var, eps, d_gamma, d_beta, relu, d_dgamma,
+                                           d_dbeta, d_workspace, workspace_bytes, stream);
+        if (rc) return rc;
     }
-    GNNX_REQUIRE(d_dgamma && d_dbeta, GNNX_ERR_INVALID_ARG, "dgamma / dbeta outputs are required");
-    size_t need = 0;
-    gnnx_bn_workspace(n_rows, n_feat, &need);
-    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
-    float *ws = static_cast<float *>(d_workspace);
-    float *rstd = ws + (size_t)2 * n_blocks_for(n_rows) * n_feat;
-    hipLaunchKernelGGL(rstd_kernel, dim3((uint32_t)ceil_div(n_feat, 256)), dim3(256), 0, st, d_var, eps, n_feat, rstd);
-    GNNX_LAUNCH_CHECK();
-    int rc = reduce(OpBnBwd{d_X, d_Y, d_dY, d_mean, rstd, ldx, ldy, ldd, relu, d_var, d_gamma, d_beta, eps}, n_rows, n_feat, 1.0f, d_dbeta,
-                    d_dgamma, ws, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean,
-                       (const float *)rstd, d_gamma, (const float *)d_dbeta, (const float *)d_dgamma, relu, d_dX, ldo, d_var, d_beta, eps);
-    GNNX_LAUNCH_CHECK();
-    return GNNX_OK;
+    return gnnx_bn_relu_bwd_apply_f32(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, d_var, eps, d_gamma, d_beta, relu, d_dgamma,
+                                      d_dbeta, n_rows, d_dX, ldo, d_workspace, workspace_bytes, stream);
 }

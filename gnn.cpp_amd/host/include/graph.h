@@ -19,6 +19,8 @@
 
 namespace graph {
 
+class Partition;  // dist.h
+
 typedef enum DataType { TRAIN, VAL, TEST } DataType;
 
 cyg::tptr<int> vec_to_edge_list(std::vector<int> source, std::vector<int> destination);
@@ -79,7 +81,12 @@ public:
     // same Data (a static graph is built once, not three times per forward).  false: op by op through the generic
     // tensor ops (MatMul, Mul, Add), exactly the reference's sequence; both give the same bits.
     bool fused = true;
-    void invalidate_graph_cache() { _cache_key = nullptr; }
+    void invalidate_graph_cache() { _cache_adj.reset(); }
+    // Multi-GPU (dist.h): after shard(), forward(Data) takes THIS RANK's rows of x ([Partition::num_local(), F_in], Data built
+    // without an edge_index -- the partition holds the graph) and returns this rank's rows of the layer output; backward leaves
+    // LOCAL partial sums in the parameter gradients until allreduce_gradients() sums them over the ranks.
+    void shard(std::shared_ptr<Partition> part);
+    void allreduce_gradients();
     // false (default): the reference's full layer, transform -> BatchNorm -> ReLU -> aggregation -> bias.
     // true: only the hot path of BASELINE.json (transform -> aggregation -> bias).
     bool hot_path_only = false;
@@ -87,9 +94,10 @@ public:
     float _dropout;
 
 private:
-    const void *_cache_key = nullptr;  // identity of the edge_index tensor the cache was built from
     size_t _cache_edges = 0, _cache_nodes = 0;
-    cyg::tptr<float> _cache_adj, _cache_norm;
+    cyg::tptr<float> _cache_adj, _cache_norm;  // _cache_adj's Csr keeps the COO it was built from: the cache key (content)
+    std::shared_ptr<Partition> _part;
+    cyg::tptr<float> forward_sharded(const cyg::tptr<float> &x_local);
 };
 
 }  // namespace graph

@@ -360,6 +360,14 @@ public:
         return h;
     }
     float *device_grad() { return _grad ? _grad->d() : nullptr; }
+    // the gradient buffer about to be updated in place by the backend (all-reduce over the ranks): a host copy goes stale
+    float *device_grad_inplace()
+    {
+        if (!_grad) return nullptr;
+        float *p = _grad->d();
+        _grad->host_ok = false;
+        return p;
+    }
 
     void requires_grad_(bool requires_grad)
     {

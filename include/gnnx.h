@@ -95,6 +95,11 @@ int gnnx_csr_from_coo(const int32_t *d_src, const int32_t *d_dst, int64_t n_edge
                       int32_t *d_rowptr, int32_t *d_colidx, int64_t *nnz_out, void *d_workspace,
                       size_t workspace_bytes, void *stream);
 
+/* *equal_out = 1 iff the two device arrays hold the same n int32 values (synchronises `stream`).  The host layer compares an
+ * incoming edge_index with the copy its cached adjacency was built from, so an edge list edited in place -- or a new one that
+ * happens to be allocated at the old address -- never hits a stale CSR / norm. */
+int gnnx_equal_i32(const int32_t *d_a, const int32_t *d_b, int64_t n, int *equal_out, void *stream);
+
 /* Weighted adjacency (edge_attr, reference graph.h:35): A[r][c] = w by assignment, so of duplicate (r, c) pairs the LAST one
  * in the list wins (edge_to_adj_mat, graph.cpp:38-40).  diag_mode:
  *   GNNX_DIAG_KEEP   self loops stay as given                         (edge_to_adj_mat alone)
@@ -287,6 +292,22 @@ int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_
                          int32_t n_feat, const float *d_mean, const float *d_var, float eps, const float *d_gamma, const float *d_beta,
                          int relu, float *d_dX, int64_t ldo, float *d_dgamma, float *d_dbeta, void *d_workspace,
                          size_t workspace_bytes, void *stream);
+/* Cross-shard BatchNorm: the batch is the whole graph, a rank holds n_rows of its n_total rows.
+ *   partial : d_out[f] = scale * sum_i x_if (d_mean == NULL), or scale * sum_i (x_if - d_mean[f])^2.  With scale = 1 / n_total an
+ *             all-reduce of the first gives the global mean, then an all-reduce of the second (against the GLOBAL mean) the global
+ *             biased variance: the exact two-pass arithmetic of gnnx_bn_stats_f32, two [F] vectors on the wire per layer.
+ *   bwd_sums / bwd_apply : the two halves of gnnx_bn_relu_bwd_f32 -- local dgamma / dbeta sums, then (after the caller's
+ *             all-reduce of those two [F] vectors) dX with the global sums and n_total. */
+int gnnx_bn_partial_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const float *d_mean, float scale, float *d_out,
+                        void *d_workspace, size_t workspace_bytes, void *stream);
+int gnnx_bn_relu_bwd_sums_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
+                              int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps, const float *d_gamma,
+                              const float *d_beta, int relu, float *d_dgamma, float *d_dbeta, void *d_workspace, size_t workspace_bytes,
+                              void *stream);
+int gnnx_bn_relu_bwd_apply_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
+                               int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps, const float *d_gamma,
+                               const float *d_beta, int relu, const float *d_dgamma, const float *d_dbeta, int64_t n_total, float *d_dX,
+                               int64_t ldo, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ next row: loss + optimiser ---- */
 /*

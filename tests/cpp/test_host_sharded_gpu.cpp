@@ -1,0 +1,284 @@
+// GPU test of the sharded graph layer of the C++ API (gnn.cpp_amd/host/include/dist.h): P ranks run as THREADS of this
+// process over the in-process communicator (dist::Comm::local_group), each building its graph::Partition and running
+// `layer(data)` / `out->backward(G)` / `layer.allreduce_gradients()` on its rows, exactly as a one-process-per-GPU job
+// would over RCCL.  Compared with the unsharded layer on the whole graph:
+//   * hot path (transform -> aggregation -> bias) and the reference's full layer (-> BatchNorm -> ReLU ->, batch statistics
+//     all-reduced across the shards): output rows and dX rows within 1e-5 * max(1, |ref|);
+//   * parameter gradients (W, bias, gammas, betas) after the all-reduce: max-norm within 1e-5 (sums over all nodes in a
+//     different order).
+// Also covers the ADVICE item on the graph cache: an edge_index edited in place, or replaced by one of the same size, must
+// not hit the cached adjacency.
+#include <cmath>
+#include <cstdio>
+#include <thread>
+#include <valarray>
+#include <vector>
+
+#include "dist.h"
+#include "graph.h"
+#include "nn.h"
+#include "tensor.h"
+
+using namespace cyg;
+using namespace std;
+
+static int failures = 0;
+#define CHECK(cond)                                                          \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);          \
+            failures++;                                                      \
+        }                                                                    \
+    } while (0)
+
+struct Rng {
+    uint64_t s;
+    explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 1) {}
+    uint64_t next()
+    {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        return s;
+    }
+    float uni() { return (float)((next() >> 40) * (1.0 / 16777216.0)); }            // [0,1)
+    float pm1() { return uni() * 2.0f - 1.0f; }
+};
+
+struct Problem {
+    size_t n, e, fin, fout;
+    vector<int> src, dst;
+    valarray<float> X, W, bias, gamma, beta, G;
+};
+
+static Problem make_problem(size_t n, size_t e, size_t fin, size_t fout)
+{
+    Problem p{n, e, fin, fout, {}, {}, valarray<float>(n * fin), valarray<float>(fout * fin), valarray<float>(fout), valarray<float>(fout),
+              valarray<float>(fout), valarray<float>(n * fout)};
+    Rng r(7);
+    for (size_t i = 0; i < e; i++) {  // skewed endpoints: a few hubs, many leaves, duplicates and self loops included
+        float u = r.uni(), v = r.uni();
+        p.src.push_back((int)(n * u * u * u));
+        p.dst.push_back((int)(n * v * v));
+    }
+    for (auto &v : p.X) v = r.pm1();
+    for (auto &v : p.W) v = r.pm1() / sqrtf((float)fin);
+    for (auto &v : p.bias) v = 0.5f * r.pm1();
+    for (auto &v : p.gamma) v = 1.0f + 0.25f * r.pm1();
+    for (auto &v : p.beta) v = 0.1f * r.pm1();
+    for (auto &v : p.G) v = r.pm1();
+    return p;
+}
+
+static void set_params(graph::GCNConv &layer, const Problem &p)
+{
+    auto w = p.W, b = p.bias, ga = p.gamma, be = p.beta;
+    layer.get_parameter("weight")->set_data(&w);
+    layer.get_parameter("bias")->set_data(&b);
+    layer.get_parameter("gammas")->set_data(&ga);
+    layer.get_parameter("betas")->set_data(&be);
+}
+
+struct Result {
+    valarray<float> out, dx, dw, dbias, dgamma, dbeta;
+};
+
+static Result run_unsharded(const Problem &p, bool hot_path_only)
+{
+    auto ei = graph::vec_to_edge_list(p.src, p.dst);
+    auto x = make_shared<tensor<float>>(vector<size_t>{p.n, p.fin}, new valarray<float>(p.X), true);
+    graph::GCNConv layer(p.fin, p.fout);
+    layer.hot_path_only = hot_path_only;
+    set_params(layer, p);
+    graph::Data data(x, ei.get());
+    auto out = layer(data);
+    auto g = make_shared<tensor<float>>(vector<size_t>{p.n, p.fout}, new valarray<float>(p.G), false);
+    out->backward(g);
+    Result r;
+    r.out = *out->data();
+    r.dx = *x->grad();
+    r.dw = *layer.get_parameter("weight")->grad();
+    r.dbias = *layer.get_parameter("bias")->grad();
+    if (!hot_path_only) {
+        r.dgamma = *layer.get_parameter("gammas")->grad();
+        r.dbeta = *layer.get_parameter("betas")->grad();
+    }
+    return r;
+}
+
+static float max_abs(const valarray<float> &a)
+{
+    float m = 0.f;
+    for (float v : a) m = fmaxf(m, fabsf(v));
+    return m;
+}
+
+static void run_sharded(const Problem &p, bool hot_path_only, int world, const Result &ref)
+{
+    auto comms = dist::Comm::local_group(world);
+    vector<string> errors((size_t)world);
+    vector<int> covered(p.n, 0);
+    vector<float> worst_out((size_t)world, 0.f), worst_dx((size_t)world, 0.f);
+    vector<Result> res((size_t)world);
+    vector<thread> th;
+    for (int rank = 0; rank < world; rank++) {
+        th.emplace_back([&, rank] {
+            try {
+                auto ei = graph::vec_to_edge_list(p.src, p.dst);
+                auto part = make_shared<graph::Partition>(*ei, p.n, comms[rank], 3);
+                auto verts = part->local_vertices();
+                const size_t nl = verts.size();
+                auto *xl = new valarray<float>(nl * p.fin);
+                auto *gl = new valarray<float>(nl * p.fout);
+                for (size_t i = 0; i < nl; i++) {
+                    for (size_t f = 0; f < p.fin; f++) (*xl)[i * p.fin + f] = p.X[(size_t)verts[i] * p.fin + f];
+                    for (size_t f = 0; f < p.fout; f++) (*gl)[i * p.fout + f] = p.G[(size_t)verts[i] * p.fout + f];
+                }
+                auto x = make_shared<tensor<float>>(vector<size_t>{nl, p.fin}, xl, true);
+                auto g = make_shared<tensor<float>>(vector<size_t>{nl, p.fout}, gl, false);
+                graph::GCNConv layer(p.fin, p.fout);
+                layer.hot_path_only = hot_path_only;
+                set_params(layer, p);
+                layer.shard(part);
+                graph::Data data(x);  // this rank's rows; the partition holds the graph
+                auto out = layer(data);
+                out->backward(g);
+                layer.allreduce_gradients();
+                auto o = *out->data();
+                auto dx = *x->grad();
+                for (size_t i = 0; i < nl; i++) {
+                    for (size_t f = 0; f < p.fout; f++) {
+                        const float a = o[i * p.fout + f], b = ref.out[(size_t)verts[i] * p.fout + f];
+                        worst_out[rank] = fmaxf(worst_out[rank], fabsf(a - b) / fmaxf(1.f, fabsf(b)));
+                    }
+                    for (size_t f = 0; f < p.fin; f++) {
+                        const float a = dx[i * p.fin + f], b = ref.dx[(size_t)verts[i] * p.fin + f];
+                        worst_dx[rank] = fmaxf(worst_dx[rank], fabsf(a - b) / fmaxf(1.f, fabsf(b)));
+                    }
+                }
+                for (int v : verts) covered[(size_t)v]++;  // disjoint index sets per rank
+                res[rank].dw = *layer.get_parameter("weight")->grad();
+                res[rank].dbias = *layer.get_parameter("bias")->grad();
+                if (!hot_path_only) {
+                    res[rank].dgamma = *layer.get_parameter("gammas")->grad();
+                    res[rank].dbeta = *layer.get_parameter("betas")->grad();
+                }
+                // take_rows gathers the same rows on the device
+                auto full = make_shared<tensor<float>>(vector<size_t>{p.n, p.fin}, new valarray<float>(p.X), false);
+                auto mine = part->take_rows(full);
+                auto mv = *mine->data();
+                bool same = mv.size() == xl->size();
+                for (size_t i = 0; same && i < mv.size(); i++) same = mv[i] == (*xl)[i];
+                if (!same) errors[rank] = "take_rows differs from the host gather";
+            } catch (const std::exception &ex) {
+                errors[rank] = ex.what();
+                comms[rank].reset();  // peers blocked in a collective fail instead of hanging
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int r = 0; r < world; r++) {
+        if (!errors[r].empty()) {
+            printf("FAIL world %d rank %d: %s\n", world, r, errors[r].c_str());
+            failures++;
+        }
+    }
+    if (failures) return;
+    bool once = true;
+    for (int c : covered) once = once && c == 1;
+    CHECK(once);
+    auto close_norm = [](const valarray<float> &a, const valarray<float> &b) {
+        if (a.size() != b.size()) return false;
+        const float tol = 1e-5f * fmaxf(1.f, max_abs(b));
+        for (size_t i = 0; i < a.size(); i++)
+            if (!(fabsf(a[i] - b[i]) <= tol)) return false;
+        return true;
+    };
+    for (int r = 0; r < world; r++) {
+        if (!(worst_out[r] <= 1e-5f)) printf("world %d rank %d: out off by %.3e\n", world, r, worst_out[r]);
+        if (!(worst_dx[r] <= 1e-5f)) printf("world %d rank %d: dx off by %.3e\n", world, r, worst_dx[r]);
+        CHECK(worst_out[r] <= 1e-5f);
+        CHECK(worst_dx[r] <= 1e-5f);
+        CHECK(close_norm(res[r].dw, ref.dw));
+        CHECK(close_norm(res[r].dbias, ref.dbias));
+        if (!hot_path_only) {
+            CHECK(close_norm(res[r].dgamma, ref.dgamma));
+            CHECK(close_norm(res[r].dbeta, ref.dbeta));
+        }
+    }
+}
+
+// the static-graph cache of GCNConv::forward must be keyed on content
+static void test_graph_cache_is_keyed_on_content()
+{
+    const size_t n = 6, f = 3;
+    vector<int> s1 = {0, 1, 2, 3, 4}, d1 = {1, 2, 3, 4, 5}, s2 = {0, 0, 0, 0, 0}, d2 = {1, 2, 3, 4, 5};
+    valarray<float> xv(n * f);
+    for (size_t i = 0; i < xv.size(); i++) xv[i] = (float)(i % 7) - 3.0f;
+    auto fresh = [&](const vector<int> &s, const vector<int> &d) {
+        graph::GCNConv layer(f, f);
+        layer.hot_path_only = true;
+        valarray<float> w(0.f, f * f);
+        for (size_t i = 0; i < f; i++) w[i * f + i] = 1.0f;
+        layer.get_parameter("weight")->set_data(&w);
+        auto ei = graph::vec_to_edge_list(s, d);
+        auto x = make_shared<tensor<float>>(vector<size_t>{n, f}, new valarray<float>(xv), false);
+        graph::Data data(x, ei.get());
+        return valarray<float>(*layer(data)->data());
+    };
+    const auto want1 = fresh(s1, d1), want2 = fresh(s2, d2);
+    bool differ = false;
+    for (size_t i = 0; i < want1.size(); i++) differ = differ || want1[i] != want2[i];
+    CHECK(differ);
+    graph::GCNConv layer(f, f);
+    layer.hot_path_only = true;
+    valarray<float> w(0.f, f * f);
+    for (size_t i = 0; i < f; i++) w[i * f + i] = 1.0f;
+    layer.get_parameter("weight")->set_data(&w);
+    auto ei = graph::vec_to_edge_list(s1, d1);
+    auto x = make_shared<tensor<float>>(vector<size_t>{n, f}, new valarray<float>(xv), false);
+    graph::Data data(x, ei.get());
+    auto eq = [](const valarray<float> &a, const valarray<float> &b) {
+        bool same = a.size() == b.size();
+        for (size_t i = 0; same && i < a.size(); i++) same = a[i] == b[i];
+        return same;
+    };
+    CHECK(eq(*layer(data)->data(), want1));
+    CHECK(eq(*layer(data)->data(), want1));  // second call: cache hit, same result
+    // (a) edited in place: same tensor object, same size, new content
+    auto *raw = ei->data();
+    for (size_t i = 0; i < s2.size(); i++) {
+        (*raw)[i] = s2[i];
+        (*raw)[s2.size() + i] = d2[i];
+    }
+    CHECK(eq(*layer(data)->data(), want2));
+    // (b) a different tensor of the same size (address reuse would look like this to a pointer key)
+    auto ei3 = graph::vec_to_edge_list(s1, d1);
+    data.set_edge_index(ei3.get());
+    CHECK(eq(*layer(data)->data(), want1));
+}
+
+int main()
+{
+    try {
+        test_graph_cache_is_keyed_on_content();
+        const Problem p = make_problem(20000, 240000, 48, 32);
+        for (bool hot : {true, false}) {
+            const Result ref = run_unsharded(p, hot);
+            for (int world : {2, 4}) run_sharded(p, hot, world, ref);
+        }
+        // more ranks than structure: 40 nodes over 8 ranks, some peers exchange nothing
+        const Problem tiny = make_problem(40, 90, 5, 4);
+        const Result tref = run_unsharded(tiny, false);
+        run_sharded(tiny, false, 8, tref);
+    } catch (const std::exception &e) {
+        printf("FAIL threw: %s\n", e.what());
+        failures++;
+    }
+    if (failures) {
+        printf("%d FAILURES\n", failures);
+        return 1;
+    }
+    printf("SHARDED_HOST_OK\n");
+    return 0;
+}

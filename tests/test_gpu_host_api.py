@@ -123,3 +123,14 @@ def test_edge_attr_forms_of_the_graph_functions(name):
     for key in ("w_fill", "w_strip"):
         assert np.array_equal(got[key + "_ei"], d["ref_" + key + "_ei"]), key
         assert same(got[key + "_ea"], d["ref_" + key + "_ea"]), key
+
+
+def test_sharded_layer_through_the_cpp_api():
+    """tests/cpp/test_host_sharded_gpu.cpp: graph::Partition + GCNConv::shard() with P = 2, 4, 8 ranks as threads over the
+    in-process communicator (the C-ABI's gnnx_partition_deal / gnnx_halo_plan_* / gnnx_halo_exchange_rows_f32 underneath)
+    against the unsharded layer -- hot path and the full BatchNorm + ReLU layer with cross-shard statistics -- and the
+    content-keyed graph cache."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_host_sharded_gpu")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("SHARDED_HOST_OK"), r.stdout[-3000:] + r.stderr[-3000:]
