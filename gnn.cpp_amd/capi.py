@@ -105,6 +105,8 @@ _SIGS = {
     "gnnx_bn_relu_fwd_f32": [_vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp],
     "gnnx_bn_relu_bwd_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp,
                              _sz, _vp],
+    "gnnx_bn_relu_bwd_quirk_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _i64, _vp, _vp, _vp,
+                                   _sz, _vp],
     "gnnx_bn_partial_f32": [_vp, _i64, _i64, _i32, _vp, _f32, _vp, _vp, _sz, _vp],
     "gnnx_bn_relu_bwd_sums_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _vp, _vp, _sz,
                                   _vp],

@@ -438,8 +438,12 @@ GNNX_API int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_coli
         GNNX_LAUNCH_CHECK();
     }
     if (d_norm) {
-        // colidx may only be null for a graph without entries: the kernels never dereference it then
-        GNNX_REQUIRE(d_colidx || n_rows == 0, GNNX_ERR_INVALID_ARG, "colidx is null");
+        if (!d_colidx) {  // only a graph without entries may come without colidx (once-per-graph call: the sync is fine)
+            int32_t h_nnz = 0;
+            GNNX_HIP_CHECK(hipMemcpyAsync(&h_nnz, d_rowptr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            GNNX_HIP_CHECK(hipStreamSynchronize(st));
+            GNNX_REQUIRE(h_nnz == 0, GNNX_ERR_INVALID_ARG, "colidx is null but the graph has %d entries", h_nnz);
+        }
         // rows' own s: d_s when written here, else the caller's column-indexed vector is also row-indexed
         const float *s_rows = d_s ? d_s : d_s_cols;
         const float *s_cols = d_s_cols ? d_s_cols : d_s;

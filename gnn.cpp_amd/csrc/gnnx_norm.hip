@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void rstd_kernel(const float *var, float eps, 
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t ldd,
                                                       int64_t n_rows, int32_t n_feat, const float *mean, const float *rstd,
                                                       const float *gamma, const float *dbeta, const float *dgamma, int relu, float *dX,
-                                                      int64_t ldo, const float *var, const float *beta, float eps, float inv_n)
+                                                      int64_t ldo, const float *var, const float *beta, float eps, float inv_n,
+                                                      int quirk)
 {
     int64_t total = n_rows * n_feat;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -158,7 +159,13 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *X, int64_t ldx
         float g = dY[r * ldd + f];
         const float x = X[r * ldx + f];
         if (relu && !relu_passed(Y, r * ldy + f, x, f, mean, var, eps, gamma, beta)) g = 0.f;
-        if (mean) {
+        if (mean && quirk) {
+            // what reaches the transform in the REFERENCE: only the first arrival at BatchNorm's input, the direct path
+            // Mul::_backward (g * gammas, operation.h:159-164) -> Div::_backward (/ (var + eps)^0.5, operation.h:192-198); the
+            // arrivals through mean and var find the transform's op already done and are dropped (operation.h:80-88)
+            if (gamma) g = __fmul_rn(g, gamma[f]);
+            g = __fdiv_rn(g, sqrtf(__fadd_rn(var[f], eps)));
+        } else if (mean) {
             float xhat = (x - mean[f]) * rstd[f];
             float gm = gamma ? gamma[f] : 1.f;
             g = gm * rstd[f] * (g - dbeta[f] * inv_n - xhat * dgamma[f] * inv_n);
@@ -311,7 +318,31 @@ GNNX_API int gnnx_bn_relu_bwd_apply_f32(const float *d_X, int64_t ldx, const flo
         rstd = r;
     }
     hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, rstd,
-                       d_gamma, d_dbeta, d_dgamma, relu, d_dX, ldo, d_var, d_beta, eps, d_mean ? 1.0f / (float)n_total : 0.f);
+                       d_gamma, d_dbeta, d_dgamma, relu, d_dX, ldo, d_var, d_beta, eps, d_mean ? 1.0f / (float)n_total : 0.f, 0);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+// OPT-IN "reference-quirk" backward: dgamma / dbeta as usual, but dX = (g * gamma) / (var + eps)^0.5 --
+// the batch statistics treated as constants, which is what the reference's traversal delivers (see bn_bwd_kernel).  Only for
+// comparing gradients with the reference's own; never the default.
+GNNX_API int gnnx_bn_relu_bwd_quirk_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
+                                        int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps,
+                                        const float *d_gamma, const float *d_beta, int relu, float *d_dX, int64_t ldo, float *d_dgamma,
+                                        float *d_dbeta, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(d_mean && d_var, GNNX_ERR_INVALID_ARG, "the quirk form is about BatchNorm: statistics are required");
+    int rc = gnnx_bn_relu_bwd_sums_f32(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, d_var, eps, d_gamma, d_beta, relu, d_dgamma,
+                                       d_dbeta, d_workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    rc = bn_bwd_check(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, d_var, d_workspace, workspace_bytes);
+    if (rc) return rc;
+    GNNX_REQUIRE(d_dX && ldo >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld");
+    int64_t blocks = ceil_div(n_rows * n_feat, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat,
+                       d_mean, (const float *)nullptr, d_gamma, (const float *)d_dbeta, (const float *)d_dgamma, relu, d_dX, ldo, d_var,
+                       d_beta, eps, 0.f, 1);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }

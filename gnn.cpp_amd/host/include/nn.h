@@ -74,6 +74,9 @@ public:
     bool _affine, _tracking_running_stats;
 };
 
+// gnnx_bn_relu_bwd_f32, or its reference-quirk form when GNNCPP_REFERENCE_QUIRKS is set (see host.cpp)
+decltype(&gnnx_bn_relu_bwd_f32) bn_backward_fn();
+
 // max(0, x) as a select (reference nn.cpp:229-237 -> functional.h:443-470)
 class ReLU : public Module {
 public:

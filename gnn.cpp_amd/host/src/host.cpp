@@ -314,6 +314,14 @@ tptr<float> Linear::forward(const tptr<float> &input_tensor)
 
 // ---- BatchNorm / ReLU as autograd ops over the fused device kernels
 namespace {
+// GNNCPP_REFERENCE_QUIRKS=1: BatchNorm's backward reproduces what the reference's traversal delivers (only the first arrival
+// at BatchNorm's input reaches the transform, operation.h:80-88) instead of the mathematical gradient -- for comparing
+// through-layer gradients with the reference's own (tests/golden ref_full_*).  Off by default.
+using bn_bwd_fn = decltype(&gnnx_bn_relu_bwd_f32);
+bn_bwd_fn bn_backward() { return std::getenv("GNNCPP_REFERENCE_QUIRKS") ? &gnnx_bn_relu_bwd_quirk_f32 : &gnnx_bn_relu_bwd_f32; }
+}  // namespace
+decltype(&gnnx_bn_relu_bwd_f32) bn_backward_fn() { return bn_backward(); }
+namespace {
 class BatchNormOp : public cyg::Operation<tensor<float>> {
 public:
     float eps = 1e-5f;
@@ -357,7 +365,7 @@ public:
         auto dx = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
         auto dgamma = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
         auto dbeta = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
-        detail::gx(gnnx_bn_relu_bwd_f32(x->device_data(), f, nullptr, 0, g->device_data(), f, n, f, mean->device_data(), var->device_data(),
+        detail::gx(bn_backward()(x->device_data(), f, nullptr, 0, g->device_data(), f, n, f, mean->device_data(), var->device_data(),
                                         eps, gamma->device_data(), nullptr, 0, dx->device_out(), f, dgamma->device_out(), dbeta->device_out(),
                                         detail::workspace(wsb), wsb, detail::current_stream()), "BatchNorm");
         if (x->requires_grad()) x->backward(dx);
@@ -754,7 +762,7 @@ public:
         auto dh = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
         auto dgamma = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
         auto dbeta = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
-        cyg::detail::gx(gnnx_bn_relu_bwd_f32(h->device_data(), f, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
+        cyg::detail::gx(nn::bn_backward_fn()(h->device_data(), f, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
                                              var->device_data(), eps, gamma->device_data(), has_beta ? beta->device_data() : nullptr, 1,
                                              dh->device_out(), f, dgamma->device_out(), dbeta->device_out(),
                                              cyg::detail::workspace(wsb), wsb, st), "BatchNorm");

@@ -292,6 +292,17 @@ def bn_stats(X):
     return mean, var
 
 
+def bn_partial(X, mean=None, scale=1.0):
+    """scale * column sums of X (mean None) or of (X - mean)^2: the per-shard halves of the batch statistics (gnnx_bn_partial_f32)."""
+    N, F = X.shape
+    out = torch.empty(F, dtype=torch.float32, device=X.device)
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_bn_workspace", N, F, C.byref(wsb))
+    ws = _workspace(wsb.value, X.device, "bn")
+    capi.call("gnnx_bn_partial_f32", _ptr(X), _ld(X), N, F, _ptr(mean), float(scale), _ptr(out), _ptr(ws), wsb.value, _stream())
+    return out
+
+
 def bn_relu_fwd(X, mean=None, var=None, gamma=None, beta=None, eps=1e-5, relu=True, out=None):
     out = torch.empty_like(X) if out is None else out
     capi.call("gnnx_bn_relu_fwd_f32", _ptr(X), _ld(X), X.shape[0], X.shape[1], _ptr(mean), _ptr(var), float(eps), _ptr(gamma),
@@ -299,8 +310,9 @@ def bn_relu_fwd(X, mean=None, var=None, gamma=None, beta=None, eps=1e-5, relu=Tr
     return out
 
 
-def bn_relu_bwd(X, Y, dY, mean=None, var=None, gamma=None, eps=1e-5, relu=True, beta=None):
-    """Y=None with relu: the forward output was never stored (fused forward); its sign is recomputed from X."""
+def bn_relu_bwd(X, Y, dY, mean=None, var=None, gamma=None, eps=1e-5, relu=True, beta=None, reference_quirk=False):
+    """Y=None with relu: the forward output was never stored (fused forward); its sign is recomputed from X.
+    reference_quirk: gnnx_bn_relu_bwd_quirk_f32, the gradient the REFERENCE's traversal delivers (statistics as constants)."""
     N, F = X.shape
     dX = torch.empty_like(X)
     dgamma = torch.empty(F, dtype=torch.float32, device=X.device) if mean is not None else None
@@ -308,7 +320,8 @@ def bn_relu_bwd(X, Y, dY, mean=None, var=None, gamma=None, eps=1e-5, relu=True, 
     wsb = C.c_size_t(0)
     capi.call("gnnx_bn_workspace", N, F, C.byref(wsb))
     ws = _workspace(wsb.value, X.device, "bn")
-    capi.call("gnnx_bn_relu_bwd_f32", _ptr(X), _ld(X), _ptr(Y), _ld(Y) if Y is not None else 0, _ptr(dY), _ld(dY), N, F, _ptr(mean),
+    capi.call("gnnx_bn_relu_bwd_quirk_f32" if reference_quirk else "gnnx_bn_relu_bwd_f32", _ptr(X), _ld(X), _ptr(Y),
+              _ld(Y) if Y is not None else 0, _ptr(dY), _ld(dY), N, F, _ptr(mean),
               _ptr(var), float(eps), _ptr(gamma), _ptr(beta), int(relu), _ptr(dX), _ld(dX), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
               wsb.value, _stream())
     return dX, dgamma, dbeta

@@ -209,6 +209,18 @@ class NativeComm:
             pass
 
 
+def sharded_bn_stats(dist, ops, X_local, n_total):
+    """Batch statistics of BatchNorm over the WHOLE graph from this rank's rows ("cross-shard statistics"):
+    two [F] all-reduces -- the mean, then the centred squares against the GLOBAL mean (the exact two-pass biased variance of
+    gnnx_bn_stats_f32 / reference nn.cpp:303,312, only summed in shard order).  Returns (mean, var) for the fused SpMM prologue."""
+    inv_n = 1.0 / float(n_total)
+    mean = ops.bn_partial(X_local, None, inv_n)
+    dist.all_reduce(mean)
+    var = ops.bn_partial(X_local, mean, inv_n)
+    dist.all_reduce(var)
+    return mean, var
+
+
 class ShardPlan:
     """Everything rank `rank` needs for sharded forward + backward aggregation.
 

@@ -298,6 +298,15 @@ int gnnx_bn_relu_bwd_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_
  *             biased variance: the exact two-pass arithmetic of gnnx_bn_stats_f32, two [F] vectors on the wire per layer.
  *   bwd_sums / bwd_apply : the two halves of gnnx_bn_relu_bwd_f32 -- local dgamma / dbeta sums, then (after the caller's
  *             all-reduce of those two [F] vectors) dX with the global sums and n_total. */
+/* OPT-IN reference-quirk backward: dgamma / dbeta as above, dX = (g * gamma) / (var + eps)^0.5 with the batch statistics treated
+ * as constants.  That is what the REFERENCE's own backward delivers through BatchNorm: an op that has completed its backward drops
+ * every later arrival (operation.h:80-88) and BatchNorm's input has three consumers (x - mean, mean, var; nn.cpp:301-316), so only
+ * the first, direct path (Mul::_backward operation.h:159-164 -> Div::_backward :192-198) reaches the transform.  Pinned against
+ * the reference's through-layer gradients (tests/golden ref_full_*); exists only to compare with them, never the default. */
+int gnnx_bn_relu_bwd_quirk_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,
+                               int64_t n_rows, int32_t n_feat, const float *d_mean, const float *d_var, float eps, const float *d_gamma,
+                               const float *d_beta, int relu, float *d_dX, int64_t ldo, float *d_dgamma, float *d_dbeta,
+                               void *d_workspace, size_t workspace_bytes, void *stream);
 int gnnx_bn_partial_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const float *d_mean, float scale, float *d_out,
                         void *d_workspace, size_t workspace_bytes, void *stream);
 int gnnx_bn_relu_bwd_sums_f32(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd,

@@ -458,6 +458,49 @@ API void gcn_oracle_bn_relu_fwd(const float *X, int64_t N, int32_t F, const floa
     free(sd);
 }
 
+/* Backward THROUGH BatchNorm + ReLU as the reference's traversal delivers it ("reference-quirk mode").
+ * An op that has completed its backward drops every later arrival (operation.h:80-88); BatchNorm's input feeds three consumers
+ * (x - mean, mean, var: nn.cpp:301-316) and the direct one is visited first, so the statistics act as constants:
+ *   mask   : g = (bn_out > 0) ? dY : 0                              Mask::_backward         operation.h:557-562
+ *   dbeta  : column sums of g, ascending rows                       Add::_backward          operation.h:114-128 -> tensor.h:618-638
+ *   dgamma : column sums of fl(g * scaled_x)                        Mul::_backward (rhs)    operation.h:151-157
+ *   dX     : fl(fl(g * gamma) / sd)                                 Mul::_backward (lhs) :158-164, Div::_backward :192-198
+ * with scaled_x, sd, bn_out exactly the forward's values (gcn_oracle_bn_relu_fwd).  Pinned to the reference's through-layer
+ * gradients (tests/golden ref_full_*). */
+API void gcn_oracle_bn_relu_bwd_quirk(const float *X, int64_t N, int32_t F, const float *gamma, const float *beta, float eps,
+                                      const float *dY, float *dX, float *dgamma, float *dbeta)
+{
+    float *mean = (float *)malloc(sizeof(float) * (size_t)(F > 0 ? F : 1));
+    float *sd = (float *)malloc(sizeof(float) * (size_t)(F > 0 ? F : 1));
+    float *var = (float *)malloc(sizeof(float) * (size_t)(F > 0 ? F : 1));
+    float *Y = (float *)malloc(sizeof(float) * (size_t)(N * F > 0 ? N * F : 1));
+    gcn_oracle_bn_relu_fwd(X, N, F, gamma, beta, eps, 1, 0, Y, mean, var);  /* bn_out, no ReLU */
+    for (int32_t f = 0; f < F; f++) {
+        sd[f] = powf(var[f] + eps, 0.5f);
+        dgamma[f] = 0.0f;
+        dbeta[f] = 0.0f;
+    }
+    for (int64_t i = 0; i < N; i++)
+        for (int32_t f = 0; f < F; f++) {
+            const float g = Y[i * F + f] > 0.0f ? dY[i * F + f] : 0.0f;
+            const float scaled = (X[i * F + f] - mean[f]) / sd[f];
+            const float t = g * scaled;
+            if (i == 0) {
+                dgamma[f] = t;
+                dbeta[f] = g;
+            } else {
+                dgamma[f] += t;
+                dbeta[f] += g;
+            }
+            const float gg = g * gamma[f];
+            dX[i * F + f] = gg / sd[f];
+        }
+    free(mean);
+    free(sd);
+    free(var);
+    free(Y);
+}
+
 /* Softmax cross-entropy, forward value only (the reference's backward throws): nn.cpp:442-453.
  *   x_n = logits->at(target); out = exp(x_n) / (exp(logits)->sum(-1) + 1e-20); out = -(log(out)); out->sum() / numel
  * row sums and the final sum walk UP (functional::sum materialises), every op separately rounded. */

@@ -16,7 +16,7 @@ _lib = None
 __all__ = ["build", "coo_to_csr", "csr_transpose", "degree_norm", "linear_fwd", "aggregate_fwd",
            "aggregate_bwd", "colsum", "linear_bwd", "dense_aggregate", "set_threads", "max_threads",
            "coo_to_csr_weighted", "spmm_vals", "rowsum_vals",
-           "powf_table", "bn_relu_fwd", "cross_entropy", "gcn_layer_fwd", "gcn_layer_bwd", "ref_driver_path"]
+           "powf_table", "bn_relu_fwd", "bn_relu_bwd_quirk", "cross_entropy", "gcn_layer_fwd", "gcn_layer_bwd", "ref_driver_path"]
 
 
 def build():
@@ -210,6 +210,22 @@ def bn_relu_fwd(X, gamma=None, beta=None, eps=1e-5, do_bn=True, do_relu=True):
                                 C.c_int(int(do_relu)), _p(Y), _p(mean), _p(var))
     return Y, mean, var
 
+
+
+def bn_relu_bwd_quirk(X, dY, gamma=None, beta=None, eps=1e-5):
+    """Backward through BatchNorm + ReLU as the REFERENCE's traversal delivers it (fan-in arrivals after the first are dropped,
+    operation.h:80-88): returns (dX, dgamma, dbeta).  See gcn_oracle_bn_relu_bwd_quirk."""
+    X = np.ascontiguousarray(X, dtype=np.float32)
+    dY = np.ascontiguousarray(dY, dtype=np.float32)
+    N, F = X.shape
+    gamma = np.ones(F, dtype=np.float32) if gamma is None else np.ascontiguousarray(gamma, dtype=np.float32).reshape(-1)
+    beta = np.zeros(F, dtype=np.float32) if beta is None else np.ascontiguousarray(beta, dtype=np.float32).reshape(-1)
+    dX = np.empty_like(X)
+    dgamma = np.empty(F, dtype=np.float32)
+    dbeta = np.empty(F, dtype=np.float32)
+    _L().gcn_oracle_bn_relu_bwd_quirk(_p(X), C.c_int64(N), C.c_int32(F), _p(gamma), _p(beta), C.c_float(eps), _p(dY), _p(dX), _p(dgamma),
+                                      _p(dbeta))
+    return dX, dgamma, dbeta
 
 def cross_entropy(logits, target):
     """Mean softmax cross-entropy, the reference's forward arithmetic (nn.cpp:442-453)."""

@@ -157,6 +157,27 @@ int main(int argc, char **argv)
         auto target = make_shared<tensor<int>>(td, new valarray<int>(tgt.data(), N), false);
         auto loss = nn::cross_entropy_loss(out_full, target);
         dump_va(outdir, "loss.f32", *loss->data());
+        // gradients THROUGH the whole layer: transform <- BatchNorm <- ReLU <- aggregation <- + bias.  In the reference an op
+        // that has finished its backward drops every later arrival (operation.h:80-88), and BatchNorm feeds its input to three
+        // consumers (x - mean, mean, var): what arrives first wins.  These dumps pin that behaviour (SURVEY.md 8(f) rank 1,
+        // "reference-quirk mode"); a backend run with GNNCPP_REFERENCE_QUIRKS=1 must reproduce them.
+        if (!nobwd) {
+            graph::GCNConv layer3(Fin, Fout);
+            layer3.get_parameter("weight")->set_data(&wv);
+            layer3.get_parameter("bias")->set_data(&bv);
+            auto x3 = make_shared<tensor<float>>(xd, new valarray<float>(X.data(), X.size()), true);
+            auto ei_copy3 = new tensor<int>(ei->shape(), new valarray<int>(*ei->data()), false);
+            graph::Data data3(x3, ei_copy3);
+            auto out3 = layer3(data3);
+            vector<size_t> gd3 = {N, Fout};
+            auto g3 = make_shared<tensor<float>>(gd3, new valarray<float>(G.data(), G.size()), false);
+            out3->backward(g3);
+            dump_va(outdir, "full_dX.f32", *x3->grad());
+            dump_va(outdir, "full_dW.f32", *layer3.get_parameter("weight")->grad());
+            dump_va(outdir, "full_dbias.f32", *layer3.get_parameter("bias")->grad());
+            dump_va(outdir, "full_dgamma.f32", *layer3.get_parameter("gammas")->grad());
+            dump_va(outdir, "full_dbeta.f32", *layer3.get_parameter("betas")->grad());
+        }
     }
 
     // ---- weighted adjacency: edge_attr through edge_to_adj_mat / sum / mm / add_self_loops   graph.cpp:21-75
