@@ -32,9 +32,17 @@ public:
     cyg::tptr<float> get_parameter(std::string name);
     cyg::tptr<float> get_buffer(std::string name);
     std::shared_ptr<Module> get_module(std::string name);
-    cyg::tptr<float> operator()(const cyg::tptr<float> &input_tensor) { return forward(input_tensor); }
+    // (*module)(x) -> forward(x); with a label tensor -> forward(x, y)   (reference nn.h:46-48, nn.cpp:71-76)
+    cyg::tptr<float> operator()(const cyg::tptr<float> &input_tensor, cyg::tensor<int> *y = nullptr)
+    {
+        return y == nullptr ? forward(input_tensor) : forward(input_tensor, y);
+    }
     virtual cyg::tptr<float> forward(const cyg::tptr<float> &) { throw std::runtime_error("not implemented"); }
+    virtual cyg::tptr<float> forward(const cyg::tptr<float> &, cyg::tensor<int> *) { throw std::runtime_error("not implemented"); }
     std::vector<std::shared_ptr<Module>> modules(const bool &recurse = true);
+    // flat name -> module over the descendants; a module without children (or recurse == false) maps its own name to
+    // itself; a colliding key is stored as "<child>_<key>" (reference nn.cpp:87-102)
+    std::unordered_map<std::string, std::shared_ptr<Module>> named_modules(const bool &recurse = true);
     std::vector<cyg::tptr<float>> parameters(const bool &recurse = true);
     // flat name -> tensor over this module and its descendants; a child's key that already exists is stored
     // as "<child>_<key>" (reference nn.cpp:110-125)

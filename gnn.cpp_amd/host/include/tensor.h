@@ -570,6 +570,9 @@ public:
         materialize();
         return (*_st->h())[i];
     }
+    // the reference declares both accessors const (tensor.h:282,295) and calls them on const tensors (graph.cpp:35-36)
+    tptr<T> operator()(size_t i, size_t j) const { return (*const_cast<tensor<T> *>(this))(i, j); }
+    T operator[](size_t i) const { return (*const_cast<tensor<T> *>(this))[i]; }
     std::tuple<tptr<T>, tptr<int>> max() { return functional::max<T>(*this); }
     // U(low, high) initialisation (reference tensor.h:693-705; the reference seeds from time(), utils.cpp:6 --
     // here the engine is seedable through cyg::manual_seed for reproducible runs)

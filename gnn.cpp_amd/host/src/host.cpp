@@ -241,6 +241,17 @@ std::vector<std::shared_ptr<Module>> Module::modules(const bool &recurse)
     }
     return out;
 }
+std::unordered_map<std::string, std::shared_ptr<Module>> Module::named_modules(const bool &recurse)
+{
+    std::unordered_map<std::string, std::shared_ptr<Module>> out;
+    if (!recurse || _modules.empty()) {
+        out[name] = shared_from_this();
+        return out;
+    }
+    for (auto &[cname, m] : _modules)
+        for (auto &[k, v] : m->named_modules(true)) out[out.count(k) ? cname + "_" + k : k] = v;
+    return out;
+}
 std::unordered_map<std::string, tptr<float>> Module::named_parameters(const bool &recurse)
 {
     auto out = _parameters;
