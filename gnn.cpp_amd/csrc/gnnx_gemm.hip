@@ -14,6 +14,7 @@
 // flight from HBM while tile t is multiplied.
 // transA = 1 reduces over the node dimension (K = millions, M x N = F_out x F_in tiny): split-K over
 // workgroups into fp32 slabs + an in-order slab reduction (deterministic; no float atomics).
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -375,6 +376,209 @@ __global__ __launch_bounds__(C::NT) void gemm_stream_kernel(GemmArgs g, int64_t 
     }
 }
 
+// ---- LDS-DMA kernel for tall products (the bench shape: millions of rows x 256 x 256) ---------------------------------
+// Resident workgroup, 256 x 256 output tile, 16 wavefronts of 64 x 64, BK = 32, the K-tile stream running across output
+// tiles -- the decomposition of gemm_stream_kernel -- but the operands never pass through VGPRs: `global_load_lds_dwordx4`
+// (LDS-DMA) moves 1 KiB per wave-instruction HBM/L2 -> LDS, 4 instructions per wavefront and K-tile.  LDS images (the DMA
+// destination is wave-uniform base + lane * 16 B, so an image is whatever order the 64 lanes' SOURCE addresses are given in):
+//   A, K-contiguous (X, dH): [256 rows][8 slots of 16 B], slot s of row r holding k-group s ^ ((r >> 1) & 7); one
+//     wave-instruction = 8 rows x 128 B, every source line used whole;
+//   B, k-major (W as [K][N]; for X.W^T the host transposes the small W once into the workspace): [32 k][256 n] as it lies in
+//     memory, one wave-instruction per k row, rows padded to 272 words so that the two k rows a half-wave reads fall on
+//     different banks.
+typedef __attribute__((address_space(3))) void gemm_lds_void_t;
+typedef float gemm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float gemm_f32x4acc __attribute__((ext_vector_type(4)));
+
+// The loop carries (almost) NO vector-ALU instruction.  Measured on this chip (mfma_peak_kernel<mode>, 4 wavefronts per SIMD): beside the f32 MFMA every VALU instruction per MFMA
+// costs 4-7 % of the matrix rate (1 / 2 / 4 per MFMA: 143 / 136 / 125 of 155 TFLOP/s), an LDS read 2-3 %, an s_nop nothing.
+// The register-staged kernels carry 2-3 VALU per MFMA (staging, fragment addresses), and so did two first LDS-DMA versions
+// (ds_read_b128 + element selects on 32x32x2, per-read address arithmetic on 16x16x4: loop-only 84-85 % of peak with loads
+// and stores switched off) -- that, not bank conflicts or the barrier, is their 78-85 %.  Here:
+//   * v_mfma_f32_16x16x4_f32, wavefront tile 64 x 64 = 4 x 4 blocks, operands SWAPPED (D = B^T-block . A^T-block), so that a
+//     lane ends up with 4 consecutive output COLUMNS of one row: 16 global_store_dwordx4 per lane and tile instead of 64 dword
+//     stores (a * b is commutative in IEEE arithmetic: the same fmaf chain, the same bits);
+//   * a lane needs exactly ONE word per operand block and 4-k step: ds_read_b32 at a precomputed per-lane address + an
+//     IMMEDIATE offset.  The k-group XOR of the image costs 8 address registers per operand (block i of 16 rows is +2048 B,
+//     the stage +32768 B: immediates), computed once per launch -- no select, no address arithmetic in the loop;
+//   * the K-tile loop is unrolled by two so that the LDS stage is a compile-time constant.
+// Needs K % 64 == 0 (two K-tiles per trip).
+template <int OFF>
+__device__ __forceinline__ void lds_read_b32(float &dst, uint32_t addr)
+{
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit unsigned immediate");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+
+template <int STAGE_ID, int KG>
+__device__ __forceinline__ void dma2_read_group(float (&a)[4], float (&b)[4], const uint32_t (&ak)[8], uint32_t bk)
+{
+    constexpr int SA = STAGE_ID * 32768;
+    lds_read_b32<SA + 0 * 2048>(a[0], ak[KG]);
+    lds_read_b32<SA + 1 * 2048>(a[1], ak[KG]);
+    lds_read_b32<SA + 2 * 2048>(a[2], ak[KG]);
+    lds_read_b32<SA + 3 * 2048>(a[3], ak[KG]);
+    constexpr int SB = STAGE_ID * (32 * 272 * 4) + 4 * KG * 272 * 4;  // k row 4 KG + q (q is in the address register)
+    lds_read_b32<SB + 0 * 64>(b[0], bk);
+    lds_read_b32<SB + 1 * 64>(b[1], bk);
+    lds_read_b32<SB + 2 * 64>(b[2], bk);
+    lds_read_b32<SB + 3 * 64>(b[3], bk);
+}
+
+#define GNNX_DMA2_WAIT(N, set)                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[set][0]), "+v"(a[set][1]), "+v"(a[set][2]), "+v"(a[set][3]), "+v"(b[set][0]), \
+                 "+v"(b[set][1]), "+v"(b[set][2]), "+v"(b[set][3])::"memory")
+#define GNNX_DMA2_MFMA(set)                                                                                \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; i_++) _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++)      \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[set][j_], a[set][i_], acc[i_][j_], 0, 0, 0)
+// one k-group: fragments of group KG + 1 on their way while group KG is multiplied
+#define GNNX_DMA2_STEP(ST, KG, cur, nxt)                                  \
+    dma2_read_group<ST, KG + 1>(a[nxt], b[nxt], ak, bk);            \
+    GNNX_DMA2_WAIT(8, cur);                                               \
+    GNNX_DMA2_MFMA(cur)
+#define GNNX_DMA2_KTILE(ST)                                               \
+    dma2_read_group<ST, 0>(a[0], b[0], ak, bk);                     \
+    GNNX_DMA2_STEP(ST, 0, 0, 1);                                          \
+    GNNX_DMA2_STEP(ST, 1, 1, 0);                                          \
+    GNNX_DMA2_STEP(ST, 2, 0, 1);                                          \
+    GNNX_DMA2_STEP(ST, 3, 1, 0);                                          \
+    GNNX_DMA2_STEP(ST, 4, 0, 1);                                          \
+    GNNX_DMA2_STEP(ST, 5, 1, 0);                                          \
+    GNNX_DMA2_STEP(ST, 6, 0, 1);                                          \
+    GNNX_DMA2_WAIT(0, 1);                                                 \
+    GNNX_DMA2_MFMA(1)
+
+// LDS-DMA with a wave-uniform 64-bit base in SGPRs + a per-lane 32-bit BYTE offset (the saddr form: no 64-bit vector address
+// arithmetic, no zero-extended offset pairs to keep alive).  M0 = LDS destination of lane 0; it is compiler-reserved, so it is
+// saved and restored inside the statement.  The leading s_nop covers a base freshly written by the scalar ALU.
+__device__ __forceinline__ void dma_16B(uint32_t voff_bytes, const float *sbase, uint32_t lds_dst)
+{
+    uint32_t keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+__global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate)
+{
+    constexpr int BM = 256, BN = 256, BK = 32;
+    constexpr int STAGE = BM * BK;                       // floats per A stage (32 KB)
+    constexpr int BROW = 272;                            // B row stride in floats (256 + 16)
+    constexpr int BSTAGE = BK * BROW;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][A stage] at 0, [2][B stage] at 64 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int64_t n0 = (int64_t)blockIdx.x * BN;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(gemm_lds_void_t *)lds_raw;
+
+    // ---- DMA: per-lane BYTE offsets inside an operand tile (u = 0, 1: this wavefront's two wave-instructions per operand)
+    uint32_t offa[2], offb[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int row = 8 * (wave + 16 * u) + (lane >> 3);
+        const int kg = (lane & 7) ^ ((row >> 1) & 7);
+        offa[u] = (uint32_t)(row * g.lda + 4 * kg) * 4u;
+        offb[u] = (uint32_t)((wave + 16 * u) * g.ldb + 4 * lane) * 4u;   // k row (wave + 16 u), 256 consecutive n
+    }
+    const float *bcol = g.B + n0;
+    const int64_t bstep = g.ldb;
+    // LDS byte addresses of this wavefront's four 1-KiB DMA pieces per stage: A piece u, B piece u
+    const uint32_t pa0 = lds0 + (uint32_t)(wave * 1024), pa1 = pa0 + 16 * 1024;
+    const uint32_t pb0 = lds0 + 2 * STAGE * 4 + (uint32_t)(wave * BROW * 4), pb1 = pb0 + 16 * BROW * 4;
+    auto issue = [&](int stage, int64_t mt, int64_t k0) {
+        const float *abase = g.A + mt * BM * g.lda + k0;
+        const float *bbase = bcol + k0 * bstep;
+        dma_16B(offa[0], abase, pa0 + stage * STAGE * 4);
+        dma_16B(offb[0], bbase, pb0 + stage * BSTAGE * 4);
+        dma_16B(offa[1], abase, pa1 + stage * STAGE * 4);
+        dma_16B(offb[1], bbase, pb1 + stage * BSTAGE * 4);
+    };
+    // ---- fragment address registers (bytes): the 8 k-groups of this lane's row of block 0 (the row's slot XOR is the same in
+    // every 16-row block: (16 i + r) >> 1 & 7 == r >> 1 & 7)
+    uint32_t ak[8];
+    {
+        const int row = wm * 64 + r16;
+        const uint32_t xa = (uint32_t)(((row >> 1) & 7) << 4);
+#pragma unroll
+        for (int kg = 0; kg < 8; kg++) ak[kg] = lds0 + (uint32_t)(row * 128 + 4 * q) + (((uint32_t)kg << 4) ^ xa);
+    }
+    const uint32_t bk = lds0 + 2 * STAGE * 4 + (uint32_t)(q * BROW * 4 + (wn * 64 + r16) * 4);
+    // ---- epilogue through LDS.  D = mfma(b, a): a lane holds C[16 i + r16][16 j + 4 q .. + 3] of its wavefront's 64 x 64
+    // block.  Block row i (16 rows x 64 columns = 4 KB) is written to the wavefront's OWN four DMA pieces of stage 1 (free
+    // after the tile's last K-tile; only this wavefront's next DMA overwrites them, and that is issued behind its reads), piece
+    // p = rows 4p..4p+3, and read back one piece per instruction: 64 lanes x 16 B = 4 rows x 256 B = whole 128-byte lines per
+    // store.  16-byte columns are XORed with (row & 3) to spread the writers over the banks.
+    const uint32_t ep_piece = (r16 >> 2) == 0 ? pa0 : (r16 >> 2) == 1 ? pb0 : (r16 >> 2) == 2 ? pa1 : pb1;  // + stage 1 below
+    const uint32_t ep_st1 = STAGE * 4;  // K-contiguous stage 1 is +32 KB for A pieces ...
+    const uint32_t ep_wr = ep_piece + (((r16 >> 2) & 1) ? (uint32_t)(BSTAGE * 4) : ep_st1) +
+                           (uint32_t)((r16 & 3) * 256) + (uint32_t)((q ^ (r16 & 3)) << 4);   // + 64 j
+    // reader: lane L reads 16 B at byte L*16 of a piece = row L/16, 16-B column L%16 (stored at column ^ (row & 3))
+    const uint32_t ep_rd = (uint32_t)((lane >> 4) * 256) + (uint32_t)(((lane & 15) ^ (lane >> 4)) << 4);
+    const uint32_t offc = (uint32_t)((wm * 64 + (lane >> 4)) * g.ldc + wn * 64 + 4 * (lane & 15)) * 4u;  // bytes: row L/16, col 4 (L%16)
+
+    gemm_f32x4acc acc[4][4];
+    float a[2][4], b[2][4];
+    int64_t mt = blockIdx.y;
+    if (mt < m_tiles) issue(0, mt, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (; mt < m_tiles; mt += gridDim.y) {
+        const int64_t mt_next = mt + gridDim.y;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
+        for (int64_t k0 = 0; k0 < g.K; k0 += 2 * BK) {
+            const bool last = k0 + 2 * BK >= g.K;
+            if (!(ablate & 2)) issue(1, mt, k0 + BK);   // K % 64 == 0: the odd K-tile of this trip always exists
+            GNNX_DMA2_KTILE(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if ((!last || mt_next < m_tiles) && !(ablate & 2)) issue(0, last ? mt_next : mt, last ? 0 : k0 + 2 * BK);
+            GNNX_DMA2_KTILE(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (ablate & 1) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) s_ += acc[i][j][r];
+            if (s_ == 1.2345e30f) g.C[0] = s_;
+            continue;
+        }
+        const float alpha = g.alpha;
+        char *ctile = reinterpret_cast<char *>(g.C + mt * BM * g.ldc + n0);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                gemm_f32x4acc v = acc[i][j];
+                if (alpha != 1.0f) v = v * alpha;
+                asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ep_wr), "v"(v), "i"(64 * j) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gemm_f32x4acc o[4];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(o[0]) : "v"(ep_rd + pa0 + ep_st1) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(o[1]) : "v"(ep_rd + pb0 + (uint32_t)(BSTAGE * 4)) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(o[2]) : "v"(ep_rd + pa1 + ep_st1) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(o[3]) : "v"(ep_rd + pb1 + (uint32_t)(BSTAGE * 4)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])::"memory");
+            char *crow = ctile + (int64_t)(16 * i) * g.ldc * 4;   // wave-uniform
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * 4 + offc) = o[p];
+        }
+    }
+}
+
 // Split-K partials -> C in a FIXED order (deterministic, no float atomics): 8 lane groups each sum a contiguous eighth of the
 // slabs for 32 consecutive elements (128-byte coalesced reads), then the eight partial sums are combined left to right.
 // (One thread walking all slabs of its element was a chain of up to 1024 dependent loads: 0.31 ms next to a 0.30 ms GEMM
@@ -407,19 +611,43 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *slab, i
 // Calibration: register-only MFMA loop (4 independent accumulators per wavefront, no memory traffic) -- what the
 // fp32 matrix pipe sustains on THIS chip at the clock it holds under load; the GEMM's fraction of that is the honest
 // utilisation figure next to the 157.3 TFLOP/s datasheet peak.
+template <int mode>
 __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float *sink)
 {
+    __shared__ float lds[4096];
     f32x16 acc[4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][r] = (float)(threadIdx.x + r);
     float a = 1.0f + threadIdx.x * 1e-3f, b = 1.0f - threadIdx.x * 1e-3f;
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    const uint32_t la = (uint32_t)(uintptr_t)(gemm_lds_void_t *)lds + (threadIdx.x & 63) * 16;
+    float d0 = a, d1 = b, d2 = a, d3 = b;
+    gemm_f32x4 w0 = {a, b, a, b}, w1 = w0;
+    uint32_t sc = (uint32_t)iters;
+    // mode (measurement only): what one extra instruction per MFMA costs the matrix pipe
+    //   0 none | 1: 1 VALU | 2: 2 VALU | 4: 4 VALU | 10: 1 ds_read_b32 | 11: 1 ds_read_b128 per 2 MFMA | 12: 1 ds_read_b128 per MFMA
     for (int it = 0; it < iters; it++) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        for (int i = 0; i < 4; i++) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+            if (mode == 1 || mode == 2 || mode == 4) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(d0) : "v"(d1));
+            if (mode == 2 || mode == 4) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(d1) : "v"(d0));
+            if (mode == 4) {
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(d2) : "v"(d3));
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(d3) : "v"(d2));
+            }
+            if (mode == 20) asm volatile("s_nop 0");
+            if (mode == 21) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sc));
+            if (mode == 10) asm volatile("ds_read_b32 %0, %1" : "=v"(d2) : "v"(la) : "memory");
+            if (mode == 11 && (i & 1)) asm volatile("ds_read_b128 %0, %1" : "=v"(w0) : "v"(la) : "memory");
+            if (mode == 12) asm volatile("ds_read_b128 %0, %1" : "=v"(w1) : "v"(la) : "memory");
+        }
+        if (mode >= 10) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d2), "+v"(w0), "+v"(w1)::"memory");
     }
-    float s = 0.f;
+    float s = d0 + d1 + d2 + d3 + w0.x + w1.y + (float)sc;
 #pragma unroll
     for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][7];
     if (s == 12345.678f) sink[0] = s;  // keep the loop alive
@@ -573,12 +801,72 @@ int launch_stream(const GemmArgs &g, bool b_kc, int waves_per_slot, hipStream_t 
     return GNNX_OK;
 }
 
+// *rows_done = number of leading rows of C written by the LDS-DMA kernel (0: shape not eligible).  B must be k-major ([K][N]).
+bool dma_shape_ok(int64_t M, int64_t N, int64_t K)
+{
+    return K % 64 == 0 && N % 256 == 0 && M >= 8 * 256;
+}
+
+int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done)
+{
+    *rows_done = 0;
+    constexpr int BM = 256, BN = 256, BK = 32;
+    if (!dma_shape_ok(g.M, g.N, g.K)) return GNNX_OK;
+    if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return GNNX_OK;
+    if ((int64_t)BM * g.lda >= (1ll << 28) || (int64_t)BK * g.ldb >= (1ll << 28) || (int64_t)BM * g.ldc >= (1ll << 28))
+        return GNNX_OK;  // per-lane BYTE offsets are 32-bit
+    const int64_t m_tiles = g.M / BM, cols = g.N / BN;
+    int64_t gy = ceil_div((int64_t)kNumCU, cols);
+    if (gy > m_tiles) gy = m_tiles;
+    constexpr size_t lds = sizeof(float) * (2 * BM * BK + 2 * BK * 272);  // 2 stages x (A 32 KB + B 34 KB) = 132 KB
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    static std::atomic<uint64_t> attr_done{0};  // bit d: the dynamic-LDS opt-in has been set on device d
+    if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+        if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    static const int ablate = [] { const char *e = getenv("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    hipLaunchKernelGGL(gemm_dma_kernel, dim3((uint32_t)cols, (uint32_t)gy, 1), dim3(1024), lds, st, g, m_tiles, ablate);
+    GNNX_LAUNCH_CHECK();
+    *rows_done = m_tiles * BM;
+    return GNNX_OK;
+}
+
+// Y[c][r] = X[r][c] for the small weight matrix (tile through LDS; the general entry point is gnnx_transpose_f32)
+__global__ __launch_bounds__(256) void gemm_transpose_w_kernel(const float *X, int64_t ldx, int64_t n_rows, int64_t n_cols, float *Y,
+                                                                int64_t ldy)
+{
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < n_rows && c0 + tx < n_cols) t[k][tx] = X[(r0 + k) * ldx + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < n_cols && r0 + tx < n_rows) Y[(c0 + k) * ldy + r0 + tx] = t[tx][k];
+}
+
 }  // namespace
 
 GNNX_API int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_sink, double *flops_out, void *stream)
 {
     GNNX_REQUIRE(iters > 0 && n_workgroups > 0 && d_sink, GNNX_ERR_INVALID_ARG, "bad arguments");
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3((uint32_t)n_workgroups), dim3(256), 0, as_stream(stream), iters, d_sink);
+    static const int peak_mode = [] { const char *e = getenv("GNNX_PEAK_MODE"); return e ? atoi(e) : 0; }();
+    const dim3 pg((uint32_t)n_workgroups), pb(256);
+    hipStream_t pst = as_stream(stream);
+    switch (peak_mode) {
+    case 1: hipLaunchKernelGGL(mfma_peak_kernel<1>, pg, pb, 0, pst, iters, d_sink); break;
+    case 2: hipLaunchKernelGGL(mfma_peak_kernel<2>, pg, pb, 0, pst, iters, d_sink); break;
+    case 4: hipLaunchKernelGGL(mfma_peak_kernel<4>, pg, pb, 0, pst, iters, d_sink); break;
+    case 10: hipLaunchKernelGGL(mfma_peak_kernel<10>, pg, pb, 0, pst, iters, d_sink); break;
+    case 11: hipLaunchKernelGGL(mfma_peak_kernel<11>, pg, pb, 0, pst, iters, d_sink); break;
+    case 12: hipLaunchKernelGGL(mfma_peak_kernel<12>, pg, pb, 0, pst, iters, d_sink); break;
+    case 20: hipLaunchKernelGGL(mfma_peak_kernel<20>, pg, pb, 0, pst, iters, d_sink); break;
+    case 21: hipLaunchKernelGGL(mfma_peak_kernel<21>, pg, pb, 0, pst, iters, d_sink); break;
+    default: hipLaunchKernelGGL(mfma_peak_kernel<0>, pg, pb, 0, pst, iters, d_sink); break;
+    }
     GNNX_LAUNCH_CHECK();
     if (flops_out) *flops_out = (double)n_workgroups * 4 /*waves*/ * 4 /*acc*/ * (double)iters * (2.0 * 32 * 32 * 2);
     return GNNX_OK;
@@ -592,6 +880,8 @@ GNNX_API int gnnx_gemm_workspace(int transA, int transB, int64_t M, int64_t N, i
     if (transA && M > 0 && N > 0 && K > 0) {
         int splits = choose_splits(M, N, K);
         if (splits > 1) *bytes = sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
+    } else if (!transA && transB && dma_shape_ok(M, N, K)) {
+        *bytes = sizeof(float) * (size_t)K * (size_t)N;  // W^T as [K][N] for the LDS-DMA kernel
     }
     return GNNX_OK;
 }
@@ -627,15 +917,37 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
         g.slab = static_cast<float *>(d_workspace);
     }
     // tall products with whole tiles: the resident streaming kernel takes the whole M-tiles, the generic kernel the rest
+    // tall products with whole tiles: the LDS-DMA kernel takes the whole 256-row tiles (B k-major; for X.W^T the small W is
+    // transposed once into the workspace, same products in the same order), the generic kernel the ragged rest
+    static const int dma_env = [] { const char *e = getenv("GNNX_GEMM_DMA"); return e ? atoi(e) : 1; }();
+    if (dma_env > 0 && a_kc && splits == 1 && beta == 0.f && K > 0 && dma_shape_ok(M, N, K) &&
+        (!b_kc || (d_workspace && workspace_bytes >= sizeof(float) * (size_t)K * (size_t)N && aligned16(d_workspace)))) {
+        GemmArgs gd = g;
+        if (b_kc) {
+            float *wt = static_cast<float *>(d_workspace);
+            hipLaunchKernelGGL(gemm_transpose_w_kernel, dim3((uint32_t)ceil_div(K, 32), (uint32_t)ceil_div(N, 32)), dim3(256), 0, st, d_B, ldb,
+                               N, K, wt, N);
+            GNNX_LAUNCH_CHECK();
+            gd.B = wt;
+            gd.ldb = N;
+        }
+        int64_t rows = 0;
+        const int src = launch_dma(gd, st, &rows);
+        if (src != GNNX_OK) return src;
+        if (rows == g.M) return GNNX_OK;
+        g.A += rows * lda;
+        g.C += rows * ldc;
+        g.M -= rows;
+    }
     static const int stream_env = [] { const char *e = getenv("GNNX_GEMM_STREAM"); return e ? atoi(e) : 1; }();
     if (stream_env > 0 && a_kc && splits == 1 && beta == 0.f && va && vb && K > 0) {
         int64_t rows = 0;  // leading rows of C written by the streaming kernel
         const int src = launch_stream(g, b_kc, stream_env, st, &rows);
         if (src != GNNX_OK) return src;
-        if (rows == M) return GNNX_OK;
+        if (rows == g.M) return GNNX_OK;
         g.A += rows * lda;
         g.C += rows * ldc;
-        g.M = M - rows;
+        g.M -= rows;  // relative to what the LDS-DMA kernel above left over
     }
     int rc;
     if (a_kc && b_kc) rc = launch<true, true>(g, splits, va, vb, st);
