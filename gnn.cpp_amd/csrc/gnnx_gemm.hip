@@ -801,6 +801,99 @@ int launch_stream(const GemmArgs &g, bool b_kc, int waves_per_slot, hipStream_t 
     return GNNX_OK;
 }
 
+// ---- the same loop for dW = dH^T . X (reduction over the node dimension, split-K) --------------------------------------
+// Both operands are k-major as they lie in memory (dH [K][M], X [K][N]): each K-tile is 32 rows of 256 floats per operand, one
+// wave-instruction per row, rows padded to 272 words in LDS; a lane's fragment word is base + immediate for both operands
+// (two address registers in all).  A workgroup owns one 256 x 256 output tile and a K range (blockIdx.z); its partial tile
+// goes to the split-K slab once, at the end, and the slabs are summed in a fixed order by splitk_reduce_kernel.
+template <int STAGE_ID, int KG>
+__device__ __forceinline__ void dma_tn_read_group(float (&a)[4], float (&b)[4], uint32_t ak, uint32_t bk)
+{
+    constexpr int SB = STAGE_ID * (32 * 272 * 4) + 4 * KG * 272 * 4;
+    lds_read_b32<SB + 0 * 64>(a[0], ak);
+    lds_read_b32<SB + 1 * 64>(a[1], ak);
+    lds_read_b32<SB + 2 * 64>(a[2], ak);
+    lds_read_b32<SB + 3 * 64>(a[3], ak);
+    lds_read_b32<SB + 0 * 64>(b[0], bk);
+    lds_read_b32<SB + 1 * 64>(b[1], bk);
+    lds_read_b32<SB + 2 * 64>(b[2], bk);
+    lds_read_b32<SB + 3 * 64>(b[3], bk);
+}
+#define GNNX_DMATN_STEP(ST, KG, cur, nxt)                                 \
+    dma_tn_read_group<ST, KG + 1>(a[nxt], b[nxt], ak, bk);                \
+    GNNX_DMA2_WAIT(8, cur);                                               \
+    GNNX_DMA2_MFMA(cur)
+#define GNNX_DMATN_KTILE(ST)                                              \
+    dma_tn_read_group<ST, 0>(a[0], b[0], ak, bk);                         \
+    GNNX_DMATN_STEP(ST, 0, 0, 1);                                         \
+    GNNX_DMATN_STEP(ST, 1, 1, 0);                                         \
+    GNNX_DMATN_STEP(ST, 2, 0, 1);                                         \
+    GNNX_DMATN_STEP(ST, 3, 1, 0);                                         \
+    GNNX_DMATN_STEP(ST, 4, 0, 1);                                         \
+    GNNX_DMATN_STEP(ST, 5, 1, 0);                                         \
+    GNNX_DMATN_STEP(ST, 6, 0, 1);                                         \
+    GNNX_DMA2_WAIT(0, 1);                                                 \
+    GNNX_DMA2_MFMA(1)
+
+__global__ __launch_bounds__(1024) void gemm_dma_tn_kernel(GemmArgs g)
+{
+    constexpr int BM = 256, BN = 256, BK = 32;
+    constexpr int BROW = 272, STAGE = BK * BROW;          // floats per operand stage (34 KB)
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][A stage] then [2][B stage] = 136 KB
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
+    const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;   // (kend - kbeg) % 64 == 0 (host)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(gemm_lds_void_t *)lds_raw;
+    // DMA: wave-instruction (wave + 16 u) = k row (wave + 16 u) of the K-tile, lane = 4 consecutive m (n)
+    const uint32_t offa0 = (uint32_t)(wave * g.lda + 4 * lane) * 4u, offa1 = offa0 + (uint32_t)(16 * g.lda) * 4u;
+    const uint32_t offb0 = (uint32_t)(wave * g.ldb + 4 * lane) * 4u, offb1 = offb0 + (uint32_t)(16 * g.ldb) * 4u;
+    const uint32_t pa0 = lds0 + (uint32_t)(wave * BROW * 4), pa1 = pa0 + 16 * BROW * 4;
+    const uint32_t pb0 = pa0 + 2 * STAGE * 4, pb1 = pb0 + 16 * BROW * 4;
+    const float *acol = g.A + m0, *bcol = g.B + n0;
+    auto issue = [&](int stage, int64_t k0) {
+        const float *abase = acol + k0 * g.lda;
+        const float *bbase = bcol + k0 * g.ldb;
+        dma_16B(offa0, abase, pa0 + stage * STAGE * 4);
+        dma_16B(offb0, bbase, pb0 + stage * STAGE * 4);
+        dma_16B(offa1, abase, pa1 + stage * STAGE * 4);
+        dma_16B(offb1, bbase, pb1 + stage * STAGE * 4);
+    };
+    const uint32_t ak = lds0 + (uint32_t)(q * BROW * 4 + (wm * 64 + r16) * 4);
+    const uint32_t bk = lds0 + 2 * STAGE * 4 + (uint32_t)(q * BROW * 4 + (wn * 64 + r16) * 4);
+    gemm_f32x4acc acc[4][4];
+    float a[2][4], b[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
+    if (kbeg < kend) issue(0, kbeg);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 2 * BK) {
+        issue(1, k0 + BK);
+        GNNX_DMATN_KTILE(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k0 + 2 * BK < kend) issue(0, k0 + 2 * BK);
+        GNNX_DMATN_KTILE(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // D = mfma(b, a): lane holds partial C[m0 + wm*64 + 16 i + r16][n0 + wn*64 + 16 j + 4 q .. + 3] -> slab of this split
+    float *out = g.slab + (int64_t)blockIdx.z * g.M * g.N + (m0 + wm * 64 + r16) * g.N + n0 + wn * 64 + 4 * q;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) *reinterpret_cast<gemm_f32x4acc *>(out + (int64_t)(16 * i) * g.N + 16 * j) = acc[i][j];
+}
+
 // *rows_done = number of leading rows of C written by the LDS-DMA kernel (0: shape not eligible).  B must be k-major ([K][N]).
 bool dma_shape_ok(int64_t M, int64_t N, int64_t K)
 {
@@ -831,6 +924,24 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done)
     hipLaunchKernelGGL(gemm_dma_kernel, dim3((uint32_t)cols, (uint32_t)gy, 1), dim3(1024), lds, st, g, m_tiles, ablate);
     GNNX_LAUNCH_CHECK();
     *rows_done = m_tiles * BM;
+    return GNNX_OK;
+}
+
+bool dma_tn_shape_ok(int64_t M, int64_t N, int64_t K) { return M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K >= 64 * 1024; }
+
+int launch_dma_tn(const GemmArgs &g, int splits, hipStream_t st)
+{
+    constexpr size_t lds = sizeof(float) * 4 * 32 * 272;  // 2 stages x 2 operands x 34 KB = 136 KB
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    static std::atomic<uint64_t> attr_done{0};
+    if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_dma_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds));
+        if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(gemm_dma_tn_kernel, dim3((uint32_t)(g.N / 256), (uint32_t)(g.M / 256), (uint32_t)splits), dim3(1024), lds, st, g);
+    GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }
 
@@ -910,6 +1021,8 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     const int bk = tile_dims(M, N).bk;
     int64_t ksteps = ceil_div(K > 0 ? K : 1, bk);
     g.k_per_split = ceil_div(ksteps, splits) * bk;
+    if (transA && !transB && splits > 1 && dma_tn_shape_ok(M, N, K))
+        g.k_per_split = ceil_div(ceil_div(K, 64), splits) * 64;  // the LDS-DMA loop takes K-tiles in pairs
     if (splits > 1) {
         size_t need = sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
         GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu",
@@ -950,7 +1063,12 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
         g.M -= rows;  // relative to what the LDS-DMA kernel above left over
     }
     int rc;
-    if (a_kc && b_kc) rc = launch<true, true>(g, splits, va, vb, st);
+    // dW = dH^T . X on the LDS-DMA loop: both operands k-major, whole 256 x 256 tiles, K in whole pairs of K-tiles per split
+    const bool dma_tn = dma_env > 0 && !a_kc && !b_kc && splits > 1 && g.slab && dma_tn_shape_ok(M, N, K) && g.k_per_split % 64 == 0 &&
+                        lda % 4 == 0 && ldb % 4 == 0 && aligned16(d_A) && aligned16(d_B) && aligned16(g.slab) &&
+                        32 * lda < (1ll << 28) && 32 * ldb < (1ll << 28);
+    if (dma_tn) rc = launch_dma_tn(g, splits, st);
+    else if (a_kc && b_kc) rc = launch<true, true>(g, splits, va, vb, st);
     else if (a_kc && !b_kc) rc = launch<true, false>(g, splits, va, vb, st);
     else if (!a_kc && b_kc) rc = launch<false, true>(g, splits, va, vb, st);
     else rc = launch<false, false>(g, splits, va, vb, st);

@@ -293,6 +293,25 @@ def test_gemm_splitk_long_reduction(env):
     assert np.abs(a - ref).max() <= 1e-5 * np.abs(dH).astype(np.float64).T.dot(np.abs(X).astype(np.float64)).max()
 
 
+@pytest.mark.parametrize("n,fo,fi", [(1_000_000, 256, 256), (262_144, 512, 256), (200_064, 256, 256)])
+def test_gemm_splitk_lds_dma_kernel(env, n, fo, fi):
+    """dW = dH^T . X with 256-multiple widths and K % 64 == 0 takes gemm_dma_tn_kernel (LDS-DMA, split-K slabs, in-order slab
+    reduction): float64 check with the condition-aware bound, run-to-run identical, and the same bits with beta = 1 as adding
+    to the previous result by hand."""
+    ops, torch = env["ops"], env["torch"]
+    dH = ops.uniform_pm1(63, (n, fo), device=env["dev"])
+    X = ops.uniform_pm1(64, (n, fi), device=env["dev"])
+    a = ops.gemm(dH, X, transA=True)
+    b = ops.gemm(dH, X, transA=True)
+    assert torch.equal(a, b)
+    ref = dH[:, :64].double().t() @ X.double()                     # 64 output rows in float64
+    bound = 1e-5 * float((dH[:, :64].abs().double().t() @ X.abs().double()).max())
+    assert float((a[:64].double() - ref).abs().max()) <= bound
+    c = a.clone()
+    ops.gemm(dH, X, transA=True, out=c, beta=1.0)
+    assert torch.equal(c, a + a)
+
+
 def test_gemm_beta_accumulate(env):
     ops = env["ops"]
     A = synth.uniform_pm1(71, (300, 40))
