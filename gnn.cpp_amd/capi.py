@@ -73,6 +73,7 @@ _SIGS = {
     "gnnx_stream_wait_event": [_vp, _vp],
     "gnnx_csr_from_coo_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_csr_from_coo": [_vp, _vp, _i64, _i32, _u32, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
+    "gnnx_csr_validate": [_vp, _vp, _i32, _i32, _vp],
     "gnnx_equal_i32": [_vp, _vp, _i64, C.POINTER(C.c_int), _vp],
     "gnnx_csr_from_coo_weighted_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_csr_from_coo_weighted": [_vp, _vp, _vp, _i64, _i32, _u32, C.c_int, _f32, _vp, _vp, _vp, C.POINTER(_i64), _vp, _sz, _vp],
@@ -86,6 +87,8 @@ _SIGS = {
     "gnnx_f32_to_bf16": [_vp, _i64, _i64, _i32, _vp, _i64, _vp],
     "gnnx_gemm_workspace": [C.c_int, C.c_int, _i64, _i64, _i64, C.POINTER(_sz)],
     "gnnx_gemm_f32": [C.c_int, C.c_int, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _sz, _vp],
+    "gnnx_gemm_relu_colsum_workspace": [_i64, _i64, _i64, C.POINTER(_sz)],
+    "gnnx_gemm_relu_colsum_f32": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _sz, _vp],
     "gnnx_gemm_split_workspace": [_i64, _i64, _i64, C.POINTER(_sz)],
     "gnnx_gemm_split_bf16_f32": [C.c_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _sz, _vp],
     "gnnx_mfma_peak_f32": [_i32, _i32, _vp, C.POINTER(_f64), _vp],

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "gnnx.h"
 
@@ -21,6 +22,14 @@ int set_error(int status, const char *fmt, ...);
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Measurement switches (kernel variants, forced tile shapes, ablation flags, the LDS-staged SpMM) exist only in an EXPERIMENTS
+// build (`make EXPERIMENTS=1`, scripts/exp_*.py); the shipped library has one code path per shape and reads no environment.
+#ifdef GNNX_EXPERIMENTS
+inline const char *experiment_env(const char *name) { return std::getenv(name); }
+#else
+inline const char *experiment_env(const char *) { return nullptr; }
+#endif
 
 }  // namespace gnnx
 

@@ -458,8 +458,26 @@ __device__ __forceinline__ void dma_16B(uint32_t voff_bytes, const float *sbase,
                  : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-__global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate)
+#ifdef GNNX_EXPERIMENTS
+#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // 1: no C stores, 2: no operand loads after the first (timing only)
+#else
+#define GNNX_ABLATE(bit) false
+#endif
+// FUSE: the epilogue of the stacked layers' backward GEMM (SURVEY.md 2b "fused ops"): C = (A . B) masked
+// by the ReLU of the layer below (C[m][n] = 0 where Ymask[m][n] <= 0: Mask::_backward, reference operation.h:557-562) and
+// colsum_partial[blockIdx.y][n] = sum over this workgroup's rows of the masked C -- the bias gradient of the layer below
+// (Add::_backward -> sum_to_size, operation.h:114-128) -- so neither the unmasked gradient nor a separate column-sum pass
+// touches HBM.  The mask values are loaded with the same full-line pattern the stores use, under the LDS round trip.
+struct GemmFuse {
+    const float *ymask;      // [M][N] forward output of the layer below (ld ldy); mask = ymask > 0
+    int64_t ldy;
+    float *colsum_partial;   // [gridDim.y][N]
+};
+
+template <bool FUSE>
+__global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate, GemmFuse fu)
 {
+    (void)ablate;
     constexpr int BM = 256, BN = 256, BK = 32;
     constexpr int STAGE = BM * BK;                       // floats per A stage (32 KB)
     constexpr int BROW = 272;                            // B row stride in floats (256 + 16)
@@ -520,6 +538,8 @@ __global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_ti
 
     gemm_f32x4acc acc[4][4];
     float a[2][4], b[2][4];
+    gemm_f32x4acc csum = {0.f, 0.f, 0.f, 0.f};   // FUSE: column sums of this lane's 4 columns over every row it stores
+    const uint32_t offy = FUSE ? (uint32_t)((wm * 64 + (lane >> 4)) * fu.ldy + wn * 64 + 4 * (lane & 15)) * 4u : 0u;
     int64_t mt = blockIdx.y;
     if (mt < m_tiles) issue(0, mt, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -534,16 +554,16 @@ __global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_ti
                 for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
         for (int64_t k0 = 0; k0 < g.K; k0 += 2 * BK) {
             const bool last = k0 + 2 * BK >= g.K;
-            if (!(ablate & 2)) issue(1, mt, k0 + BK);   // K % 64 == 0: the odd K-tile of this trip always exists
+            if (!GNNX_ABLATE(2)) issue(1, mt, k0 + BK);   // K % 64 == 0: the odd K-tile of this trip always exists
             GNNX_DMA2_KTILE(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if ((!last || mt_next < m_tiles) && !(ablate & 2)) issue(0, last ? mt_next : mt, last ? 0 : k0 + 2 * BK);
+            if ((!last || mt_next < m_tiles) && !GNNX_ABLATE(2)) issue(0, last ? mt_next : mt, last ? 0 : k0 + 2 * BK);
             GNNX_DMA2_KTILE(1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (ablate & 1) {
+        if (GNNX_ABLATE(1)) {
             float s_ = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -556,6 +576,7 @@ __global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_ti
         }
         const float alpha = g.alpha;
         char *ctile = reinterpret_cast<char *>(g.C + mt * BM * g.ldc + n0);
+        const char *ytile = FUSE ? reinterpret_cast<const char *>(fu.ymask + mt * BM * fu.ldy + n0) : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -563,6 +584,13 @@ __global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_ti
                 gemm_f32x4acc v = acc[i][j];
                 if (alpha != 1.0f) v = v * alpha;
                 asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ep_wr), "v"(v), "i"(64 * j) : "memory");
+            }
+            gemm_f32x4acc ym[4];
+            if constexpr (FUSE) {   // issued behind the LDS writes (block row i's accumulators are dead by now: their registers
+                                    // take the mask values) and in flight during the LDS round trip below
+                const char *yrow = ytile + (int64_t)(16 * i) * fu.ldy * 4;
+#pragma unroll
+                for (int p = 0; p < 4; p++) ym[p] = *reinterpret_cast<const gemm_f32x4acc *>(yrow + (int64_t)(4 * p) * fu.ldy * 4 + offy);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             gemm_f32x4acc o[4];
@@ -573,8 +601,30 @@ __global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_ti
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])::"memory");
             char *crow = ctile + (int64_t)(16 * i) * g.ldc * 4;   // wave-uniform
 #pragma unroll
-            for (int p = 0; p < 4; p++)
+            for (int p = 0; p < 4; p++) {
+                if constexpr (FUSE) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) o[p][c] = ym[p][c] > 0.f ? o[p][c] : 0.f;
+                    csum += o[p];
+                }
                 *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * 4 + offc) = o[p];
+            }
+        }
+    }
+    if constexpr (FUSE) {
+        // column sums of the workgroup: lanes with equal (lane & 15) in the 4 wavefronts of a column group wn hold the same 4
+        // columns.  Everything is parked in LDS (the operand stages are dead: every DMA was waited for, the last K-tile
+        // ended with a barrier) and added in a fixed order: wm 0..3, lane group 0..3.
+        gemm_f32x4acc *red = reinterpret_cast<gemm_f32x4acc *>(lds_raw);   // [wave][lane]
+        __syncthreads();
+        red[wave * 64 + lane] = csum;
+        __syncthreads();
+        if (tid < 64) {   // thread t: columns 4t..4t+3 of the tile = column group t / 16, 16-byte column t % 16
+            const int cg = tid >> 4, c16 = tid & 15;
+            gemm_f32x4acc sum = {0.f, 0.f, 0.f, 0.f};
+            for (int w = 0; w < 4; w++)
+                for (int lg = 0; lg < 4; lg++) sum += red[(w * 4 + cg) * 64 + lg * 16 + c16];
+            *reinterpret_cast<gemm_f32x4acc *>(fu.colsum_partial + (int64_t)blockIdx.y * g.N + n0 + 4 * tid) = sum;
         }
     }
 }
@@ -670,7 +720,7 @@ enum TileId { kSquare = 0, kWide = 1, kK16 = 2, kWide32 = 3, kTall = 4, kTall32 
 int forced_tile()
 {
     static const int v = [] {
-        const char *e = getenv("GNNX_GEMM_TILE");
+        const char *e = experiment_env("GNNX_GEMM_TILE");
         if (!e) return -1;
         if (!strcmp(e, "square")) return (int)kSquare;
         if (!strcmp(e, "wide")) return (int)kWide;
@@ -724,11 +774,14 @@ int launch_one(const GemmArgs &g, int splits, hipStream_t st)
 {
     dim3 grid((uint32_t)ceil_div(g.N, C::BN), (uint32_t)ceil_div(g.M, C::BM), (uint32_t)splits);
     constexpr size_t lds = C::lds_bytes(A_KC, B_KC);
-    static bool attr_set = false;  // > 64 KB of dynamic LDS needs the opt-in, once per kernel instantiation
-    if (!attr_set) {
+    // > 64 KB of dynamic LDS needs the opt-in: once per kernel instantiation AND device (bit d of the mask; thread-safe)
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    static std::atomic<uint64_t> attr_done{0};
+    if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
         GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<C, A_KC, B_KC, VA, VB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
     }
     hipLaunchKernelGGL((gemm_kernel<C, A_KC, B_KC, VA, VB>), grid, dim3(C::NT), lds, st, g);
     GNNX_LAUNCH_CHECK();
@@ -749,9 +802,11 @@ int launch(const GemmArgs &g, int splits, bool va, bool vb, hipStream_t st)
 {
     switch (pick_tile(g.M, g.N)) {
     case kWide: return launch_cfg<CfgWide, A_KC, B_KC>(g, splits, va, vb, st);
+#ifdef GNNX_EXPERIMENTS
     case kK16: return launch_cfg<CfgK16, A_KC, B_KC>(g, splits, va, vb, st);
     case kWide32: return launch_cfg<CfgWide32, A_KC, B_KC>(g, splits, va, vb, st);
     case kTall: return launch_cfg<CfgTall, A_KC, B_KC>(g, splits, va, vb, st);
+#endif
     case kTall32: return launch_cfg<CfgTall32, A_KC, B_KC>(g, splits, va, vb, st);
     default: return launch_cfg<CfgDefault, A_KC, B_KC>(g, splits, va, vb, st);
     }
@@ -762,11 +817,13 @@ template <class C, bool B_KC>
 int launch_stream_cfg(const GemmArgs &g, int64_t m_tiles, int64_t gy, hipStream_t st)
 {
     constexpr size_t lds = C::lds_bytes(true, B_KC);
-    static bool attr_set = false;
-    if (!attr_set) {
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    static std::atomic<uint64_t> attr_done{0};
+    if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
         GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_stream_kernel<C, B_KC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
     }
     dim3 grid((uint32_t)(g.N / C::BN), (uint32_t)gy, 1);
     hipLaunchKernelGGL((gemm_stream_kernel<C, B_KC>), grid, dim3(C::NT), lds, st, g, m_tiles);
@@ -900,7 +957,7 @@ bool dma_shape_ok(int64_t M, int64_t N, int64_t K)
     return K % 64 == 0 && N % 256 == 0 && M >= 8 * 256;
 }
 
-int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done)
+int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse = nullptr, int64_t *partial_rows = nullptr)
 {
     *rows_done = 0;
     constexpr int BM = 256, BN = 256, BK = 32;
@@ -916,12 +973,21 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done)
     GNNX_HIP_CHECK(hipGetDevice(&dev));
     static std::atomic<uint64_t> attr_done{0};  // bit d: the dynamic-LDS opt-in has been set on device d
     if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds));
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_dma_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_dma_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
     }
-    static const int ablate = [] { const char *e = getenv("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL(gemm_dma_kernel, dim3((uint32_t)cols, (uint32_t)gy, 1), dim3(1024), lds, st, g, m_tiles, ablate);
+    static const int ablate = [] { const char *e = experiment_env("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
+    if (fuse) {
+        if (fuse->ldy % 4 || !aligned16(fuse->ymask) || (int64_t)BM * fuse->ldy >= (1ll << 28)) return GNNX_OK;
+        hipLaunchKernelGGL(gemm_dma_kernel<true>, grid, dim3(1024), lds, st, g, m_tiles, ablate, *fuse);
+        if (partial_rows) *partial_rows = gy;
+    } else {
+        hipLaunchKernelGGL(gemm_dma_kernel<false>, grid, dim3(1024), lds, st, g, m_tiles, ablate, GemmFuse{});
+    }
     GNNX_LAUNCH_CHECK();
     *rows_done = m_tiles * BM;
     return GNNX_OK;
@@ -964,10 +1030,11 @@ __global__ __launch_bounds__(256) void gemm_transpose_w_kernel(const float *X, i
 GNNX_API int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_sink, double *flops_out, void *stream)
 {
     GNNX_REQUIRE(iters > 0 && n_workgroups > 0 && d_sink, GNNX_ERR_INVALID_ARG, "bad arguments");
-    static const int peak_mode = [] { const char *e = getenv("GNNX_PEAK_MODE"); return e ? atoi(e) : 0; }();
+    static const int peak_mode = [] { const char *e = experiment_env("GNNX_PEAK_MODE"); return e ? atoi(e) : 0; }();
     const dim3 pg((uint32_t)n_workgroups), pb(256);
     hipStream_t pst = as_stream(stream);
     switch (peak_mode) {
+#ifdef GNNX_EXPERIMENTS
     case 1: hipLaunchKernelGGL(mfma_peak_kernel<1>, pg, pb, 0, pst, iters, d_sink); break;
     case 2: hipLaunchKernelGGL(mfma_peak_kernel<2>, pg, pb, 0, pst, iters, d_sink); break;
     case 4: hipLaunchKernelGGL(mfma_peak_kernel<4>, pg, pb, 0, pst, iters, d_sink); break;
@@ -976,6 +1043,7 @@ GNNX_API int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_si
     case 12: hipLaunchKernelGGL(mfma_peak_kernel<12>, pg, pb, 0, pst, iters, d_sink); break;
     case 20: hipLaunchKernelGGL(mfma_peak_kernel<20>, pg, pb, 0, pst, iters, d_sink); break;
     case 21: hipLaunchKernelGGL(mfma_peak_kernel<21>, pg, pb, 0, pst, iters, d_sink); break;
+#endif
     default: hipLaunchKernelGGL(mfma_peak_kernel<0>, pg, pb, 0, pst, iters, d_sink); break;
     }
     GNNX_LAUNCH_CHECK();
@@ -993,6 +1061,66 @@ GNNX_API int gnnx_gemm_workspace(int transA, int transB, int64_t M, int64_t N, i
         if (splits > 1) *bytes = sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
     } else if (!transA && transB && dma_shape_ok(M, N, K)) {
         *bytes = sizeof(float) * (size_t)K * (size_t)N;  // W^T as [K][N] for the LDS-DMA kernel
+    }
+    return GNNX_OK;
+}
+
+// C = (A . B) with the ReLU mask of the layer below applied, colsum[n] = sum_m C[m][n]: the stacked layers' backward step
+// G_{l-1} = (dH_l . W_l) (.) (Y_{l-1} > 0), db_{l-1} = colsum(G_{l-1}) in ONE pass over the output (LDS-DMA kernel, FUSE epilogue);
+// rows outside whole 256-row tiles and shapes the kernel does not cover go through gemm -> mask -> colsum.
+GNNX_API int gnnx_gemm_relu_colsum_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes)
+{
+    (void)K;
+    GNNX_REQUIRE(bytes && M >= 0 && N >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    size_t cs = 0;
+    int rc = gnnx_colsum_workspace(M > 256 ? M : 256, (int32_t)N, &cs);
+    if (rc) return rc;
+    *bytes = sizeof(float) * 256 * (size_t)N + cs;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_gemm_relu_colsum_f32(int64_t M, int64_t N, int64_t K, const float *d_A, int64_t lda, const float *d_B, int64_t ldb,
+                                       const float *d_Ymask, int64_t ldy, float *d_C, int64_t ldc, float *d_colsum, void *d_workspace,
+                                       size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(M >= 0 && N > 0 && K > 0 && N < (1ll << 31), GNNX_ERR_INVALID_ARG, "bad sizes");
+    GNNX_REQUIRE(d_colsum, GNNX_ERR_INVALID_ARG, "colsum is null");
+    size_t need = 0;
+    gnnx_gemm_relu_colsum_workspace(M, N, K, &need);
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    if (M == 0) {
+        GNNX_HIP_CHECK(hipMemsetAsync(d_colsum, 0, sizeof(float) * (size_t)N, st));
+        return GNNX_OK;
+    }
+    GNNX_REQUIRE(d_A && d_B && d_Ymask && d_C && lda >= K && ldb >= N && ldy >= N && ldc >= N, GNNX_ERR_INVALID_ARG, "null pointer or ld");
+    float *partial = static_cast<float *>(d_workspace);
+    void *cs_ws = static_cast<char *>(d_workspace) + sizeof(float) * 256 * (size_t)N;
+    const size_t cs_bytes = workspace_bytes - sizeof(float) * 256 * (size_t)N;
+    int64_t rows = 0, prow = 0;
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.A = d_A; g.lda = lda; g.B = d_B; g.ldb = ldb; g.C = d_C; g.ldc = ldc; g.alpha = 1.f; g.beta = 0.f;
+    g.k_per_split = K;
+    GemmFuse fu{d_Ymask, ldy, partial};
+    int rc = launch_dma(g, st, &rows, &fu, &prow);
+    if (rc) return rc;
+    float beta = 0.f;
+    if (rows > 0) {   // the workgroups' partial column sums -> colsum, fixed order
+        rc = gnnx_colsum_f32(partial, N, prow, (int32_t)N, 0.f, d_colsum, cs_ws, cs_bytes, stream);
+        if (rc) return rc;
+        beta = 1.f;
+    }
+    if (rows < M) {   // ragged tail (or a shape the fused kernel does not take): three plain passes over those rows
+        const int64_t mr = M - rows;
+        float *cr = d_C + rows * ldc;
+        const float *yr = d_Ymask + rows * ldy;
+        rc = gnnx_gemm_f32(0, 0, mr, N, K, 1.f, d_A + rows * lda, lda, d_B, ldb, 0.f, cr, ldc, nullptr, 0, stream);
+        if (rc) return rc;
+        rc = gnnx_bn_relu_bwd_f32(yr, ldy, yr, ldy, cr, ldc, mr, (int32_t)N, nullptr, nullptr, 0.f, nullptr, nullptr, 1, cr, ldc, nullptr, nullptr,
+                                  nullptr, 0, stream);
+        if (rc) return rc;
+        rc = gnnx_colsum_f32(cr, ldc, mr, (int32_t)N, beta, d_colsum, cs_ws, cs_bytes, stream);
+        if (rc) return rc;
     }
     return GNNX_OK;
 }
@@ -1032,7 +1160,7 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     // tall products with whole tiles: the resident streaming kernel takes the whole M-tiles, the generic kernel the rest
     // tall products with whole tiles: the LDS-DMA kernel takes the whole 256-row tiles (B k-major; for X.W^T the small W is
     // transposed once into the workspace, same products in the same order), the generic kernel the ragged rest
-    static const int dma_env = [] { const char *e = getenv("GNNX_GEMM_DMA"); return e ? atoi(e) : 1; }();
+    static const int dma_env = [] { const char *e = experiment_env("GNNX_GEMM_DMA"); return e ? atoi(e) : 1; }();
     if (dma_env > 0 && a_kc && splits == 1 && beta == 0.f && K > 0 && dma_shape_ok(M, N, K) &&
         (!b_kc || (d_workspace && workspace_bytes >= sizeof(float) * (size_t)K * (size_t)N && aligned16(d_workspace)))) {
         GemmArgs gd = g;
@@ -1052,7 +1180,7 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
         g.C += rows * ldc;
         g.M -= rows;
     }
-    static const int stream_env = [] { const char *e = getenv("GNNX_GEMM_STREAM"); return e ? atoi(e) : 1; }();
+    static const int stream_env = [] { const char *e = experiment_env("GNNX_GEMM_STREAM"); return e ? atoi(e) : 1; }();
     if (stream_env > 0 && a_kc && splits == 1 && beta == 0.f && va && vb && K > 0) {
         int64_t rows = 0;  // leading rows of C written by the streaming kernel
         const int src = launch_stream(g, b_kc, stream_env, st, &rows);

@@ -296,6 +296,43 @@ GNNX_API int gnnx_equal_i32(const int32_t *d_a, const int32_t *d_b, int64_t n, i
     return GNNX_OK;
 }
 
+__global__ void csr_validate_kernel(const int32_t *rowptr, const int32_t *colidx, int32_t n_rows, int32_t n_cols, int32_t *bad)
+{
+    int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const int32_t b = rowptr[r], e = rowptr[r + 1];
+    if (b < 0 || e < b || (r == 0 && b != 0)) {
+        *bad = 1;
+        return;
+    }
+    for (int32_t p = b; p < e; p++) {
+        const int32_t c = colidx[p];
+        if (c < 0 || c >= n_cols) *bad = 1;
+    }
+}
+
+GNNX_API int gnnx_csr_validate(const int32_t *d_rowptr, const int32_t *d_colidx, int32_t n_rows, int32_t n_cols, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0, GNNX_ERR_INVALID_ARG, "negative size");
+    if (n_rows == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_rowptr, GNNX_ERR_INVALID_ARG, "rowptr is null");
+    hipStream_t st = as_stream(stream);
+    int32_t h[2] = {0, 0};
+    GNNX_HIP_CHECK(hipMemcpyAsync(&h[0], d_rowptr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    GNNX_REQUIRE(h[0] >= 0 && (h[0] == 0 || d_colidx), GNNX_ERR_INVALID_ARG, "colidx is null but the graph has %d entries", h[0]);
+    int32_t *bad = nullptr;
+    GNNX_HIP_CHECK(hipMallocAsync((void **)&bad, sizeof(int32_t), st));
+    GNNX_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(csr_validate_kernel, dim3((uint32_t)ceil_div(n_rows, 256)), dim3(256), 0, st, d_rowptr, d_colidx, n_rows, n_cols, bad);
+    GNNX_LAUNCH_CHECK();
+    GNNX_HIP_CHECK(hipMemcpyAsync(&h[1], bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipFreeAsync(bad, st));
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    GNNX_REQUIRE(!h[1], GNNX_ERR_INDEX_RANGE, "CSR is malformed: rowptr not monotone from 0, or a column id outside [0, %d)", n_cols);
+    return GNNX_OK;
+}
+
 GNNX_API int gnnx_csr_from_coo_workspace(int64_t n_edges, int32_t n_nodes, size_t *bytes)
 {
     GNNX_REQUIRE(bytes && n_edges >= 0 && n_nodes >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");

@@ -521,6 +521,7 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     }
 }
 
+#ifdef GNNX_EXPERIMENTS
 // ---- LDS-staged variant (measurement only: GNNX_SPMM_VARIANT=lds, F = 256, forward mode) ---------------------------
 // Same streaming structure, but the neighbour rows land in LDS through LDS-DMA (global_load_lds_dwordx4: one 1-KiB
 // row per wave-instruction, per-lane source address = a row gather) and are summed from there, B = 16 rows per batch,
@@ -645,6 +646,8 @@ __global__ __launch_bounds__(64) void spmm_lds_kernel(SpmmArgs a, int32_t n_item
     }
 }
 
+#endif  // GNNX_EXPERIMENTS
+
 // Combine the partial slabs of split rows in chunk order (chunk 0 holds the HIGHEST columns), then the
 // same epilogue as the main kernel.  One G-lane group per split row.
 template <int G, int VEC>
@@ -702,7 +705,7 @@ __global__ void plan_fill_kernel(const int32_t *rowptr, int32_t n_rows, int32_t 
 bool use_stream_kernel(int G)
 {
     static const int forced = [] {
-        const char *v = getenv("GNNX_SPMM_VARIANT");
+        const char *v = experiment_env("GNNX_SPMM_VARIANT");
         if (!v) return 0;
         return strcmp(v, "rows") == 0 ? 1 : (strcmp(v, "stream") == 0 ? 2 : 0);
     }();
@@ -713,7 +716,7 @@ bool use_stream_kernel(int G)
 
 bool use_lds_variant()
 {
-    static const bool v = [] { const char *e = getenv("GNNX_SPMM_VARIANT"); return e && strcmp(e, "lds") == 0; }();
+    static const bool v = [] { const char *e = experiment_env("GNNX_SPMM_VARIANT"); return e && strcmp(e, "lds") == 0; }();
     return v;
 }
 
@@ -805,6 +808,7 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     const int mode = a.vals != nullptr ? (a.colscale ? 6 : 2) : (a.colscale ? 1 : (pro ? 2 + pro : 0));
     bool stream = false;
     if constexpr (G >= 8) stream = use_stream_kernel(G);
+#ifdef GNNX_EXPERIMENTS
     if constexpr (G == 64 && VEC == 4) {
         if (use_lds_variant() && a.n_feat == 256 && mode == 0 && !a.relu_out && !a.x_bf16) {  // measurement variant, forward mode only
             grid.x = (uint32_t)(a.n_items + (a.block_starts ? a.n_blocks : ceil_div(a.n_rows, StreamCfg<64>::R)));
@@ -819,12 +823,13 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
             return GNNX_OK;
         }
     }
+#endif
     if (stream) {
         if constexpr (G >= 8) {
             constexpr int R = StreamCfg<G>::R;
             // One wavefront per workgroup: a workgroup's CU slot is held until its slowest wavefront ends, and
             // blocks of a power-law graph differ a lot in non-zeros, so multi-wave workgroups strand slots.
-            static const int tpb_env = [] { const char *v = getenv("GNNX_SPMM_TPB"); return v ? atoi(v) : 64; }();
+            static const int tpb_env = [] { const char *v = experiment_env("GNNX_SPMM_TPB"); return v ? atoi(v) : 64; }();
             const int tpb = tpb_env == 256 ? 256 : 64;
             n_item_blocks = (int32_t)ceil_div(a.n_items, tpb / G);
             grid.x = (uint32_t)(n_item_blocks + (a.block_starts ? ceil_div(a.n_blocks, tpb / G)
@@ -881,7 +886,7 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
     }
     // non-zero-balanced row blocks
     {
-        static const int env_bn = [] { const char *v = getenv("GNNX_SPMM_BLOCK_NNZ"); return v ? atoi(v) : 0; }();
+        static const int env_bn = [] { const char *v = experiment_env("GNNX_SPMM_BLOCK_NNZ"); return v ? atoi(v) : 0; }();
         plan->block_nnz = env_bn > 0 ? env_bn : (chunk < 256 ? chunk : 256);
         int32_t *flag = nullptr, *pos = nullptr;
         void *tmp = nullptr;

@@ -199,6 +199,21 @@ def gemm(A, B, transA=False, transB=False, out=None, alpha=1.0, beta=0.0):
     return out
 
 
+def gemm_relu_colsum(A, B, Ymask, out=None, colsum_out=None):
+    """gnnx_gemm_relu_colsum_f32: C = (A . B) (.) (Ymask > 0), colsum = column sums of C -- the stacked layers' backward step
+    G_{l-1} = (dH_l . W_l) (.) relu'(Y_{l-1}), db_{l-1} = colsum(G_{l-1}) in one pass over the output."""
+    M, K = A.shape
+    N = B.shape[1]
+    out = torch.empty((M, N), dtype=torch.float32, device=A.device) if out is None else out
+    colsum_out = torch.empty(N, dtype=torch.float32, device=A.device) if colsum_out is None else colsum_out
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_gemm_relu_colsum_workspace", M, N, K, C.byref(wsb))
+    ws = _workspace(wsb.value, A.device, "gemm_fuse")
+    capi.call("gnnx_gemm_relu_colsum_f32", M, N, K, _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(Ymask), _ld(Ymask), _ptr(out), _ld(out),
+              _ptr(colsum_out), _ptr(ws), wsb.value, _stream())
+    return out, colsum_out
+
+
 def gemm_split(A, B, transB=False, out=None):
     """OPT-IN split-precision GEMM (gnnx_gemm_split_bf16_f32): A[M,K] . op(B) on the bf16 matrix cores from exact 3-way bf16
     splits of the f32 operands, f32 accumulation; f32-level accuracy, not the reference's arithmetic."""
@@ -446,15 +461,24 @@ class GcnStack:
         self._saved = saved
         return h
 
-    def backward(self, dOut):
+    def backward(self, dOut, fused=True):
+        """fused: the ReLU mask of the layer below and its bias gradient ride in the epilogue of dH . W
+        (gnnx_gemm_relu_colsum_f32); fused=False runs them as their own passes (same G bits, db within rounding)."""
         G = dOut
-        for l in reversed(range(len(self.W))):
+        L = len(self.W)
+        colsum(G, out=self.db[L - 1])
+        for l in reversed(range(L)):
             h, Y = self._saved[l]
-            if l + 1 < len(self.W):
-                G, _, _ = bn_relu_bwd(Y, Y, G, relu=True)
-            colsum(G, out=self.db[l])
             dH = aggregate_bwd(self.g, G)
-            G, _ = linear_bwd(dH, h, self.W[l], dW=self.dW[l])
+            gemm(dH, h, transA=True, out=self.dW[l])          # dW_l = dH^T . h
+            if l == 0:
+                G = gemm(dH, self.W[l])                          # dX of the first layer: no ReLU below it
+            elif fused:
+                G, _ = gemm_relu_colsum(dH, self.W[l], h, colsum_out=self.db[l - 1])   # h = Y_{l-1} = relu output of the layer below
+            else:
+                G = gemm(dH, self.W[l])
+                G, _, _ = bn_relu_bwd(h, h, G, relu=True)
+                colsum(G, out=self.db[l - 1])
         return G
 
     def step(self, lr, weight_decay=0.0):

@@ -95,6 +95,12 @@ int gnnx_csr_from_coo(const int32_t *d_src, const int32_t *d_dst, int64_t n_edge
                       int32_t *d_rowptr, int32_t *d_colidx, int64_t *nnz_out, void *d_workspace,
                       size_t workspace_bytes, void *stream);
 
+/* The SpMM entry points TRUST the CSR they are given (column ids index X without a bounds check: a check per gathered row would
+ * sit in the hottest loop).  A CSR made by gnnx_csr_from_coo / gnnx_halo_plan_create is valid by construction; validate one from
+ * anywhere else once, before its first use: rowptr[0] == 0, monotone, every column id in [0, n_cols).  Synchronises `stream`;
+ * GNNX_ERR_INDEX_RANGE otherwise. */
+int gnnx_csr_validate(const int32_t *d_rowptr, const int32_t *d_colidx, int32_t n_rows, int32_t n_cols, void *stream);
+
 /* *equal_out = 1 iff the two device arrays hold the same n int32 values (synchronises `stream`).  The host layer compares an
  * incoming edge_index with the copy its cached adjacency was built from, so an edge list edited in place -- or a new one that
  * happens to be allocated at the old address -- never hits a stale CSR / norm. */
@@ -211,6 +217,20 @@ int gnnx_gemm_workspace(int transA, int transB, int64_t M, int64_t N, int64_t K,
 int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float *d_A,
                   int64_t lda, const float *d_B, int64_t ldb, float beta, float *d_C, int64_t ldc,
                   void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* The backward GEMM of a stacked layer with its two followers fused into the epilogue:
+ *   C[M,N] = (A[M,K] . B[K,N]) masked by the ReLU of the layer below: C[m][n] = 0 where Ymask[m][n] <= 0   (Mask::_backward,
+ *            reference operation.h:557-562; Ymask = that layer's stored forward output)
+ *   colsum[n] = sum_m C[m][n]                                                 (its bias gradient: Add::_backward -> sum_to_size,
+ *            operation.h:114-128, tensor.h:618-638)
+ * i.e. G_{l-1} = (dH_l . W_l) (.) (Y_{l-1} > 0) and db_{l-1} in ONE pass over the output: the unmasked gradient is never written,
+ * the mask pass (read Y, read G, write G) and the column-sum pass (read G) disappear.  C holds the same bits as gnnx_gemm_f32
+ * followed by the mask; colsum is summed per workgroup then over workgroups in a fixed order (deterministic; a different order
+ * than gnnx_colsum_f32, so equal within rounding).  Any shape: what the fused kernel does not cover runs as three plain passes. */
+int gnnx_gemm_relu_colsum_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes);
+int gnnx_gemm_relu_colsum_f32(int64_t M, int64_t N, int64_t K, const float *d_A, int64_t lda, const float *d_B, int64_t ldb,
+                              const float *d_Ymask, int64_t ldy, float *d_C, int64_t ldc, float *d_colsum, void *d_workspace,
+                              size_t workspace_bytes, void *stream);
 
 /* OPT-IN split-precision GEMM -- never the default, not used by any parity-graded call.  C[M,N] = A[M,K] . op(B)
  * (transB: B is [N,K], else [K,N]) on the bf16 matrix cores: every f32 operand is split exactly into three bf16 pieces

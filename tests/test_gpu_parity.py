@@ -312,6 +312,45 @@ def test_gemm_splitk_lds_dma_kernel(env, n, fo, fi):
     assert torch.equal(c, a + a)
 
 
+@pytest.mark.parametrize("M,N,K", [(300_077, 256, 256), (70_000, 512, 128), (5_000, 256, 256), (40_000, 128, 128), (3_000, 100, 100)])
+def test_gemm_with_fused_relu_mask_and_colsum_epilogue(env, M, N, K):
+    """gnnx_gemm_relu_colsum_f32 -- G = (dH . W) (.) (Y > 0) and db = colsum(G) in the GEMM epilogue (stacked layers' backward) --
+    against the three separate passes: G bit-identical (same GEMM chain, the mask is exact), db within rounding of the
+    float64 column sums; shapes with whole 256-row tiles + ragged tail (fused kernel + fallback rows), widths the fused kernel
+    does not take (pure fallback), and run-to-run identical."""
+    ops, torch = env["ops"], env["torch"]
+    dH = ops.uniform_pm1(81, (M, K), device=env["dev"])
+    W = ops.uniform_pm1(82, (K, N), scale=K ** -0.5, device=env["dev"])
+    Y = torch.relu(ops.uniform_pm1(83, (M, N), device=env["dev"]))      # a ReLU output: about half zeros
+    G, db = ops.gemm_relu_colsum(dH, W, Y)
+    G2, db2 = ops.gemm_relu_colsum(dH, W, Y)
+    assert torch.equal(G, G2) and torch.equal(db, db2)
+    ref = ops.gemm(dH, W)
+    ref = torch.where(Y > 0, ref, torch.zeros_like(ref))
+    assert torch.equal(G, ref), "masked GEMM output differs from gemm + mask"
+    exact = ref.double().sum(0)
+    bound = 1e-5 * max(1.0, float(ref.abs().double().sum(0).max()))
+    assert float((db.double() - exact).abs().max()) <= bound
+
+
+def test_gcn_stack_backward_fused_equals_unfused(env):
+    ops, torch = env["ops"], env["torch"]
+    n, e, F = 30_000, 300_000, 256
+    src, dst, rp, ci, g = make_graph(env, n, e, seed=41)
+    net = ops.GcnStack(g, [F, F, F], seed=7, device=env["dev"])
+    X = ops.uniform_pm1(91, (n, F), device=env["dev"])
+    dOut = ops.uniform_pm1(92, (n, F), device=env["dev"])
+    net.forward(X)
+    ga = net.backward(dOut, fused=True).clone()
+    dWa, dba = [w.clone() for w in net.dW], [b.clone() for b in net.db]
+    gb = net.backward(dOut, fused=False)
+    assert torch.equal(ga, gb)
+    for a, b in zip(dWa, net.dW):
+        assert torch.equal(a, b)
+    for a, b in zip(dba, net.db):
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+
+
 def test_gemm_beta_accumulate(env):
     ops = env["ops"]
     A = synth.uniform_pm1(71, (300, 40))
@@ -774,18 +813,20 @@ def test_two_layer_training_step_vs_float64(env):
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
 
-def test_lds_staged_variant_is_bit_exact_too(env):
-    """GNNX_SPMM_VARIANT=lds (LDS-DMA staging of the neighbour rows, kept as a measured alternative: DESIGN.md 4.1) is read
-    once per process, so run the F = 256 parity cases in a child interpreter with the variable set."""
-    import os
-    import subprocess
-    import sys
-    from tests.helpers import ROOT
-    e = dict(os.environ, GNNX_SPMM_VARIANT="lds")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-m", "gpu", "-q", "-x",
-                        "-k", "spmm_forward_backward_bit_exact_vs_oracle or spmm_accumulate or golden_aggregate"],
-                       capture_output=True, text=True, env=e, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+def test_csr_validate_rejects_foreign_csr_with_bad_columns(env):
+    """The SpMM trusts its CSR; gnnx_csr_validate is the one-off check for a CSR that did not come from the builder."""
+    ops, capi, torch = env["ops"], env["capi"], env["torch"]
+    src, dst, rp, ci, g = make_graph(env, 500, 4000, seed=31)
+    capi.call("gnnx_csr_validate", ops._ptr(g.rowptr), ops._ptr(g.colidx), g.n, g.n, ops._stream())
+    bad = g.colidx.clone()
+    bad[17] = g.n  # one past the last column
+    with pytest.raises(capi.GnnxError) as ei:
+        capi.call("gnnx_csr_validate", ops._ptr(g.rowptr), ops._ptr(bad), g.n, g.n, ops._stream())
+    assert ei.value.status == -3
+    rp2 = g.rowptr.clone()
+    rp2[5] = rp2[6] + 1  # not monotone
+    with pytest.raises(capi.GnnxError):
+        capi.call("gnnx_csr_validate", ops._ptr(rp2), ops._ptr(g.colidx), g.n, g.n, ops._stream())
 
 
 @pytest.mark.parametrize("self_term", [False, True])
