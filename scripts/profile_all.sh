@@ -1,0 +1,33 @@
+#!/usr/bin/env bash
+# Round profile set (run ON THE GPU BOX through gpurun, from the repo root):
+#   bash scripts/profile_all.sh r02
+# For every workload: one `rocprofv3 --kernel-trace --stats` pass and two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE; never
+# combined with a trace domain) of the SAME bench command; for the GEMMs one SQ-counter pass of scripts/exp_gemm.py.  Raw output
+# lands under gpurun_out/prof_<tag>_*; scripts/summarize_profile.py turns it into the small files committed under profiles/.
+set -euo pipefail
+TAG=${1:-r02}
+ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+OUT="$ROOT/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+run_set() {  # name, bench args...
+  local name=$1; shift
+  rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_${name}_stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline "$@" > "$OUT/prof_${TAG}_${name}_stats.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/prof_${TAG}_${name}_fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/prof_${TAG}_${name}_write.log" 2>&1
+  (cd "$ROOT" && WORKLOAD="${WL:-rmat10m_100m_f256}" PROFILE_CMD="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $*" \
+     python3 scripts/summarize_profile.py "${TAG}_bench_${name}" "$OUT/prof_${TAG}_${name}_stats" "$OUT/prof_${TAG}_${name}_fetch" "$OUT/prof_${TAG}_${name}_write")
+  echo "profiled $name"
+}
+WL=rmat10m_100m_f256 run_set rmat10m
+WL=rmat1m_10m_f128 run_set rmat1m_10m_f128 --workload rmat1m_10m_f128
+WL=products_2p4m_62m_f100 run_set products_2p4m_62m_f100 --workload products_2p4m_62m_f100
+# whole 2-layer training step on the headline graph: kernel stats only
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_train2_stats" -- python3 "$ROOT/bench.py" --train-layers 2 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/prof_${TAG}_train2_stats.log" 2>&1
+(cd "$ROOT" && python3 scripts/summarize_profile.py "${TAG}_bench_rmat10m_train2" "$OUT/prof_${TAG}_train2_stats")
+echo "profiled train2"
+# GEMM SQ counters (MFMA busy, waits, LDS conflicts) on the three 10M x 256 x 256 products
+FS=256 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -f csv \
+  -d "$OUT/prof_${TAG}_gemm_sq" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm_sq.log" 2>&1
+FS=256 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_gemm_stats" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm_stats.log" 2>&1
+(cd "$ROOT" && python3 scripts/summarize_profile.py --sq "${TAG}_gemm_sq_counters" "$OUT/prof_${TAG}_gemm_sq" "$OUT/prof_${TAG}_gemm_stats")
+echo "profiled gemm sq"

@@ -44,7 +44,34 @@ def counters(d, counter):
     return {k: sum(v) / len(v) * 1024.0 for k, v in acc.items()}  # KiB -> bytes, mean per launch
 
 
+def sq_summary(tag, sq_dir, stats_dir):
+    """profiles/<tag>.json: mean SQ counters per GEMM kernel + mean duration from the stats pass of the same command."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(one(os.path.join(sq_dir, "*", "*_counter_collection.csv")))):
+        k = short(r["Kernel_Name"])
+        if re.search(r"gemm|splitk|mfma", k):
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = {short(r["Name"]): float(r["AverageNs"]) / 1e6 for r in csv.DictReader(open(one(os.path.join(stats_dir, "*", "*_kernel_stats.csv"))))}
+    res = {}
+    for k, cs in acc.items():
+        row = {c: sum(v) / len(v) for c, v in cs.items()}
+        row["mean_duration_ms"] = dur.get(k)
+        if row.get("mean_duration_ms") and "SQ_VALU_MFMA_BUSY_CYCLES" in row:
+            # 1024 SIMDs; clock taken as 2.4 GHz (the GEMMs hold 2.33-2.41 GHz: DESIGN.md section 4.2)
+            row["mfma_pipe_busy_frac_at_2p4GHz"] = row["SQ_VALU_MFMA_BUSY_CYCLES"] / (row["mean_duration_ms"] * 1e-3 * 2.4e9 * 1024)
+        res[k] = row
+    out = os.path.join(ROOT, "profiles", f"{tag}.json")
+    json.dump({"command": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
+                          "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -- python3 scripts/exp_gemm.py (FS=256: 10M x 256 x 256 products + one 4096^3); "
+                          "durations from a separate --kernel-trace --stats pass of the same command",
+               "note": "means over the dispatches of each kernel; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_* count quad-cycles, "
+                       "SQ_VALU_MFMA_BUSY_CYCLES cycles (MI355X_MICROARCH.md)", "kernels": res}, open(out, "w"), indent=1)
+    print("wrote", out)
+
+
 def main():
+    if sys.argv[1] == "--sq":
+        return sq_summary(sys.argv[2], sys.argv[3], sys.argv[4])
     tag, stats_dir = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     rows = list(csv.DictReader(open(one(os.path.join(stats_dir, "*", "*_kernel_stats.csv")))))
@@ -60,7 +87,7 @@ def main():
         fetch, write = counters(sys.argv[3], "FETCH_SIZE"), counters(sys.argv[4], "WRITE_SIZE")
         res = {}
         for k in sorted(set(fetch) | set(write)):
-            if not re.search(r"spmm|gemm_kernel|gemm_stream_kernel|colsum_stage1|splitk|rows_kernel", k):
+            if not re.search(r"spmm|gemm_kernel|gemm_stream_kernel|gemm_dma|colsum_stage1|splitk|rows_kernel", k):
                 continue
             fb, wb = fetch.get(k, 0.0), write.get(k, 0.0)
             res[k] = {"fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb}
