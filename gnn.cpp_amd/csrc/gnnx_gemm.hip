@@ -410,15 +410,36 @@ __device__ __forceinline__ void lds_read_b32(float &dst, uint32_t addr)
     asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
 }
 
-template <int STAGE_ID, int KG>
+// Geometry of an LDS-DMA GEMM workgroup: WM x WN wavefronts of 64 x 64 -> BM x BN output tile.  4 x 4 (1024 threads, 256 x 256)
+// is the bench shape; 4 x 2 (512 threads, 256 x 128) takes 128-wide outputs (BASELINE configs[2]).  A k-major operand row of
+// 256 floats is one wave-instruction (padded to 272 words in LDS: conflict-free); one of 128 floats is half of one, two
+// consecutive k rows per instruction, which forces an unpadded 128-word stride (2-way conflicts on those reads: 4 instead of 2
+// LDS cycles; LDS stays far from saturated).
+template <int WM_, int WN_>
+struct DmaGeo {
+    static constexpr int WM = WM_, WN = WN_, NW = WM * WN, NT = 64 * NW;
+    static constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
+    static constexpr int A_STAGE_BYTES = BM * BK * 4;                 // K-contiguous image: [BM rows][8 slots of 16 B]
+    static constexpr int A_PER_WAVE = (BM / 8) / NW;                  // 1-KiB wave-instructions per wavefront and K-tile
+    static constexpr int row_words(int width) { return width == 256 ? 272 : width; }
+    static constexpr int rows_per_instr(int width) { return 256 / width; }
+    static constexpr int BROW = row_words(BN);                        // k-major B: row stride in floats
+    static constexpr int B_STAGE_BYTES = BK * BROW * 4;
+    static constexpr int B_PIECE_BYTES = rows_per_instr(BN) * BROW * 4;   // LDS bytes one B wave-instruction covers (>= 1024)
+    static constexpr int B_PER_WAVE = (BK / rows_per_instr(BN)) / NW;
+    static constexpr int LDS_BYTES = 2 * A_STAGE_BYTES + 2 * B_STAGE_BYTES;
+    static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1 && A_PER_WAVE + B_PER_WAVE >= 4, "the epilogue needs four private 1-KiB pieces");
+};
+
+template <class GEO, int STAGE_ID, int KG>
 __device__ __forceinline__ void dma2_read_group(float (&a)[4], float (&b)[4], const uint32_t (&ak)[8], uint32_t bk)
 {
-    constexpr int SA = STAGE_ID * 32768;
+    constexpr int SA = STAGE_ID * GEO::A_STAGE_BYTES;
     lds_read_b32<SA + 0 * 2048>(a[0], ak[KG]);
     lds_read_b32<SA + 1 * 2048>(a[1], ak[KG]);
     lds_read_b32<SA + 2 * 2048>(a[2], ak[KG]);
     lds_read_b32<SA + 3 * 2048>(a[3], ak[KG]);
-    constexpr int SB = STAGE_ID * (32 * 272 * 4) + 4 * KG * 272 * 4;  // k row 4 KG + q (q is in the address register)
+    constexpr int SB = STAGE_ID * GEO::B_STAGE_BYTES + 4 * KG * GEO::BROW * 4;  // k row 4 KG + q (q is in the address register)
     lds_read_b32<SB + 0 * 64>(b[0], bk);
     lds_read_b32<SB + 1 * 64>(b[1], bk);
     lds_read_b32<SB + 2 * 64>(b[2], bk);
@@ -433,11 +454,11 @@ __device__ __forceinline__ void dma2_read_group(float (&a)[4], float (&b)[4], co
         acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[set][j_], a[set][i_], acc[i_][j_], 0, 0, 0)
 // one k-group: fragments of group KG + 1 on their way while group KG is multiplied
 #define GNNX_DMA2_STEP(ST, KG, cur, nxt)                                  \
-    dma2_read_group<ST, KG + 1>(a[nxt], b[nxt], ak, bk);            \
+    dma2_read_group<GEO, ST, KG + 1>(a[nxt], b[nxt], ak, bk);            \
     GNNX_DMA2_WAIT(8, cur);                                               \
     GNNX_DMA2_MFMA(cur)
 #define GNNX_DMA2_KTILE(ST)                                               \
-    dma2_read_group<ST, 0>(a[0], b[0], ak, bk);                     \
+    dma2_read_group<GEO, ST, 0>(a[0], b[0], ak, bk);                     \
     GNNX_DMA2_STEP(ST, 0, 0, 1);                                          \
     GNNX_DMA2_STEP(ST, 1, 1, 0);                                          \
     GNNX_DMA2_STEP(ST, 2, 0, 1);                                          \
@@ -474,44 +495,48 @@ struct GemmFuse {
     float *colsum_partial;   // [gridDim.y][N]
 };
 
-template <bool FUSE>
-__global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate, GemmFuse fu)
+template <int WM_, int WN_, bool FUSE>
+__global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate, GemmFuse fu)
 {
     (void)ablate;
-    constexpr int BM = 256, BN = 256, BK = 32;
-    constexpr int STAGE = BM * BK;                       // floats per A stage (32 KB)
-    constexpr int BROW = 272;                            // B row stride in floats (256 + 16)
-    constexpr int BSTAGE = BK * BROW;
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][A stage] at 0, [2][B stage] at 64 KB
+    using GEO = DmaGeo<WM_, WN_>;
+    constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK, NW = GEO::NW, BROW = GEO::BROW;
+    constexpr int APW = GEO::A_PER_WAVE, BPW = GEO::B_PER_WAVE;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][A stage], then [2][B stage]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / GEO::WN, wn = wave % GEO::WN;
     const int q = lane >> 4, r16 = lane & 15;
     const int64_t n0 = (int64_t)blockIdx.x * BN;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(gemm_lds_void_t *)lds_raw;
+    constexpr uint32_t B0 = 2 * GEO::A_STAGE_BYTES;   // byte offset of the B stages
 
-    // ---- DMA: per-lane BYTE offsets inside an operand tile (u = 0, 1: this wavefront's two wave-instructions per operand)
-    uint32_t offa[2], offb[2];
+    // ---- DMA: per-lane BYTE offsets inside an operand tile; wave-instruction (wave + NW u) of the K-tile
+    uint32_t offa[APW], offb[BPW], pa[APW], pb[BPW];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-        const int row = 8 * (wave + 16 * u) + (lane >> 3);
+    for (int u = 0; u < APW; u++) {
+        const int row = 8 * (wave + NW * u) + (lane >> 3);
         const int kg = (lane & 7) ^ ((row >> 1) & 7);
         offa[u] = (uint32_t)(row * g.lda + 4 * kg) * 4u;
-        offb[u] = (uint32_t)((wave + 16 * u) * g.ldb + 4 * lane) * 4u;   // k row (wave + 16 u), 256 consecutive n
+        pa[u] = lds0 + (uint32_t)((wave + NW * u) * 1024);
+    }
+#pragma unroll
+    for (int u = 0; u < BPW; u++) {
+        constexpr int RPI = GEO::rows_per_instr(BN), LPR = 64 / RPI;   // k rows per instruction, lanes per row
+        const int krow = (wave + NW * u) * RPI + lane / LPR;
+        offb[u] = (uint32_t)(krow * g.ldb + 4 * (lane % LPR)) * 4u;
+        pb[u] = lds0 + B0 + (uint32_t)((wave + NW * u) * GEO::B_PIECE_BYTES);
     }
     const float *bcol = g.B + n0;
-    const int64_t bstep = g.ldb;
-    // LDS byte addresses of this wavefront's four 1-KiB DMA pieces per stage: A piece u, B piece u
-    const uint32_t pa0 = lds0 + (uint32_t)(wave * 1024), pa1 = pa0 + 16 * 1024;
-    const uint32_t pb0 = lds0 + 2 * STAGE * 4 + (uint32_t)(wave * BROW * 4), pb1 = pb0 + 16 * BROW * 4;
     auto issue = [&](int stage, int64_t mt, int64_t k0) {
         const float *abase = g.A + mt * BM * g.lda + k0;
-        const float *bbase = bcol + k0 * bstep;
-        dma_16B(offa[0], abase, pa0 + stage * STAGE * 4);
-        dma_16B(offb[0], bbase, pb0 + stage * BSTAGE * 4);
-        dma_16B(offa[1], abase, pa1 + stage * STAGE * 4);
-        dma_16B(offb[1], bbase, pb1 + stage * BSTAGE * 4);
+        const float *bbase = bcol + k0 * g.ldb;
+#pragma unroll
+        for (int u = 0; u < (APW > BPW ? APW : BPW); u++) {
+            if (u < APW) dma_16B(offa[u < APW ? u : 0], abase, pa[u < APW ? u : 0] + stage * GEO::A_STAGE_BYTES);
+            if (u < BPW) dma_16B(offb[u < BPW ? u : 0], bbase, pb[u < BPW ? u : 0] + stage * GEO::B_STAGE_BYTES);
+        }
     };
     // ---- fragment address registers (bytes): the 8 k-groups of this lane's row of block 0 (the row's slot XOR is the same in
     // every 16-row block: (16 i + r) >> 1 & 7 == r >> 1 & 7)
@@ -522,16 +547,21 @@ __global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_ti
 #pragma unroll
         for (int kg = 0; kg < 8; kg++) ak[kg] = lds0 + (uint32_t)(row * 128 + 4 * q) + (((uint32_t)kg << 4) ^ xa);
     }
-    const uint32_t bk = lds0 + 2 * STAGE * 4 + (uint32_t)(q * BROW * 4 + (wn * 64 + r16) * 4);
+    const uint32_t bk = lds0 + B0 + (uint32_t)(q * BROW * 4 + (wn * 64 + r16) * 4);
     // ---- epilogue through LDS.  D = mfma(b, a): a lane holds C[16 i + r16][16 j + 4 q .. + 3] of its wavefront's 64 x 64
-    // block.  Block row i (16 rows x 64 columns = 4 KB) is written to the wavefront's OWN four DMA pieces of stage 1 (free
+    // block.  Block row i (16 rows x 64 columns = 4 KB) is written to four of the wavefront's OWN DMA pieces of stage 1 (free
     // after the tile's last K-tile; only this wavefront's next DMA overwrites them, and that is issued behind its reads), piece
     // p = rows 4p..4p+3, and read back one piece per instruction: 64 lanes x 16 B = 4 rows x 256 B = whole 128-byte lines per
     // store.  16-byte columns are XORed with (row & 3) to spread the writers over the banks.
-    const uint32_t ep_piece = (r16 >> 2) == 0 ? pa0 : (r16 >> 2) == 1 ? pb0 : (r16 >> 2) == 2 ? pa1 : pb1;  // + stage 1 below
-    const uint32_t ep_st1 = STAGE * 4;  // K-contiguous stage 1 is +32 KB for A pieces ...
-    const uint32_t ep_wr = ep_piece + (((r16 >> 2) & 1) ? (uint32_t)(BSTAGE * 4) : ep_st1) +
-                           (uint32_t)((r16 & 3) * 256) + (uint32_t)((q ^ (r16 & 3)) << 4);   // + 64 j
+    uint32_t ep[4];   // stage-1 byte address of private piece p
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        if (p < APW) ep[p] = pa[p < APW ? p : 0] + GEO::A_STAGE_BYTES;
+        else ep[p] = pb[p >= APW && p - APW < BPW ? p - APW : 0] + GEO::B_STAGE_BYTES;
+    }
+    const int pw = r16 >> 2;
+    const uint32_t ep_wr = (pw == 0 ? ep[0] : pw == 1 ? ep[1] : pw == 2 ? ep[2] : ep[3]) + (uint32_t)((r16 & 3) * 256) +
+                           (uint32_t)((q ^ (r16 & 3)) << 4);   // + 64 j
     // reader: lane L reads 16 B at byte L*16 of a piece = row L/16, 16-B column L%16 (stored at column ^ (row & 3))
     const uint32_t ep_rd = (uint32_t)((lane >> 4) * 256) + (uint32_t)(((lane & 15) ^ (lane >> 4)) << 4);
     const uint32_t offc = (uint32_t)((wm * 64 + (lane >> 4)) * g.ldc + wn * 64 + 4 * (lane & 15)) * 4u;  // bytes: row L/16, col 4 (L%16)
@@ -594,10 +624,8 @@ __global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_ti
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             gemm_f32x4acc o[4];
-            asm volatile("ds_read_b128 %0, %1" : "=v"(o[0]) : "v"(ep_rd + pa0 + ep_st1) : "memory");
-            asm volatile("ds_read_b128 %0, %1" : "=v"(o[1]) : "v"(ep_rd + pb0 + (uint32_t)(BSTAGE * 4)) : "memory");
-            asm volatile("ds_read_b128 %0, %1" : "=v"(o[2]) : "v"(ep_rd + pa1 + ep_st1) : "memory");
-            asm volatile("ds_read_b128 %0, %1" : "=v"(o[3]) : "v"(ep_rd + pb1 + (uint32_t)(BSTAGE * 4)) : "memory");
+#pragma unroll
+            for (int p = 0; p < 4; p++) asm volatile("ds_read_b128 %0, %1" : "=v"(o[p]) : "v"(ep_rd + ep[p]) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])::"memory");
             char *crow = ctile + (int64_t)(16 * i) * g.ldc * 4;   // wave-uniform
 #pragma unroll
@@ -612,18 +640,18 @@ __global__ __launch_bounds__(1024) void gemm_dma_kernel(GemmArgs g, int64_t m_ti
         }
     }
     if constexpr (FUSE) {
-        // column sums of the workgroup: lanes with equal (lane & 15) in the 4 wavefronts of a column group wn hold the same 4
+        // column sums of the workgroup: lanes with equal (lane & 15) in the WM wavefronts of a column group wn hold the same 4
         // columns.  Everything is parked in LDS (the operand stages are dead: every DMA was waited for, the last K-tile
-        // ended with a barrier) and added in a fixed order: wm 0..3, lane group 0..3.
+        // ended with a barrier) and added in a fixed order: wm 0..WM-1, lane group 0..3.
         gemm_f32x4acc *red = reinterpret_cast<gemm_f32x4acc *>(lds_raw);   // [wave][lane]
         __syncthreads();
         red[wave * 64 + lane] = csum;
         __syncthreads();
-        if (tid < 64) {   // thread t: columns 4t..4t+3 of the tile = column group t / 16, 16-byte column t % 16
+        if (tid < BN / 4) {   // thread t: columns 4t..4t+3 of the tile = column group t / 16, 16-byte column t % 16
             const int cg = tid >> 4, c16 = tid & 15;
             gemm_f32x4acc sum = {0.f, 0.f, 0.f, 0.f};
-            for (int w = 0; w < 4; w++)
-                for (int lg = 0; lg < 4; lg++) sum += red[(w * 4 + cg) * 64 + lg * 16 + c16];
+            for (int w = 0; w < GEO::WM; w++)
+                for (int lg = 0; lg < 4; lg++) sum += red[(w * GEO::WN + cg) * 64 + lg * 16 + c16];
             *reinterpret_cast<gemm_f32x4acc *>(fu.colsum_partial + (int64_t)blockIdx.y * g.N + n0 + 4 * tid) = sum;
         }
     }
@@ -863,25 +891,26 @@ int launch_stream(const GemmArgs &g, bool b_kc, int waves_per_slot, hipStream_t 
 // wave-instruction per row, rows padded to 272 words in LDS; a lane's fragment word is base + immediate for both operands
 // (two address registers in all).  A workgroup owns one 256 x 256 output tile and a K range (blockIdx.z); its partial tile
 // goes to the split-K slab once, at the end, and the slabs are summed in a fixed order by splitk_reduce_kernel.
-template <int STAGE_ID, int KG>
+template <class GEO, int STAGE_ID, int KG>
 __device__ __forceinline__ void dma_tn_read_group(float (&a)[4], float (&b)[4], uint32_t ak, uint32_t bk)
 {
-    constexpr int SB = STAGE_ID * (32 * 272 * 4) + 4 * KG * 272 * 4;
-    lds_read_b32<SB + 0 * 64>(a[0], ak);
-    lds_read_b32<SB + 1 * 64>(a[1], ak);
-    lds_read_b32<SB + 2 * 64>(a[2], ak);
-    lds_read_b32<SB + 3 * 64>(a[3], ak);
+    constexpr int SA = STAGE_ID * GEO::AT_STAGE_BYTES + 4 * KG * GEO::AROW * 4;
+    constexpr int SB = STAGE_ID * GEO::B_STAGE_BYTES + 4 * KG * GEO::BROW * 4;
+    lds_read_b32<SA + 0 * 64>(a[0], ak);
+    lds_read_b32<SA + 1 * 64>(a[1], ak);
+    lds_read_b32<SA + 2 * 64>(a[2], ak);
+    lds_read_b32<SA + 3 * 64>(a[3], ak);
     lds_read_b32<SB + 0 * 64>(b[0], bk);
     lds_read_b32<SB + 1 * 64>(b[1], bk);
     lds_read_b32<SB + 2 * 64>(b[2], bk);
     lds_read_b32<SB + 3 * 64>(b[3], bk);
 }
 #define GNNX_DMATN_STEP(ST, KG, cur, nxt)                                 \
-    dma_tn_read_group<ST, KG + 1>(a[nxt], b[nxt], ak, bk);                \
+    dma_tn_read_group<GEO, ST, KG + 1>(a[nxt], b[nxt], ak, bk);           \
     GNNX_DMA2_WAIT(8, cur);                                               \
     GNNX_DMA2_MFMA(cur)
 #define GNNX_DMATN_KTILE(ST)                                              \
-    dma_tn_read_group<ST, 0>(a[0], b[0], ak, bk);                         \
+    dma_tn_read_group<GEO, ST, 0>(a[0], b[0], ak, bk);                    \
     GNNX_DMATN_STEP(ST, 0, 0, 1);                                         \
     GNNX_DMATN_STEP(ST, 1, 1, 0);                                         \
     GNNX_DMATN_STEP(ST, 2, 0, 1);                                         \
@@ -892,36 +921,61 @@ __device__ __forceinline__ void dma_tn_read_group(float (&a)[4], float (&b)[4], 
     GNNX_DMA2_WAIT(0, 1);                                                 \
     GNNX_DMA2_MFMA(1)
 
-__global__ __launch_bounds__(1024) void gemm_dma_tn_kernel(GemmArgs g)
+// both operands k-major: A^T tile [32 k][BM m], B tile [32 k][BN n]
+template <int WM_, int WN_>
+struct DmaGeoTN : DmaGeo<WM_, WN_> {
+    using Base = DmaGeo<WM_, WN_>;
+    static constexpr int AROW = Base::row_words(Base::BM);
+    static constexpr int AT_STAGE_BYTES = Base::BK * AROW * 4;
+    static constexpr int AT_PIECE_BYTES = Base::rows_per_instr(Base::BM) * AROW * 4;
+    static constexpr int AT_PER_WAVE = (Base::BK / Base::rows_per_instr(Base::BM)) / Base::NW;
+    static constexpr int LDS_BYTES_TN = 2 * AT_STAGE_BYTES + 2 * Base::B_STAGE_BYTES;
+    static_assert(AT_PER_WAVE >= 1, "too many wavefronts for the operand tile");
+};
+
+template <int WM_, int WN_>
+__global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_tn_kernel(GemmArgs g)
 {
-    constexpr int BM = 256, BN = 256, BK = 32;
-    constexpr int BROW = 272, STAGE = BK * BROW;          // floats per operand stage (34 KB)
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][A stage] then [2][B stage] = 136 KB
+    using GEO = DmaGeoTN<WM_, WN_>;
+    constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK, NW = GEO::NW;
+    constexpr int APW = GEO::AT_PER_WAVE, BPW = GEO::B_PER_WAVE;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][A^T stage] then [2][B stage]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / GEO::WN, wn = wave % GEO::WN;
     const int q = lane >> 4, r16 = lane & 15;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
     const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;   // (kend - kbeg) % 64 == 0 (host)
     const uint32_t lds0 = (uint32_t)(uintptr_t)(gemm_lds_void_t *)lds_raw;
-    // DMA: wave-instruction (wave + 16 u) = k row (wave + 16 u) of the K-tile, lane = 4 consecutive m (n)
-    const uint32_t offa0 = (uint32_t)(wave * g.lda + 4 * lane) * 4u, offa1 = offa0 + (uint32_t)(16 * g.lda) * 4u;
-    const uint32_t offb0 = (uint32_t)(wave * g.ldb + 4 * lane) * 4u, offb1 = offb0 + (uint32_t)(16 * g.ldb) * 4u;
-    const uint32_t pa0 = lds0 + (uint32_t)(wave * BROW * 4), pa1 = pa0 + 16 * BROW * 4;
-    const uint32_t pb0 = pa0 + 2 * STAGE * 4, pb1 = pb0 + 16 * BROW * 4;
+    constexpr uint32_t B0 = 2 * GEO::AT_STAGE_BYTES;
+    // DMA: wave-instruction (wave + NW u) covers 1 (256-wide) or 2 (128-wide) k rows; a lane moves 4 consecutive m (n)
+    uint32_t offa[APW], offb[BPW], pa[APW], pb[BPW];
+#pragma unroll
+    for (int u = 0; u < APW; u++) {
+        constexpr int RPI = GEO::rows_per_instr(BM), LPR = 64 / RPI;
+        offa[u] = (uint32_t)(((wave + NW * u) * RPI + lane / LPR) * g.lda + 4 * (lane % LPR)) * 4u;
+        pa[u] = lds0 + (uint32_t)((wave + NW * u) * GEO::AT_PIECE_BYTES);
+    }
+#pragma unroll
+    for (int u = 0; u < BPW; u++) {
+        constexpr int RPI = GEO::rows_per_instr(BN), LPR = 64 / RPI;
+        offb[u] = (uint32_t)(((wave + NW * u) * RPI + lane / LPR) * g.ldb + 4 * (lane % LPR)) * 4u;
+        pb[u] = lds0 + B0 + (uint32_t)((wave + NW * u) * GEO::B_PIECE_BYTES);
+    }
     const float *acol = g.A + m0, *bcol = g.B + n0;
     auto issue = [&](int stage, int64_t k0) {
         const float *abase = acol + k0 * g.lda;
         const float *bbase = bcol + k0 * g.ldb;
-        dma_16B(offa0, abase, pa0 + stage * STAGE * 4);
-        dma_16B(offb0, bbase, pb0 + stage * STAGE * 4);
-        dma_16B(offa1, abase, pa1 + stage * STAGE * 4);
-        dma_16B(offb1, bbase, pb1 + stage * STAGE * 4);
+#pragma unroll
+        for (int u = 0; u < (APW > BPW ? APW : BPW); u++) {
+            if (u < APW) dma_16B(offa[u < APW ? u : 0], abase, pa[u < APW ? u : 0] + stage * GEO::AT_STAGE_BYTES);
+            if (u < BPW) dma_16B(offb[u < BPW ? u : 0], bbase, pb[u < BPW ? u : 0] + stage * GEO::B_STAGE_BYTES);
+        }
     };
-    const uint32_t ak = lds0 + (uint32_t)(q * BROW * 4 + (wm * 64 + r16) * 4);
-    const uint32_t bk = lds0 + 2 * STAGE * 4 + (uint32_t)(q * BROW * 4 + (wn * 64 + r16) * 4);
+    const uint32_t ak = lds0 + (uint32_t)(q * GEO::AROW * 4 + (wm * 64 + r16) * 4);
+    const uint32_t bk = lds0 + B0 + (uint32_t)(q * GEO::BROW * 4 + (wn * 64 + r16) * 4);
     gemm_f32x4acc acc[4][4];
     float a[2][4], b[2][4];
 #pragma unroll
@@ -951,64 +1005,84 @@ __global__ __launch_bounds__(1024) void gemm_dma_tn_kernel(GemmArgs g)
         for (int j = 0; j < 4; j++) *reinterpret_cast<gemm_f32x4acc *>(out + (int64_t)(16 * i) * g.N + 16 * j) = acc[i][j];
 }
 
-// *rows_done = number of leading rows of C written by the LDS-DMA kernel (0: shape not eligible).  B must be k-major ([K][N]).
 bool dma_shape_ok(int64_t M, int64_t N, int64_t K)
 {
-    return K % 64 == 0 && N % 256 == 0 && M >= 8 * 256;
+    return K % 64 == 0 && N % 128 == 0 && M >= 8 * 256;
 }
 
-int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse = nullptr, int64_t *partial_rows = nullptr)
+// dynamic-LDS opt-in of a kernel: once per kernel AND device (bit d of the caller's mask; thread-safe)
+template <class K>
+int lds_opt_in(K kernel, size_t lds, std::atomic<uint64_t> &done)
 {
-    *rows_done = 0;
-    constexpr int BM = 256, BN = 256, BK = 32;
-    if (!dma_shape_ok(g.M, g.N, g.K)) return GNNX_OK;
-    if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return GNNX_OK;
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    return GNNX_OK;
+}
+
+template <int WM, int WN>
+int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse, int64_t *partial_rows)
+{
+    using GEO = DmaGeo<WM, WN>;
+    constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK;
     if ((int64_t)BM * g.lda >= (1ll << 28) || (int64_t)BK * g.ldb >= (1ll << 28) || (int64_t)BM * g.ldc >= (1ll << 28))
         return GNNX_OK;  // per-lane BYTE offsets are 32-bit
     const int64_t m_tiles = g.M / BM, cols = g.N / BN;
     int64_t gy = ceil_div((int64_t)kNumCU, cols);
     if (gy > m_tiles) gy = m_tiles;
-    constexpr size_t lds = sizeof(float) * (2 * BM * BK + 2 * BK * 272);  // 2 stages x (A 32 KB + B 34 KB) = 132 KB
-    int dev = 0;
-    GNNX_HIP_CHECK(hipGetDevice(&dev));
-    static std::atomic<uint64_t> attr_done{0};  // bit d: the dynamic-LDS opt-in has been set on device d
-    if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_dma_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_dma_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
-    }
+    constexpr size_t lds = GEO::LDS_BYTES;   // 4 x 4: 2 x (32 KB + 34 KB) = 132 KB; 4 x 2: 2 x (32 KB + 16 KB) = 96 KB
+    static std::atomic<uint64_t> done_plain{0}, done_fuse{0};
     static const int ablate = [] { const char *e = experiment_env("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
     if (fuse) {
         if (fuse->ldy % 4 || !aligned16(fuse->ymask) || (int64_t)BM * fuse->ldy >= (1ll << 28)) return GNNX_OK;
-        hipLaunchKernelGGL(gemm_dma_kernel<true>, grid, dim3(1024), lds, st, g, m_tiles, ablate, *fuse);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, true>, lds, done_fuse);
+        if (rc) return rc;
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, true>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else {
-        hipLaunchKernelGGL(gemm_dma_kernel<false>, grid, dim3(1024), lds, st, g, m_tiles, ablate, GemmFuse{});
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, false>, lds, done_plain);
+        if (rc) return rc;
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, false>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
     }
     GNNX_LAUNCH_CHECK();
     *rows_done = m_tiles * BM;
     return GNNX_OK;
 }
 
-bool dma_tn_shape_ok(int64_t M, int64_t N, int64_t K) { return M % 256 == 0 && N % 256 == 0 && K % 64 == 0 && K >= 64 * 1024; }
+// *rows_done = number of leading rows of C written by the LDS-DMA kernel (0: shape not eligible).  B must be k-major ([K][N]).
+int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse = nullptr, int64_t *partial_rows = nullptr)
+{
+    *rows_done = 0;
+    if (!dma_shape_ok(g.M, g.N, g.K)) return GNNX_OK;
+    if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return GNNX_OK;
+    if (g.N % 256 == 0) return launch_dma_geo<4, 4>(g, st, rows_done, fuse, partial_rows);
+    return launch_dma_geo<4, 2>(g, st, rows_done, fuse, partial_rows);
+}
+
+bool dma_tn_shape_ok(int64_t M, int64_t N, int64_t K) { return M % 128 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 64 * 1024; }
+
+template <int WM, int WN>
+int launch_dma_tn_geo(const GemmArgs &g, int splits, hipStream_t st)
+{
+    using GEO = DmaGeoTN<WM, WN>;
+    constexpr size_t lds = GEO::LDS_BYTES_TN;   // 4 x 4: 136 KB; 2 x 2: 64 KB (two workgroups per CU)
+    static std::atomic<uint64_t> done{0};
+    int rc = lds_opt_in(&gemm_dma_tn_kernel<WM, WN>, lds, done);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gemm_dma_tn_kernel<WM, WN>), dim3((uint32_t)(g.N / GEO::BN), (uint32_t)(g.M / GEO::BM), (uint32_t)splits),
+                       dim3(GEO::NT), lds, st, g);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
 
 int launch_dma_tn(const GemmArgs &g, int splits, hipStream_t st)
 {
-    constexpr size_t lds = sizeof(float) * 4 * 32 * 272;  // 2 stages x 2 operands x 34 KB = 136 KB
-    int dev = 0;
-    GNNX_HIP_CHECK(hipGetDevice(&dev));
-    static std::atomic<uint64_t> attr_done{0};
-    if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_dma_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds));
-        if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
-    }
-    hipLaunchKernelGGL(gemm_dma_tn_kernel, dim3((uint32_t)(g.N / 256), (uint32_t)(g.M / 256), (uint32_t)splits), dim3(1024), lds, st, g);
-    GNNX_LAUNCH_CHECK();
-    return GNNX_OK;
+    if (g.M % 256 == 0 && g.N % 256 == 0) return launch_dma_tn_geo<4, 4>(g, splits, st);
+    return launch_dma_tn_geo<2, 2>(g, splits, st);
 }
 
 // Y[c][r] = X[r][c] for the small weight matrix (tile through LDS; the general entry point is gnnx_transpose_f32)

@@ -293,9 +293,9 @@ def test_gemm_splitk_long_reduction(env):
     assert np.abs(a - ref).max() <= 1e-5 * np.abs(dH).astype(np.float64).T.dot(np.abs(X).astype(np.float64)).max()
 
 
-@pytest.mark.parametrize("n,fo,fi", [(1_000_000, 256, 256), (262_144, 512, 256), (200_064, 256, 256)])
+@pytest.mark.parametrize("n,fo,fi", [(1_000_000, 256, 256), (262_144, 512, 256), (200_064, 256, 256), (500_032, 128, 128), (131_072, 128, 384)])
 def test_gemm_splitk_lds_dma_kernel(env, n, fo, fi):
-    """dW = dH^T . X with 256-multiple widths and K % 64 == 0 takes gemm_dma_tn_kernel (LDS-DMA, split-K slabs, in-order slab
+    """dW = dH^T . X with widths that are multiples of 128 (256 x 256 tiles where both are multiples of 256) and K % 64 == 0 takes gemm_dma_tn_kernel (LDS-DMA, split-K slabs, in-order slab
     reduction): float64 check with the condition-aware bound, run-to-run identical, and the same bits with beta = 1 as adding
     to the previous result by hand."""
     ops, torch = env["ops"], env["torch"]
@@ -304,7 +304,7 @@ def test_gemm_splitk_lds_dma_kernel(env, n, fo, fi):
     a = ops.gemm(dH, X, transA=True)
     b = ops.gemm(dH, X, transA=True)
     assert torch.equal(a, b)
-    ref = dH[:, :64].double().t() @ X.double()                     # 64 output rows in float64
+    ref = dH[:, :64].double().t() @ X.double()                     # 64 output rows in float64 (covers the first wavefront row)
     bound = 1e-5 * float((dH[:, :64].abs().double().t() @ X.abs().double()).max())
     assert float((a[:64].double() - ref).abs().max()) <= bound
     c = a.clone()
