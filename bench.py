@@ -12,7 +12,9 @@ what the reference semantics sum over) / time per step, whole job.
 
 Workload at N = 1: BASELINE configs[3], the one the metric's target is quoted on (RMAT 10M nodes / 100M
 edges, 256 features); it fits one GPU (~60 GB).  At N > 1 the same graph is sharded by 1-D vertex partition
-with a halo exchange per aggregation (RCCL all-to-all-v) => "scaling": "strong".
+(degree-sorted snake deal: equal rows, non-zeros and per-link halo volume) with a halo exchange per aggregation
+(RCCL all-to-all-v), both exchanges asynchronous and each chain's compute under the other chain's exchange
+=> "scaling": "strong".  Started as plain `python bench.py --gpus N` it spawns torch.distributed.run itself.
 
 Besides the contract fields the JSON line carries
   roofline     for the dominant kernel (forward SpMM): algorithmic bytes B_gather / HIP-event time
@@ -97,7 +99,9 @@ def main():
                     help="N=1: capture one step (6 kernel launches + their small helpers) into a hipGraph and replay it in the "
                          "timed loop -- for launch-bound sizes such as the Cora-sized config")
     ap.add_argument("--native-comm", action="store_true",
-                    help="N>1: halo all-to-all-v and all-reduce through the C-ABI (gnnx_halo_exchange_f32) instead of torch.distributed")
+                    help="N>1: halo all-to-all-v and all-reduce through the C-ABI (gnnx_halo_exchange_f32, RCCL send/recv group on a "
+                         "communication stream of its own) instead of torch.distributed.  UNVERIFIED for more than one rank: no "
+                         "multi-GPU node was available to the builder (one-rank communicator and the in-process transport are tested)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank (rehearsal)")
     ap.add_argument("--schedule", default="overlap", choices=["overlap", "sequential"],
                     help="N>1: overlap = both halo exchanges asynchronous, each chain's compute under the other's exchange (same "
