@@ -208,10 +208,14 @@ int gnnx_spmm_csr_bf16_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const
  *   backward  dX = dH . W       (operation.h:516-523)   transA=0 transB=0  A=dH[N,Fout] B=W[Fout,Fin]
  *             dW = dH^T . X     (operation.h:524-531 + Transpose::_backward :416-433)
  *                                                       transA=1 transB=0  A=dH[N,Fout] B=X[N,Fin]
- * No operand is ever transposed in memory (the reference materialises W^T, nn.cpp:207, and a clone of
- * each operand's transpose in backward).  transA=1 (reduction over the node dimension) runs split-K over
- * workgroups into the caller's workspace and reduces slabs in a fixed order (deterministic).
- * Workspace: gnnx_gemm_workspace() bytes (0 for transA=0).
+ * The big operands (X, dH, the outputs) are never transposed in memory (the reference materialises W^T, nn.cpp:207, and a
+ * clone of each operand's transpose in backward).  transA=1 (reduction over the node dimension) runs split-K over workgroups
+ * into the caller's workspace and reduces slabs in a fixed order (deterministic).  Tall products with whole 256-row tiles,
+ * N % 128 == 0 and K % 64 == 0 take the LDS-DMA kernels; for X . W^T those want the small W k-major, so
+ * gnnx_gemm_workspace() asks for K * N floats and the call transposes W into them first (same products, same order).  Every
+ * kernel computes an output element as the same k-ascending fmaf chain: which kernel ran never changes a bit.
+ * Workspace: gnnx_gemm_workspace() bytes (split-K slabs for transA=1; W^T for the tall transB=1 case; else 0).  A call with
+ * less workspace than that still works, on the generic kernels.
  */
 int gnnx_gemm_workspace(int transA, int transB, int64_t M, int64_t N, int64_t K, size_t *bytes);
 int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t K, float alpha, const float *d_A,

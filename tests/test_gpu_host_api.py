@@ -162,3 +162,34 @@ def test_through_layer_gradients_match_the_reference_in_quirk_mode(name):
         bad = np.abs(got["full_dX"] - ref) > 1e-4 * np.maximum(1.0, np.abs(ref))
         assert bad.mean() <= 1e-3, f"{bad.sum()} of {bad.size} elements of dX differ"
         assert np.abs(plain["full_dX"] - ref).max() > 1e-2, "without the switch the gradient is the mathematical one"
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "bench.py must print exactly ONE JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_gpu_and_sharded_rehearsal():
+    """bench.py's JSON line (the driver's contract): metric / value / unit / n_gpus / steps / warmup / ms_per_step / scaling /
+    dtype / data / config.workload, a roofline object for the dominant kernel and the cpu_baseline object at N = 1; and the
+    N > 1 code path (partition, halo plan, overlap schedule, all-reduce) rehearsed on one rank."""
+    d = _run_bench(["--workload", "tiny", "--steps", "3", "--warmup", "1", "--cpu-sample-nodes", "20000"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "edges/s" and d["dtype"] == "f32"
+    assert d["config"]["workload"] == "tiny" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    ro = d["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+    assert abs(d["value"] - d["config"]["nnz"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    for sched in ("overlap", "sequential"):
+        s = _run_bench(["--workload", "tiny", "--steps", "2", "--warmup", "1", "--force-sharded", "--no-cpu-baseline", "--schedule", sched])
+        assert s["n_gpus"] == 1 and "halo all-to-all-v" in s["config"]["parallelism"] and s["roofline"]["schedule"] == sched
+        assert s["config"]["nnz"] == d["config"]["nnz"], "the sharded path must see the same graph"
