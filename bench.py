@@ -109,6 +109,11 @@ def main():
     ap.add_argument("--partition", default="deal", choices=["deal", "contiguous"],
                     help="N>1: deal = degree-sorted snake deal (equal rows / non-zeros / per-link volume); contiguous = ranges of "
                          "original ids balanced on degree (round 1)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N>1: nccl (= RCCL over xGMI, the measured path) or gloo = REHEARSAL: device tensors staged through host "
+                         "memory over a CPU process group, so that the whole multi-process job can run on a box with one GPU")
+    ap.add_argument("--all-ranks-on-device0", action="store_true",
+                    help="rehearsal: every rank uses GPU 0 (needs --dist-backend gloo; RCCL refuses two ranks on one device)")
     ap.add_argument("--cpu-sample-nodes", type=int, default=2_500_000,
                     help="nodes of the bounded CPU-baseline sample (same generator and average degree): about 12 s on all host "
                          "threads + about 10 s for the single-thread leg on a tenth of it")
@@ -132,6 +137,10 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the product path has no CPU fallback")
+    if args.all_ranks_on_device0:
+        if args.dist_backend != "gloo":
+            sys.exit("--all-ranks-on-device0 is a rehearsal mode and needs --dist-backend gloo")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -141,9 +150,14 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     pkg = load_package()
+    if dist is not None and args.dist_backend == "gloo":   # rehearsal transport (shard.HostStagedDist): never the measured path
+        dist = importlib.import_module("gnncpp_amd.shard").HostStagedDist(dist)
     ops = importlib.import_module("gnncpp_amd.ops")
     capi = importlib.import_module("gnncpp_amd.capi")
 
@@ -236,7 +250,8 @@ def main():
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 and not args.force_sharded else
-                       f"1-D vertex shard x{world} ({args.partition}), halo all-to-all-v, schedule {args.schedule}",
+                       f"1-D vertex shard x{world} ({args.partition}), halo all-to-all-v, schedule {args.schedule}" +
+                       (" -- REHEARSAL: gloo through host memory, all ranks on GPU 0: not a measurement" if args.dist_backend == "gloo" else ""),
                        "plan_chunk": args.chunk, "hip_graph": graph is not None, "mode": "SYM" if args.sym else "REF",
                        "feature_storage": "bf16 for the aggregations (opt-in, NOT the parity path)" if args.bf16_features else "f32",
                        "gemm": "split-bf16 x6 for X.W^T and dH.W (opt-in, NOT the parity path)" if args.split_gemm else "f32 MFMA"},

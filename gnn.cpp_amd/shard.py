@@ -128,6 +128,53 @@ class HaloSide:
         assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
 
 
+class HostStagedDist:
+    """torch.distributed look-alike that moves device tensors through host memory over a CPU process group (gloo).
+
+    REHEARSAL transport, never the measured one: it lets the whole multi-process job -- torch.distributed.run, one process per
+    rank, rendezvous, partition, halo plan, both schedules, parameter all-reduce, the JSON line -- run on a box with ONE GPU
+    (every rank on device 0), which is all the builder had; on a multi-GPU node the backend is nccl (= RCCL) and this class is
+    not used.  Collectives are synchronous (the device stream is drained first); async_op returns a completed handle."""
+
+    class ReduceOp:
+        pass
+
+    def __init__(self, dist):
+        self._d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    class _Work:
+        def wait(self):
+            return True
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, async_op=False):
+        torch.cuda.synchronize()
+        o = torch.empty(out.shape, dtype=out.dtype)
+        self._d.all_to_all_single(o, inp.detach().cpu().contiguous(), output_split_sizes, input_split_sizes)
+        out.copy_(o)
+        torch.cuda.synchronize()
+        return self._Work() if async_op else None
+
+    def all_reduce(self, t, op=None):
+        torch.cuda.synchronize()
+        h = t.detach().cpu()
+        self._d.all_reduce(h) if op is None else self._d.all_reduce(h, op=op)
+        t.copy_(h)
+        torch.cuda.synchronize()
+
+    def broadcast(self, t, src):
+        h = t.detach().cpu()
+        self._d.broadcast(h, src)
+        t.copy_(h)
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        self._d.barrier()
+
+    def destroy_process_group(self):
+        self._d.destroy_process_group()
+
+
 class _Done:
     """Handle of an exchange that has already completed on the caller's stream."""
 

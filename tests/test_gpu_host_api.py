@@ -193,3 +193,25 @@ def test_bench_contract_single_gpu_and_sharded_rehearsal():
         s = _run_bench(["--workload", "tiny", "--steps", "2", "--warmup", "1", "--force-sharded", "--no-cpu-baseline", "--schedule", sched])
         assert s["n_gpus"] == 1 and "halo all-to-all-v" in s["config"]["parallelism"] and s["roofline"]["schedule"] == sched
         assert s["config"]["nnz"] == d["config"]["nnz"], "the sharded path must see the same graph"
+
+
+def test_multi_process_job_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` exactly as the driver starts it for N > 1 -- plain python, which spawns torch.distributed.run,
+    one PROCESS per rank, rendezvous on 127.0.0.1, partition + halo plan + overlap schedule + parameter all-reduce, max-over-ranks
+    timing, ONE JSON line from rank 0 -- with the one thing a one-GPU box cannot provide swapped out: the ranks share GPU 0 and
+    the collectives are staged through host memory over gloo (--dist-backend gloo --all-ranks-on-device0).  Checks the line
+    and that the sharded job saw the same graph as the single-GPU one; 3 ranks too (odd world, uneven n/P)."""
+    single = _run_bench(["--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    for world, port in ((2, "29651"), (3, "29652")):
+        env_port = dict(os.environ, MASTER_PORT=port)
+        import json
+        import sys
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--workload", "tiny", "--steps", "2",
+                            "--warmup", "1", "--dist-backend", "gloo", "--all-ranks-on-device0"], capture_output=True, text=True,
+                           timeout=600, cwd=ROOT, env=env_port)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["nnz"] == single["config"]["nnz"]
+        assert "REHEARSAL" in d["config"]["parallelism"] and d["value"] > 0 and d["roofline"]["frac"] > 0
