@@ -89,6 +89,8 @@ _SIGS = {
     "gnnx_gemm_f32": [C.c_int, C.c_int, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _f32, _vp, _i64, _vp, _sz, _vp],
     "gnnx_gemm_relu_colsum_workspace": [_i64, _i64, _i64, C.POINTER(_sz)],
     "gnnx_gemm_relu_colsum_f32": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _sz, _vp],
+    "gnnx_gemm_bn_stats_workspace": [_i64, _i64, _i64, C.POINTER(_sz)],
+    "gnnx_gemm_bn_stats_f32": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp],
     "gnnx_gemm_split_workspace": [_i64, _i64, _i64, C.POINTER(_sz)],
     "gnnx_gemm_split_bf16_f32": [C.c_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _sz, _vp],
     "gnnx_mfma_peak_f32": [_i32, _i32, _vp, C.POINTER(_f64), _vp],

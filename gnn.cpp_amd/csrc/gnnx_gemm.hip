@@ -489,13 +489,17 @@ __device__ __forceinline__ void dma_16B(uint32_t voff_bytes, const float *sbase,
 // colsum_partial[blockIdx.y][n] = sum over this workgroup's rows of the masked C -- the bias gradient of the layer below
 // (Add::_backward -> sum_to_size, operation.h:114-128) -- so neither the unmasked gradient nor a separate column-sum pass
 // touches HBM.  The mask values are loaded with the same full-line pattern the stores use, under the LDS round trip.
+// FUSE == 2 (opt-in, gnnx_gemm_bn_stats_f32): the batch statistics of BatchNorm over the columns of C = X . W^T in the same
+// pass -- per-lane sums of d = c - shift[n] and d^2 (shift = row 0 of C: a sample value, so the single-pass variance
+// Q/M - (S/M)^2 cancels mildly), reduced per workgroup into [gridDim.y][2][N] partials and finished in double.  C itself is
+// stored unchanged.  Not the reference's two-pass arithmetic (nn.cpp:303,312): tolerance-level, next to the exact gnnx_bn_stats_f32.
 struct GemmFuse {
-    const float *ymask;      // [M][N] forward output of the layer below (ld ldy); mask = ymask > 0
+    const float *ymask;      // FUSE 1: [M][N] forward output of the layer below (ld ldy), mask = ymask > 0; FUSE 2: shift[N]
     int64_t ldy;
-    float *colsum_partial;   // [gridDim.y][N]
+    float *colsum_partial;   // FUSE 1: [gridDim.y][N]; FUSE 2: [gridDim.y][2][N]
 };
 
-template <int WM_, int WN_, bool FUSE>
+template <int WM_, int WN_, int FUSE>
 __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate, GemmFuse fu)
 {
     (void)ablate;
@@ -569,7 +573,10 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
     gemm_f32x4acc acc[4][4];
     float a[2][4], b[2][4];
     gemm_f32x4acc csum = {0.f, 0.f, 0.f, 0.f};   // FUSE: column sums of this lane's 4 columns over every row it stores
-    const uint32_t offy = FUSE ? (uint32_t)((wm * 64 + (lane >> 4)) * fu.ldy + wn * 64 + 4 * (lane & 15)) * 4u : 0u;
+    gemm_f32x4acc csq = {0.f, 0.f, 0.f, 0.f};    // FUSE 2: sums of squares (of the shifted values)
+    gemm_f32x4acc shift4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (FUSE == 2) shift4 = *reinterpret_cast<const gemm_f32x4acc *>(fu.ymask + n0 + wn * 64 + 4 * (lane & 15));
+    const uint32_t offy = FUSE == 1 ? (uint32_t)((wm * 64 + (lane >> 4)) * fu.ldy + wn * 64 + 4 * (lane & 15)) * 4u : 0u;
     int64_t mt = blockIdx.y;
     if (mt < m_tiles) issue(0, mt, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
         }
         const float alpha = g.alpha;
         char *ctile = reinterpret_cast<char *>(g.C + mt * BM * g.ldc + n0);
-        const char *ytile = FUSE ? reinterpret_cast<const char *>(fu.ymask + mt * BM * fu.ldy + n0) : nullptr;
+        const char *ytile = FUSE == 1 ? reinterpret_cast<const char *>(fu.ymask + mt * BM * fu.ldy + n0) : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
                 asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ep_wr), "v"(v), "i"(64 * j) : "memory");
             }
             gemm_f32x4acc ym[4];
-            if constexpr (FUSE) {   // issued behind the LDS writes (block row i's accumulators are dead by now: their registers
+            if constexpr (FUSE == 1) {   // issued behind the LDS writes (block row i's accumulators are dead by now: their registers
                                     // take the mask values) and in flight during the LDS round trip below
                 const char *yrow = ytile + (int64_t)(16 * i) * fu.ldy * 4;
 #pragma unroll
@@ -630,16 +637,21 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
             char *crow = ctile + (int64_t)(16 * i) * g.ldc * 4;   // wave-uniform
 #pragma unroll
             for (int p = 0; p < 4; p++) {
-                if constexpr (FUSE) {
+                if constexpr (FUSE == 1) {
 #pragma unroll
                     for (int c = 0; c < 4; c++) o[p][c] = ym[p][c] > 0.f ? o[p][c] : 0.f;
                     csum += o[p];
+                }
+                if constexpr (FUSE == 2) {
+                    const gemm_f32x4acc d = o[p] - shift4;
+                    csum += d;
+                    csq += d * d;
                 }
                 *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * 4 + offc) = o[p];
             }
         }
     }
-    if constexpr (FUSE) {
+    if constexpr (FUSE != 0) {
         // column sums of the workgroup: lanes with equal (lane & 15) in the WM wavefronts of a column group wn hold the same 4
         // columns.  Everything is parked in LDS (the operand stages are dead: every DMA was waited for, the last K-tile
         // ended with a barrier) and added in a fixed order: wm 0..WM-1, lane group 0..3.
@@ -652,7 +664,20 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
             gemm_f32x4acc sum = {0.f, 0.f, 0.f, 0.f};
             for (int w = 0; w < GEO::WM; w++)
                 for (int lg = 0; lg < 4; lg++) sum += red[(w * GEO::WN + cg) * 64 + lg * 16 + c16];
-            *reinterpret_cast<gemm_f32x4acc *>(fu.colsum_partial + (int64_t)blockIdx.y * g.N + n0 + 4 * tid) = sum;
+            float *prow = fu.colsum_partial + (int64_t)blockIdx.y * (FUSE == 2 ? 2 : 1) * g.N;
+            *reinterpret_cast<gemm_f32x4acc *>(prow + n0 + 4 * tid) = sum;
+        }
+        if constexpr (FUSE == 2) {   // the same for the squares
+            __syncthreads();
+            red[wave * 64 + lane] = csq;
+            __syncthreads();
+            if (tid < BN / 4) {
+                const int cg = tid >> 4, c16 = tid & 15;
+                gemm_f32x4acc sum = {0.f, 0.f, 0.f, 0.f};
+                for (int w = 0; w < GEO::WM; w++)
+                    for (int lg = 0; lg < 4; lg++) sum += red[(w * GEO::WN + cg) * 64 + lg * 16 + c16];
+                *reinterpret_cast<gemm_f32x4acc *>(fu.colsum_partial + ((int64_t)blockIdx.y * 2 + 1) * g.N + n0 + 4 * tid) = sum;
+            }
         }
     }
 }
@@ -1024,7 +1049,7 @@ int lds_opt_in(K kernel, size_t lds, std::atomic<uint64_t> &done)
 }
 
 template <int WM, int WN>
-int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse, int64_t *partial_rows)
+int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse, int64_t *partial_rows, int fuse_mode)
 {
     using GEO = DmaGeo<WM, WN>;
     constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK;
@@ -1034,19 +1059,25 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
     int64_t gy = ceil_div((int64_t)kNumCU, cols);
     if (gy > m_tiles) gy = m_tiles;
     constexpr size_t lds = GEO::LDS_BYTES;   // 4 x 4: 2 x (32 KB + 34 KB) = 132 KB; 4 x 2: 2 x (32 KB + 16 KB) = 96 KB
-    static std::atomic<uint64_t> done_plain{0}, done_fuse{0};
+    static std::atomic<uint64_t> done_plain{0}, done_fuse{0}, done_stats{0};
     static const int ablate = [] { const char *e = experiment_env("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
-    if (fuse) {
-        if (fuse->ldy % 4 || !aligned16(fuse->ymask) || (int64_t)BM * fuse->ldy >= (1ll << 28)) return GNNX_OK;
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, true>, lds, done_fuse);
+    if (fuse && fuse_mode == 2) {
+        if (!aligned16(fuse->ymask)) return GNNX_OK;
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 2>, lds, done_stats);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, true>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 2>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
+        if (partial_rows) *partial_rows = gy;
+    } else if (fuse) {
+        if (fuse->ldy % 4 || !aligned16(fuse->ymask) || (int64_t)BM * fuse->ldy >= (1ll << 28)) return GNNX_OK;
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 1>, lds, done_fuse);
+        if (rc) return rc;
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 1>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else {
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, false>, lds, done_plain);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0>, lds, done_plain);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, false>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
     }
     GNNX_LAUNCH_CHECK();
     *rows_done = m_tiles * BM;
@@ -1054,13 +1085,14 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
 }
 
 // *rows_done = number of leading rows of C written by the LDS-DMA kernel (0: shape not eligible).  B must be k-major ([K][N]).
-int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse = nullptr, int64_t *partial_rows = nullptr)
+int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse = nullptr, int64_t *partial_rows = nullptr,
+               int fuse_mode = 1)
 {
     *rows_done = 0;
     if (!dma_shape_ok(g.M, g.N, g.K)) return GNNX_OK;
     if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return GNNX_OK;
-    if (g.N % 256 == 0) return launch_dma_geo<4, 4>(g, st, rows_done, fuse, partial_rows);
-    return launch_dma_geo<4, 2>(g, st, rows_done, fuse, partial_rows);
+    if (g.N % 256 == 0) return launch_dma_geo<4, 4>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    return launch_dma_geo<4, 2>(g, st, rows_done, fuse, partial_rows, fuse_mode);
 }
 
 bool dma_tn_shape_ok(int64_t M, int64_t N, int64_t K) { return M % 128 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 64 * 1024; }
@@ -1196,6 +1228,109 @@ GNNX_API int gnnx_gemm_relu_colsum_f32(int64_t M, int64_t N, int64_t K, const fl
         rc = gnnx_colsum_f32(cr, ldc, mr, (int32_t)N, beta, d_colsum, cs_ws, cs_bytes, stream);
         if (rc) return rc;
     }
+    return GNNX_OK;
+}
+
+// ---- opt-in: H = X . W^T with the BatchNorm batch statistics of H in the same pass (single-pass shifted variance) --------------
+__global__ void gemm_row0_kernel(const float *A, const float *B, int64_t ldb, int64_t N, int64_t K, int transB, float *shift)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int64_t k = 0; k < K; k++) acc = fmaf(A[k], transB ? B[n * ldb + k] : B[k * ldb + n], acc);
+    shift[n] = acc;   // row 0 of C (any rounding will do: it is only the shift of the one-pass variance)
+}
+
+__global__ void shifted_sums_rows_kernel(const float *C, int64_t ldc, int64_t n_rows, int64_t N, const float *shift, float *sum, float *sq)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f, q = 0.f;
+    const float sh = shift[n];
+    for (int64_t r = 0; r < n_rows; r++) {
+        const float d = C[r * ldc + n] - sh;
+        s += d;
+        q += d * d;
+    }
+    sum[n] = s;
+    sq[n] = q;
+}
+
+__global__ void bn_stats_finalize_kernel(const float *partial, int64_t n_part, int64_t N, int64_t M, const float *shift, float *mean, float *var)
+{
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double S = 0.0, Q = 0.0;
+    for (int64_t p = 0; p < n_part; p++) {   // fixed order
+        S += (double)partial[(2 * p) * N + n];
+        Q += (double)partial[(2 * p + 1) * N + n];
+    }
+    const double m = S / (double)M;
+    mean[n] = (float)((double)shift[n] + m);
+    const double v = Q / (double)M - m * m;
+    var[n] = (float)(v > 0.0 ? v : 0.0);
+}
+
+GNNX_API int gnnx_gemm_bn_stats_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes)
+{
+    GNNX_REQUIRE(bytes && M >= 0 && N >= 0 && K >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    size_t bn = 0;
+    int rc = gnnx_bn_workspace(M, (int32_t)N, &bn);
+    if (rc) return rc;
+    // [257][2][N] partial sums + shift[N] + W^T [K][N] + the exact path's scratch (fallback)
+    *bytes = sizeof(float) * ((size_t)257 * 2 * N + (size_t)N + (size_t)K * N) + bn + 64;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_gemm_bn_stats_f32(int64_t M, int64_t N, int64_t K, const float *d_X, int64_t ldx, const float *d_W, int64_t ldw,
+                                    float *d_H, int64_t ldh, float *d_mean, float *d_var, void *d_workspace, size_t workspace_bytes,
+                                    void *stream)
+{
+    GNNX_REQUIRE(M > 0 && N > 0 && K > 0 && N < (1ll << 31), GNNX_ERR_INVALID_ARG, "bad sizes");
+    GNNX_REQUIRE(d_X && d_W && d_H && d_mean && d_var && ldx >= K && ldw >= K && ldh >= N, GNNX_ERR_INVALID_ARG, "null pointer or ld");
+    size_t need = 0;
+    gnnx_gemm_bn_stats_workspace(M, N, K, &need);
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    float *partial = static_cast<float *>(d_workspace);
+    float *shift = partial + (size_t)257 * 2 * N;
+    float *wt = shift + (((size_t)N + 3) & ~(size_t)3);
+    char *bn_ws = reinterpret_cast<char *>(wt + (size_t)K * N);
+    bn_ws += (16 - (reinterpret_cast<uintptr_t>(bn_ws) & 15)) & 15;
+    const size_t bn_bytes = workspace_bytes - (size_t)(bn_ws - static_cast<char *>(d_workspace));
+    const bool eligible = dma_shape_ok(M, N, K) && ldx % 4 == 0 && ldh % 4 == 0 && aligned16(d_X) && aligned16(d_H) && aligned16(d_workspace);
+    if (!eligible) {   // exact two-pass statistics on the plain product
+        int rc = gnnx_gemm_f32(0, 1, M, N, K, 1.f, d_X, ldx, d_W, ldw, 0.f, d_H, ldh, wt, sizeof(float) * (size_t)K * N, stream);
+        if (rc) return rc;
+        return gnnx_bn_stats_f32(d_H, ldh, M, (int32_t)N, d_mean, d_var, bn_ws, bn_bytes, stream);
+    }
+    hipLaunchKernelGGL(gemm_row0_kernel, dim3((uint32_t)ceil_div(N, 256)), dim3(256), 0, st, d_X, d_W, ldw, N, K, 1, shift);
+    GNNX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_transpose_w_kernel, dim3((uint32_t)ceil_div(K, 32), (uint32_t)ceil_div(N, 32)), dim3(256), 0, st, d_W, ldw, N, K, wt, N);
+    GNNX_LAUNCH_CHECK();
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.A = d_X; g.lda = ldx; g.B = wt; g.ldb = N; g.C = d_H; g.ldc = ldh; g.alpha = 1.f; g.beta = 0.f;
+    g.k_per_split = K;
+    GemmFuse fu{shift, 0, partial};
+    int64_t rows = 0, prow = 0;
+    int rc = launch_dma(g, st, &rows, &fu, &prow, 2);
+    if (rc) return rc;
+    if (rows == 0) {   // the kernel declined (alignment of a sub-buffer): exact path
+        rc = gnnx_gemm_f32(0, 1, M, N, K, 1.f, d_X, ldx, d_W, ldw, 0.f, d_H, ldh, wt, sizeof(float) * (size_t)K * N, stream);
+        if (rc) return rc;
+        return gnnx_bn_stats_f32(d_H, ldh, M, (int32_t)N, d_mean, d_var, bn_ws, bn_bytes, stream);
+    }
+    if (rows < M) {    // ragged tail: plain product, then its shifted sums as one more partial row
+        const int64_t mr = M - rows;
+        rc = gnnx_gemm_f32(0, 0, mr, N, K, 1.f, d_X + rows * ldx, ldx, wt, N, 0.f, d_H + rows * ldh, ldh, nullptr, 0, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(shifted_sums_rows_kernel, dim3((uint32_t)ceil_div(N, 256)), dim3(256), 0, st, d_H + rows * ldh, ldh, mr, N, shift,
+                           partial + (size_t)(2 * prow) * N, partial + (size_t)(2 * prow + 1) * N);
+        GNNX_LAUNCH_CHECK();
+        prow++;
+    }
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((uint32_t)ceil_div(N, 256)), dim3(256), 0, st, partial, prow, N, M, shift, d_mean, d_var);
+    GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }
 

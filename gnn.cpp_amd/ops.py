@@ -214,6 +214,22 @@ def gemm_relu_colsum(A, B, Ymask, out=None, colsum_out=None):
     return out, colsum_out
 
 
+def linear_fwd_bn_stats(X, W, out=None):
+    """OPT-IN gnnx_gemm_bn_stats_f32: H = X . W^T and the BatchNorm batch statistics of H in one pass (single-pass shifted
+    variance: within rounding of bn_stats(H), not bit-equal).  Returns (H, mean, var)."""
+    M, K = X.shape
+    N = W.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=X.device) if out is None else out
+    mean = torch.empty(N, dtype=torch.float32, device=X.device)
+    var = torch.empty(N, dtype=torch.float32, device=X.device)
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_gemm_bn_stats_workspace", M, N, K, C.byref(wsb))
+    ws = _workspace(wsb.value, X.device, "gemm_bn")
+    capi.call("gnnx_gemm_bn_stats_f32", M, N, K, _ptr(X), _ld(X), _ptr(W), _ld(W), _ptr(out), _ld(out), _ptr(mean), _ptr(var), _ptr(ws),
+              wsb.value, _stream())
+    return out, mean, var
+
+
 def gemm_split(A, B, transB=False, out=None):
     """OPT-IN split-precision GEMM (gnnx_gemm_split_bf16_f32): A[M,K] . op(B) on the bf16 matrix cores from exact 3-way bf16
     splits of the f32 operands, f32 accumulation; f32-level accuracy, not the reference's arithmetic."""

@@ -236,6 +236,16 @@ int gnnx_gemm_relu_colsum_f32(int64_t M, int64_t N, int64_t K, const float *d_A,
                               const float *d_Ymask, int64_t ldy, float *d_C, int64_t ldc, float *d_colsum, void *d_workspace,
                               size_t workspace_bytes, void *stream);
 
+/* OPT-IN (never the default; the parity path uses gnnx_gemm_f32 + gnnx_bn_stats_f32): H = X[M,K] . W[N,K]^T together with the
+ * BatchNorm batch statistics of H's columns in ONE pass over H -- SURVEY.md 2b "BN statistics as the GEMM epilogue".  H holds the
+ * same bits as gnnx_gemm_f32.  mean / var (biased) come from per-lane sums of d = h - shift[n] and d^2, shift = row 0 of H (a
+ * sample value, so Q/M - (S/M)^2 cancels mildly), finished in double: a single-pass variance, within rounding of -- not bit-equal
+ * to -- the exact two-pass statistics (x->mean(-2), x->var(-2, 0); reference nn.cpp:303,312).  Saves the two reads of H that
+ * gnnx_bn_stats_f32 makes.  Shapes the fused kernel does not cover fall back to the exact pair of calls. */
+int gnnx_gemm_bn_stats_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes);
+int gnnx_gemm_bn_stats_f32(int64_t M, int64_t N, int64_t K, const float *d_X, int64_t ldx, const float *d_W, int64_t ldw, float *d_H,
+                           int64_t ldh, float *d_mean, float *d_var, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* OPT-IN split-precision GEMM -- never the default, not used by any parity-graded call.  C[M,N] = A[M,K] . op(B)
  * (transB: B is [N,K], else [K,N]) on the bf16 matrix cores: every f32 operand is split exactly into three bf16 pieces
  * (8 + 8 + 8 significand bits) and the six piece products with i + j <= 2 are accumulated in f32, smallest first -- f32-level

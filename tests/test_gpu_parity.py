@@ -333,6 +333,25 @@ def test_gemm_with_fused_relu_mask_and_colsum_epilogue(env, M, N, K):
     assert float((db.double() - exact).abs().max()) <= bound
 
 
+@pytest.mark.parametrize("M,N,K,offset", [(300_077, 256, 256, 0.0), (100_000, 128, 128, 3.0), (50_000, 256, 64, -20.0), (4_000, 100, 100, 0.5)])
+def test_gemm_with_fused_batchnorm_statistics_opt_in(env, M, N, K, offset):
+    """gnnx_gemm_bn_stats_f32 (opt-in): H = X . W^T with the batch mean / biased variance of H's columns from the GEMM epilogue
+    (single-pass, shifted by row 0 of H).  H must be the bits of the plain product; the statistics are checked against float64
+    -- also with a large common offset in the data (mean^2 >> var), where an unshifted E[x^2] - E[x]^2 in float would lose
+    everything -- and against the exact two-pass kernel; a shape the fused kernel does not take falls back to the exact pair."""
+    ops, torch = env["ops"], env["torch"]
+    X = ops.uniform_pm1(85, (M, K), device=env["dev"]) + offset
+    W = ops.uniform_pm1(86, (N, K), scale=K ** -0.5, device=env["dev"])
+    H, mean, var = ops.linear_fwd_bn_stats(X, W)
+    H0 = ops.linear_fwd(X, W)
+    assert torch.equal(H, H0)
+    m64, v64 = H0.double().mean(0), H0.double().var(0, unbiased=False)
+    assert float((mean.double() - m64).abs().max()) <= 1e-5 * max(1.0, float(m64.abs().max()))
+    assert float(((var.double() - v64).abs() / v64.clamp_min(1e-30)).max()) <= 1e-4
+    m2, v2 = ops.bn_stats(H0)
+    assert float(((var - v2).abs() / v2.clamp_min(1e-30)).max()) <= 1e-4
+
+
 def test_gcn_stack_backward_fused_equals_unfused(env):
     ops, torch = env["ops"], env["torch"]
     n, e, F = 30_000, 300_000, 256
