@@ -256,6 +256,7 @@ def main():
                        "feature_storage": "bf16 for the aggregations (opt-in, NOT the parity path)" if args.bf16_features else "f32",
                        "gemm": "split-bf16 x6 for X.W^T and dH.W (opt-in, NOT the parity path)" if args.split_gemm else "f32 MFMA"},
             "roofline": roof,
+            "roofline_mfma": runner.mfma_roofline() if hasattr(runner, "mfma_roofline") else None,
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,
             "kernels_ms": runner.kernel_times(),
@@ -361,6 +362,20 @@ class SingleGpu:
                 # the cache-perfect lower bound (every feature row read once) beside the gather figure
                 "cache_perfect_bytes": 4 * (self.n + 1) + 4 * self.g.nnz + 4 * self.n + 8 * self.F * self.n,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0}
+
+
+    def mfma_roofline(self):
+        """The second bound of the step: the three dense products against the fp32 matrix peak (MI355X_MICROARCH.md: 157.3 TFLOP/s,
+        exact-f32 MFMA).  Informational; the contract's `roofline` object is the dominant kernel, the forward SpMM."""
+        kt = self.kernel_times()
+        if not all(kt.get(k) for k in ("gemm_xwT", "gemm_dX", "gemm_dW")):
+            return None
+        fl = 2.0 * self.n * self.F * self.F
+        out = {"bound": "mfma", "peak": 157.3, "unit": "TFLOP/s", "flops_per_launch": fl}
+        for k in ("gemm_xwT", "gemm_dX", "gemm_dW"):
+            tf = fl / (kt[k] * 1e-3) / 1e12
+            out[k] = {"achieved": tf, "frac": tf / 157.3, "avg_launch_ms": kt[k]}
+        return out
 
 
 class TrainStep(SingleGpu):

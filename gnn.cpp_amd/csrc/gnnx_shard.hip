@@ -171,6 +171,14 @@ struct gnnx_halo_plan {
     int32_t *d_halo = nullptr;      // [n_halo] new ids, ascending => grouped by owner
     int32_t *d_send_idx = nullptr;  // [n_send] local row ids, peer-major
     std::vector<int64_t> recv_rows, send_rows;
+    gnnx_halo_plan() = default;
+    gnnx_halo_plan(const gnnx_halo_plan &) = delete;
+    gnnx_halo_plan &operator=(const gnnx_halo_plan &) = delete;
+    ~gnnx_halo_plan()   // owns its device lists: an error path that drops the plan frees them too
+    {
+        if (d_halo) hipFree(d_halo);
+        if (d_send_idx) hipFree(d_send_idx);
+    }
 };
 
 GNNX_API int gnnx_vertex_weights(const int32_t *d_src, const int32_t *d_dst, int64_t n_edges, int32_t n_nodes, int32_t row_weight,
@@ -320,23 +328,14 @@ GNNX_API int gnnx_halo_plan_create(const int32_t *d_colidx_orig, int64_t nnz, co
     GNNX_HIP_CHECK(hipMalloc((void **)&plan->d_halo, sizeof(int32_t) * (size_t)(plan->n_halo ? plan->n_halo : 1)));
     if (n_nodes) {
         hipLaunchKernelGGL(halo_list_kernel, grid_for(n_nodes), dim3(T), 0, st, mark.as<int32_t>(), slot.as<int32_t>(), n_nodes, plan->d_halo);
-        if (hipGetLastError() != hipSuccess) {
-            hipFree(plan->d_halo);
-            return set_error(GNNX_ERR_HIP, "halo_list_kernel launch failed");
-        }
+        GNNX_LAUNCH_CHECK();
     }
     if (nnz) {
         hipLaunchKernelGGL(renumber_kernel, grid_for(nnz), dim3(T), 0, st, col_nid.as<int32_t>(), nnz, slot.as<int32_t>(), lo, hi,
                            (int32_t)plan->n_local, d_colidx_local);
-        if (hipGetLastError() != hipSuccess) {
-            hipFree(plan->d_halo);
-            return set_error(GNNX_ERR_HIP, "renumber_kernel launch failed");
-        }
+        GNNX_LAUNCH_CHECK();
     }
-    if (hipStreamSynchronize(st) != hipSuccess) {  // the scratch buffers are freed on return
-        hipFree(plan->d_halo);
-        return set_error(GNNX_ERR_HIP, "halo plan build failed");
-    }
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));  // the scratch buffers are freed on return
     if (world == 1) {
         plan->send_rows.assign(1, 0);
         plan->n_send = 0;
@@ -347,9 +346,6 @@ GNNX_API int gnnx_halo_plan_create(const int32_t *d_colidx_orig, int64_t nnz, co
 
 GNNX_API int gnnx_halo_plan_destroy(gnnx_halo_plan *plan)
 {
-    if (!plan) return GNNX_OK;
-    if (plan->d_halo) hipFree(plan->d_halo);
-    if (plan->d_send_idx) hipFree(plan->d_send_idx);
     delete plan;
     return GNNX_OK;
 }

@@ -225,8 +225,8 @@ public:
                "BatchNorm");
             part->comm->allreduce_sum(var->device_inplace(), f);
         }
-        const size_t ext_bytes = sizeof(float) * (size_t)(nl + part->fwd.n_halo) * (size_t)f;
-        float *hext = (float *)dev_alloc(ext_bytes);
+        Scratch hext_buf(sizeof(float) * (size_t)(nl + part->fwd.n_halo) * (size_t)f);   // back to the pool on every exit path
+        float *hext = hext_buf.as<float>();
         if (nl) gx(gnnx_memcpy_d2d(hext, h->device_data(), sizeof(float) * (size_t)nl * f, st), "aggregate");
         part->exchange(part->fwd, hext, f);
         const bool req = h->requires_grad() || (bias && bias->requires_grad()) || (use_bn && gamma->requires_grad()) ||
@@ -245,7 +245,6 @@ public:
                                          (const int32_t *)part->fwd.colidx, nullptr, nullptr, part->norm->device_data(),
                                          bias ? bias->device_data() : nullptr, hext, f, 0.0f, out->device_out(), f, use_bn ? &fu : nullptr,
                                          part->fwd.spmm_plan, st);
-        dev_free(hext, ext_bytes);
         gx(rc, "aggregate");
         has_bias = (bool)bias;
         if (req) context->save_for_backward({h, bias ? bias : h, use_bn ? gamma : h, has_beta ? beta : h});
@@ -264,15 +263,14 @@ public:
         if (has_bias && bias->requires_grad()) bias->backward(cyg::functional::sum(g, 0, bias->rank() == 2));  // local colsum(G)
         if (!(h->requires_grad() || (use_bn && gamma->requires_grad()) || (has_beta && beta->requires_grad()))) return;
         part->ensure_spmm_plans(f);
-        const size_t ext_bytes = sizeof(float) * (size_t)(nl + part->bwd.n_halo) * (size_t)f;
-        float *gext = (float *)dev_alloc(ext_bytes);
+        Scratch gext_buf(sizeof(float) * (size_t)(nl + part->bwd.n_halo) * (size_t)f);
+        float *gext = gext_buf.as<float>();
         if (nl) gx(gnnx_memcpy_d2d(gext, g->device_data(), sizeof(float) * (size_t)nl * f, st), "aggregate");
         part->exchange(part->bwd, gext, f);
         auto dy = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
         int rc = gnnx_spmm_csr_f32((int32_t)nl, (int32_t)(nl + part->bwd.n_halo), f, (const int32_t *)part->bwd.rowptr,
                                    (const int32_t *)part->bwd.colidx, (const float *)part->norm_nz_bwd, nullptr, nullptr, nullptr, gext, f,
                                    0.0f, dy->device_out(), f, part->bwd.spmm_plan, st);
-        dev_free(gext, ext_bytes);
         gx(rc, "aggregate");
         if (!use_bn) {
             if (h->requires_grad()) h->backward(dy);

@@ -136,9 +136,6 @@ class HostStagedDist:
     (every rank on device 0), which is all the builder had; on a multi-GPU node the backend is nccl (= RCCL) and this class is
     not used.  Collectives are synchronous (the device stream is drained first); async_op returns a completed handle."""
 
-    class ReduceOp:
-        pass
-
     def __init__(self, dist):
         self._d = dist
         self.ReduceOp = dist.ReduceOp
