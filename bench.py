@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--train-layers", type=int, default=0,
                     help="N=1 only: time a whole training step of an L-layer GCN instead (forward, softmax-CE, backward, SGD); "
                          "value counts L*nnz edges per step")
+    ap.add_argument("--no-pad-features", action="store_true",
+                    help="store feature rows at their own width even when it is not a multiple of 128 floats (default: pad the stride)")
     ap.add_argument("--sym", action="store_true",
                     help="N=1: Mode SYM, the textbook D^-1/2 A D^-1/2 aggregation of the north_star (per-edge scale) instead of the "
                          "reference's factorised norm (Mode REF, the parity-graded default); same kernel, +4 B/edge of traffic")
@@ -167,7 +169,7 @@ def main():
         runner = TrainStep(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk, args.train_layers)
         runner.workload = args.workload
     elif world == 1 and not args.force_sharded:
-        runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk)
+        runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk, pad=not args.no_pad_features)
         runner.workload = args.workload
         runner.sym = args.sym
         runner.bf16_features = args.bf16_features
@@ -246,7 +248,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": runner.nnz_total,
-                       "features": F, "layer": f"{F}->{F}",
+                       "features": F, "layer": f"{F}->{F}", "feature_row_stride": getattr(runner, "Fp", F),
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 and not args.force_sharded else
@@ -271,8 +273,15 @@ def main():
 class SingleGpu:
     """Whole graph on one MI355X.  All buffers are allocated here, outside the timed region."""
 
-    def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk):
+    def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk, pad=True):
         self.ops, self.capi, self.F, self.n = ops, capi, F, n
+        # When the width is not a multiple of 128 floats (the products-shaped F = 100) the rows that are only STREAMED -- X, dH, dX,
+        # and W / dW -- are stored with a 128-float stride (pad columns zero, and they stay zero), so the two backward products run
+        # as 128-wide ones on the LDS-DMA kernels (zero columns add exact zeros at the end of every fmaf chain: the same bits in
+        # the first F columns).  The rows that are GATHERED -- H and G -- keep their own width: measured, a 512-byte stride there
+        # costs the aggregation 11 % (5.03 vs 4.53 ms; 28 % more footprint in L2 / MALL), more than all three products gain.
+        Fp = -(-F // 128) * 128 if (pad and F % 128 and F >= 64 and n >= 100_000) else F
+        self.Fp = Fp
         if abc is None:
             s, d = pkg.synth.uniform_edges(seed, n, e)
             src, dst = torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)
@@ -285,15 +294,28 @@ class SingleGpu:
         if chunk > 0:
             g.make_plans(chunk, F)
         self.nnz_total = g.nnz
-        self.X = ops.uniform_pm1(seed + 10, (n, F), device=dev)
-        self.W = ops.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5, device=dev)
+        def padded(t, rows):   # [rows, Fp] zero-padded copy of t (or t itself); the GEMMs take the padded tensor, everything
+            if Fp == F:        # else its [:, :F] view
+                return t
+            p = torch.zeros((rows, Fp), dtype=torch.float32, device=dev)
+            p[:, :F] = t
+            return p
+
+        self.Xp = padded(ops.uniform_pm1(seed + 10, (n, F), device=dev), n)
+        Wf = ops.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5, device=dev)
+        self.Wp = padded(Wf, F) if Fp == F else torch.zeros((Fp, Fp), dtype=torch.float32, device=dev)
+        if Fp != F:
+            self.Wp[:F, :F] = Wf
         self.bias = torch.zeros(F, dtype=torch.float32, device=dev)  # graph.cpp:167
-        self.G = ops.uniform_pm1(seed + 12, (n, F), device=dev)
-        self.H = torch.empty((n, F), dtype=torch.float32, device=dev)
-        self.out = torch.empty((n, F), dtype=torch.float32, device=dev)
-        self.dH = torch.empty((n, F), dtype=torch.float32, device=dev)
-        self.dX = torch.empty((n, F), dtype=torch.float32, device=dev)
-        self.dW = torch.empty((F, F), dtype=torch.float32, device=dev)
+        self.Gp = ops.uniform_pm1(seed + 12, (n, F), device=dev)
+        self.Hp = torch.zeros((n, F), dtype=torch.float32, device=dev)
+        self.outp = torch.zeros((n, F), dtype=torch.float32, device=dev)
+        self.dHp = torch.zeros((n, Fp), dtype=torch.float32, device=dev)
+        self.dXp = torch.zeros((n, Fp), dtype=torch.float32, device=dev)
+        self.dWp = torch.zeros((Fp, Fp), dtype=torch.float32, device=dev)
+        self.X, self.W, self.G = self.Xp[:, :F], self.Wp[:F, :F], self.Gp[:, :F]
+        self.H, self.out, self.dH, self.dX, self.dW = (self.Hp[:, :F], self.outp[:, :F], self.dHp[:, :F], self.dXp[:, :F],
+                                                        self.dWp[:F, :F])
         self.dbias = torch.empty(F, dtype=torch.float32, device=dev)
         self.names = ["gemm_xwT", "spmm_fwd", "colsum", "spmm_bwd", "gemm_dX", "gemm_dW"]
         self.ev = []  # per timed step: list of (start, stop) HIP events on the launch stream
@@ -336,8 +358,8 @@ class SingleGpu:
         run(lambda: ops.aggregate_fwd_sym(g, self.H, self.bias, out=self.out) if sym else ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
         run(lambda: ops.colsum(self.G, out=self.dbias))
         run(lambda: ops.aggregate_bwd_sym(g, self.G, out=self.dH) if sym else ops.aggregate_bwd(g, self.G, out=self.dH))
-        run(lambda: ops.gemm_split(self.dH, self.W, transB=False, out=self.dX) if split else ops.gemm(self.dH, self.W, out=self.dX))
-        run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+        run(lambda: ops.gemm_split(self.dH, self.W, transB=False, out=self.dX) if split else ops.gemm(self.dHp, self.Wp, out=self.dXp))
+        run(lambda: ops.gemm(self.dHp, self.Xp, transA=True, out=self.dWp))
         if timed:
             self.ev.append(evs)
 
@@ -383,8 +405,8 @@ class TrainStep(SingleGpu):
     against synthetic labels, backward, SGD.  Reuses SingleGpu's graph / plans / roofline bookkeeping."""
 
     def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk, layers):
-        super().__init__(ops, capi, pkg, dev, n, e, F, abc, seed, chunk)
-        for nm in ("H", "out", "dH", "dX", "G"):
+        super().__init__(ops, capi, pkg, dev, n, e, F, abc, seed, chunk, pad=False)
+        for nm in ("H", "out", "dH", "dX", "G", "Hp", "outp", "dHp", "dXp", "Gp"):
             setattr(self, nm, None)  # free the single-layer buffers
         torch.cuda.empty_cache()
         self.net = ops.GcnStack(self.g, [F] * (layers + 1), seed=seed + 100, device=dev)

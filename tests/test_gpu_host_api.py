@@ -215,3 +215,32 @@ def test_multi_process_job_rehearsal_on_one_gpu():
         d = json.loads(lines[0])
         assert d["n_gpus"] == world and d["scaling"] == "strong" and d["config"]["nnz"] == single["config"]["nnz"]
         assert "REHEARSAL" in d["config"]["parallelism"] and d["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+def test_bench_padded_feature_rows_same_bits():
+    """bench.py stores the streamed F = 100 rows (X, dH, dX) with a 128-float stride (products-shaped config) so the backward
+    products run on the 128-wide LDS-DMA kernels: every output of the step equals, bit for bit (dW: to split-K rounding), the one computed on rows stored at their own width."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pkg = bench.load_package()
+    from importlib import import_module
+    ops, capi = import_module("gnncpp_amd.ops"), import_module("gnncpp_amd.capi")
+    dev = torch.device("cuda:0")
+    outs = []
+    for pad in (True, False):
+        r = bench.SingleGpu(ops, capi, pkg, dev, 120_000, 1_000_000, 100, (0.57, 0.19, 0.19), 5, 4096, pad=pad)
+        r.step()
+        torch.cuda.synchronize()
+        outs.append({k: getattr(r, k).clone() for k in ("H", "out", "dH", "dX", "dW", "dbias")})
+        assert r.Fp == (128 if pad else 100)
+        if pad:
+            for nm in ("dHp", "dXp"):
+                assert not getattr(r, nm)[:, 100:].any(), nm + ": pad columns must stay zero"
+    for k in outs[0]:
+        if k == "dW":   # split-K over the 120 000 rows: the two kernels cut K differently (tolerance as in test_gpu_parity's dW cases)
+            torch.testing.assert_close(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-5 * float(outs[1][k].abs().max()))
+        else:
+            assert torch.equal(outs[0][k], outs[1][k]), k
