@@ -29,6 +29,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this driver stack shares device memory through dmabuf IPC only (RCCL's peer mappings need it); the
+# HSA runtime reads the switch when the first HIP call initialises it, so it is set before torch is imported
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -250,7 +254,7 @@ def main():
             "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": runner.nnz_total,
                        "features": F, "layer": f"{F}->{F}", "feature_row_stride": getattr(runner, "Fp", F),
                        "step": "layer fwd+bwd" if not args.train_layers else
-                       f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd, SGD); value counts {args.train_layers}*nnz",
+                       f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd of every parameter, SGD; no input gradient); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 and not args.force_sharded else
                        f"1-D vertex shard x{world} ({args.partition}), halo all-to-all-v, schedule {args.schedule}" +
                        (" -- REHEARSAL: gloo through host memory, all ranks on GPU 0: not a measurement" if args.dist_backend == "gloo" else ""),
@@ -308,11 +312,12 @@ class SingleGpu:
             self.Wp[:F, :F] = Wf
         self.bias = torch.zeros(F, dtype=torch.float32, device=dev)  # graph.cpp:167
         self.Gp = ops.uniform_pm1(seed + 12, (n, F), device=dev)
-        self.Hp = torch.zeros((n, F), dtype=torch.float32, device=dev)
-        self.outp = torch.zeros((n, F), dtype=torch.float32, device=dev)
-        self.dHp = torch.zeros((n, Fp), dtype=torch.float32, device=dev)
-        self.dXp = torch.zeros((n, Fp), dtype=torch.float32, device=dev)
-        self.dWp = torch.zeros((Fp, Fp), dtype=torch.float32, device=dev)
+        alloc = torch.zeros if Fp != F else torch.empty   # pad columns must start (and stay) zero
+        self.Hp = torch.empty((n, F), dtype=torch.float32, device=dev)
+        self.outp = torch.empty((n, F), dtype=torch.float32, device=dev)
+        self.dHp = alloc((n, Fp), dtype=torch.float32, device=dev)
+        self.dXp = alloc((n, Fp), dtype=torch.float32, device=dev)
+        self.dWp = alloc((Fp, Fp), dtype=torch.float32, device=dev)
         self.X, self.W, self.G = self.Xp[:, :F], self.Wp[:F, :F], self.Gp[:, :F]
         self.H, self.out, self.dH, self.dX, self.dW = (self.Hp[:, :F], self.outp[:, :F], self.dHp[:, :F], self.dXp[:, :F],
                                                         self.dWp[:F, :F])
@@ -420,8 +425,8 @@ class TrainStep(SingleGpu):
             a, b = self.capi.Event(), self.capi.Event()
             a.record(stream)
         logits = self.net.forward(self.X)
-        _, dlog = ops.softmax_ce(logits, self.target)
-        self.net.backward(dlog)
+        _, dlog = ops.softmax_ce(logits, self.target, colsum_out=self.net.db[-1])   # last layer's bias gradient from the loss kernel
+        self.net.backward(dlog, input_grad=False, have_last_bias_grad=True)           # the features are data: no dX of layer 1
         self.net.step(lr=1e-3)
         if timed:
             b.record(stream)

@@ -435,16 +435,21 @@ def gcn_layer_bwd(g, X, W, G):
 
 
 # ---- whole training step: multi-layer GCN + softmax cross-entropy + SGD ----------
-def softmax_ce(logits, target, want_grad=True):
-    """(mean loss as a 1-element device tensor, dlogits or None): gnnx_softmax_ce_f32 (reference forward nn.cpp:442-453)."""
+def softmax_ce(logits, target, want_grad=True, colsum_out=None):
+    """(mean loss as a 1-element device tensor, dlogits or None): gnnx_softmax_ce_f32 (reference forward nn.cpp:442-453).
+    colsum_out [C]: also the column sums of dlogits (the last layer's bias gradient), from the kernel that writes dlogits."""
     N, Cn = logits.shape
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
     d = torch.empty_like(logits) if want_grad else None
     wsb = C.c_size_t(0)
-    capi.call("gnnx_softmax_ce_workspace", N, C.byref(wsb))
+    if colsum_out is not None:
+        assert want_grad and colsum_out.numel() == Cn and colsum_out.is_contiguous()
+        capi.call("gnnx_softmax_ce_colsum_workspace", N, Cn, C.byref(wsb))
+    else:
+        capi.call("gnnx_softmax_ce_workspace", N, C.byref(wsb))
     ws = _workspace(wsb.value, logits.device, "ce")
-    capi.call("gnnx_softmax_ce_f32", _ptr(logits), _ld(logits), _ptr(target), N, Cn, _ptr(loss), _ptr(d), _ld(d) if want_grad else 0,
-              _ptr(ws), wsb.value, _stream())
+    capi.call("gnnx_softmax_ce_colsum_f32", _ptr(logits), _ld(logits), _ptr(target), N, Cn, _ptr(loss), _ptr(d), _ld(d) if want_grad else 0,
+              _ptr(colsum_out), _ptr(ws), wsb.value, _stream())
     return loss, d
 
 
@@ -477,18 +482,22 @@ class GcnStack:
         self._saved = saved
         return h
 
-    def backward(self, dOut, fused=True):
+    def backward(self, dOut, fused=True, input_grad=True, have_last_bias_grad=False):
         """fused: the ReLU mask of the layer below and its bias gradient ride in the epilogue of dH . W
-        (gnnx_gemm_relu_colsum_f32); fused=False runs them as their own passes (same G bits, db within rounding)."""
+        (gnnx_gemm_relu_colsum_f32); fused=False runs them as their own passes (same G bits, db within rounding).
+        input_grad=False: the stack's input is data (no requires_grad, as the reference's DataBatch features): dH . W of the
+        first layer is not computed and None is returned.  have_last_bias_grad: db[L-1] was already written by the loss kernel
+        (softmax_ce(..., colsum_out=net.db[-1]))."""
         G = dOut
         L = len(self.W)
-        colsum(G, out=self.db[L - 1])
+        if not have_last_bias_grad:
+            colsum(G, out=self.db[L - 1])
         for l in reversed(range(L)):
             h, Y = self._saved[l]
             dH = aggregate_bwd(self.g, G)
             gemm(dH, h, transA=True, out=self.dW[l])          # dW_l = dH^T . h
             if l == 0:
-                G = gemm(dH, self.W[l])                          # dX of the first layer: no ReLU below it
+                G = gemm(dH, self.W[l]) if input_grad else None  # dX of the first layer: no ReLU below it
             elif fused:
                 G, _ = gemm_relu_colsum(dH, self.W[l], h, colsum_out=self.db[l - 1])   # h = Y_{l-1} = relu output of the layer below
             else:

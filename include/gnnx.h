@@ -365,6 +365,14 @@ int gnnx_bn_relu_bwd_apply_f32(const float *d_X, int64_t ldx, const float *d_Y, 
 int gnnx_softmax_ce_workspace(int64_t n_rows, size_t *bytes);
 int gnnx_softmax_ce_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes, float *d_loss,
                         float *d_dlogits, int64_t ldd, void *d_workspace, size_t workspace_bytes, void *stream);
+/* The same with the column sums of dlogits -- the last layer's bias gradient (operation.h:114-128 sum_to_size on the Add node's
+ * bias operand, reached with dlogits as the incoming gradient) -- accumulated by the kernel that writes dlogits instead of one more
+ * pass over them.  d_colsum [n_classes] may be NULL (then exactly gnnx_softmax_ce_f32).  Deterministic (fixed summation order);
+ * the order differs from gnnx_colsum_f32's, so the two agree to rounding. */
+int gnnx_softmax_ce_colsum_workspace(int64_t n_rows, int32_t n_classes, size_t *bytes);
+int gnnx_softmax_ce_colsum_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes,
+                               float *d_loss, float *d_dlogits, int64_t ldd, float *d_colsum, void *d_workspace,
+                               size_t workspace_bytes, void *stream);
 int gnnx_sgd_step_f32(float *d_param, const float *d_grad, int64_t n, float lr, float weight_decay, void *stream);
 
 /* ------------------------------------------------------------------ halo (multi-GPU) ------------- */

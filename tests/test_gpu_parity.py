@@ -779,6 +779,38 @@ def test_softmax_cross_entropy_vs_oracle_and_float64(env):
         ops.softmax_ce(dev(env, X), dev(env, np.full(n, c, dtype=np.int32)))
 
 
+@pytest.mark.parametrize("n,c", [(20001, 256), (777, 48), (5000, 1000), (3001, 1028), (100, 7), (9, 4)])
+def test_softmax_cross_entropy_shapes_and_fused_bias_gradient(env, n, c):
+    """Both kernels of gnnx_softmax_ce_colsum_f32 (the one-16-byte-load-per-lane form for class counts that are multiples of 4 up
+    to 1024 -- the bench's 256 is one 1-KiB wave-instruction per row -- and the generic walk) against float64, an odd number of
+    rows (the two-rows-in-flight tail), a padded row stride, and the column sums of dlogits written by the same kernel against a
+    float64 column sum and against gnnx_colsum_f32 over the stored gradient."""
+    ops, torch = env["ops"], env["torch"]
+    X = synth.uniform_pm1(900 + c, (n, c)) * 3.0
+    t = ((7 * np.arange(n) + 3) % c).astype(np.int32)
+    x = X.astype(np.float64)
+    p = np.exp(x) / np.exp(x).sum(1, keepdims=True)
+    loss_ref = float(-np.log(p[np.arange(n), t]).mean())
+    p[np.arange(n), t] -= 1.0
+    p /= n
+    for pad in (0, 4):
+        Xd = torch.zeros((n, c + pad), dtype=torch.float32, device="cuda")
+        Xd[:, :c] = dev(env, X)
+        db = torch.full((c,), 7.0, dtype=torch.float32, device="cuda")
+        loss, d = ops.softmax_ce(Xd[:, :c], dev(env, t), colsum_out=db)
+        assert abs(float(host(loss)[0]) - loss_ref) <= 1e-5 * max(1.0, abs(loss_ref))
+        assert abs(float(host(loss)[0]) - oracle.cross_entropy(X, t)) <= 1e-5 * max(1.0, abs(loss_ref))
+        assert np.abs(host(d) - p).max() <= 1e-5 / n * 10
+        ref_db = p.sum(0)
+        assert np.abs(host(db) - ref_db).max() <= 1e-5 * max(np.abs(p).sum(0).max(), 1e-12)
+        sep = ops.colsum(d)
+        assert np.abs(host(db) - host(sep)).max() <= 1e-5 * max(np.abs(p).sum(0).max(), 1e-12)
+        loss2, d2 = ops.softmax_ce(Xd[:, :c], dev(env, t))   # without the column sums: the same loss and gradient bits
+        assert torch.equal(d, d2) and torch.equal(loss, loss2)
+    with pytest.raises(env["capi"].GnnxError):
+        ops.softmax_ce(dev(env, X), dev(env, np.full(n, c, dtype=np.int32)))
+
+
 def test_two_layer_training_step_vs_float64(env):
     """Whole step of a 2-layer GCN (transform, aggregate, ReLU, transform, aggregate, softmax-CE, backward, SGD) against a
     float64 numpy evaluation of the same network; then the loss goes down under SGD."""
@@ -823,11 +855,20 @@ def test_two_layer_training_step_vs_float64(env):
         assert err <= 2e-5 * max(np.abs(ref).max(), 1e-3), f"{nm}: {err:.3e} vs scale {np.abs(ref).max():.3e}"
     # ---- SGD: the loss decreases
     losses = []
+    # ---- the training-step form bench.py --train-layers runs: bias gradient of the last layer from the loss kernel, no input
+    # gradient: the same parameter gradients
+    keep = [host(v).copy() for v in net.dW + net.db]
+    logits = net.forward(dev(env, X))
+    loss, dlog = ops.softmax_ce(logits, dev(env, t), colsum_out=net.db[-1])
+    assert net.backward(dlog, input_grad=False, have_last_bias_grad=True) is None
+    for a, bref, nm in zip(net.dW + net.db, keep, ("dW0", "dW1", "db0", "db1")):
+        tol = 0.0 if nm != "db1" else 1e-6 * float(np.abs(bref).max())
+        assert np.abs(host(a) - bref).max() <= tol, nm
     for _ in range(20):
         logits = net.forward(dev(env, X))
-        loss, dlog = ops.softmax_ce(logits, dev(env, t))
+        loss, dlog = ops.softmax_ce(logits, dev(env, t), colsum_out=net.db[-1])
         losses.append(float(host(loss)[0]))
-        net.backward(dlog)
+        net.backward(dlog, input_grad=False, have_last_bias_grad=True)
         net.step(lr=0.05)
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
 
