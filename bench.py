@@ -283,7 +283,8 @@ class SingleGpu:
         # and W / dW -- are stored with a 128-float stride (pad columns zero, and they stay zero), so the two backward products run
         # as 128-wide ones on the LDS-DMA kernels (zero columns add exact zeros at the end of every fmaf chain: the same bits in
         # the first F columns).  The rows that are GATHERED -- H and G -- keep their own width: measured, a 512-byte stride there
-        # costs the aggregation 11 % (5.03 vs 4.53 ms; 28 % more footprint in L2 / MALL), more than all three products gain.
+        # costs the aggregation 11 % (5.03 vs 4.53 ms; 28 % more footprint in L2 / MALL), more than all three products gain;
+        # X.W^T (K = 128 padded, N = F) writes the F-wide H through the LDS-DMA kernel's guarded last column tile.
         Fp = -(-F // 128) * 128 if (pad and F % 128 and F >= 64 and n >= 100_000) else F
         self.Fp = Fp
         if abc is None:
@@ -359,7 +360,7 @@ class SingleGpu:
                 self.ev.append(evs)
             return
         split = getattr(self, "split_gemm", False)
-        run(lambda: ops.gemm_split(self.X, self.W, transB=True, out=self.H) if split else ops.linear_fwd(self.X, self.W, out=self.H))
+        run(lambda: ops.gemm_split(self.X, self.W, transB=True, out=self.H) if split else ops.linear_fwd(self.Xp, self.Wp[:self.F], out=self.H))
         run(lambda: ops.aggregate_fwd_sym(g, self.H, self.bias, out=self.out) if sym else ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
         run(lambda: ops.colsum(self.G, out=self.dbias))
         run(lambda: ops.aggregate_bwd_sym(g, self.G, out=self.dH) if sym else ops.aggregate_bwd(g, self.G, out=self.dH))
@@ -415,6 +416,7 @@ class TrainStep(SingleGpu):
             setattr(self, nm, None)  # free the single-layer buffers
         torch.cuda.empty_cache()
         self.net = ops.GcnStack(self.g, [F] * (layers + 1), seed=seed + 100, device=dev)
+        self.X = self.net.pad_input(self.X)   # static features: stored once in the stack's streamed layout (a no-op for F % 128 == 0)
         self.target = (torch.arange(n, device=dev, dtype=torch.int64) * 7 + 3).remainder(F).to(torch.int32)
         self.names = ["train_step"]
 

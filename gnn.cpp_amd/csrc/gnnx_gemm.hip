@@ -499,7 +499,10 @@ struct GemmFuse {
     float *colsum_partial;   // FUSE 1: [gridDim.y][N]; FUSE 2: [gridDim.y][2][N]
 };
 
-template <int WM_, int WN_, int FUSE>
+// NG (N guard): the last column tile is narrower than BN (N % 4 == 0): lanes whose 16 bytes lie past column N neither load B
+// (their LDS slots keep whatever they held: the products of those columns are garbage and stay in registers) nor store C nor
+// contribute column sums.
+template <int WM_, int WN_, int FUSE, bool NG>
 __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate, GemmFuse fu)
 {
     (void)ablate;
@@ -533,13 +536,16 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
         pb[u] = lds0 + B0 + (uint32_t)((wave + NW * u) * GEO::B_PIECE_BYTES);
     }
     const float *bcol = g.B + n0;
+    const int64_t n_left = g.N - n0;   // columns of this tile that exist
+    const bool okb = !NG || 4 * (lane % (64 / GEO::rows_per_instr(BN))) + 4 <= n_left;   // this lane's 4 B columns
+    const bool okc = !NG || wn * 64 + 4 * (lane & 15) + 4 <= n_left;                      // this lane's 4 C columns
     auto issue = [&](int stage, int64_t mt, int64_t k0) {
         const float *abase = g.A + mt * BM * g.lda + k0;
         const float *bbase = bcol + k0 * g.ldb;
 #pragma unroll
         for (int u = 0; u < (APW > BPW ? APW : BPW); u++) {
             if (u < APW) dma_16B(offa[u < APW ? u : 0], abase, pa[u < APW ? u : 0] + stage * GEO::A_STAGE_BYTES);
-            if (u < BPW) dma_16B(offb[u < BPW ? u : 0], bbase, pb[u < BPW ? u : 0] + stage * GEO::B_STAGE_BYTES);
+            if (u < BPW && okb) dma_16B(offb[u < BPW ? u : 0], bbase, pb[u < BPW ? u : 0] + stage * GEO::B_STAGE_BYTES);
         }
     };
     // ---- fragment address registers (bytes): the 8 k-groups of this lane's row of block 0 (the row's slot XOR is the same in
@@ -575,7 +581,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
     gemm_f32x4acc csum = {0.f, 0.f, 0.f, 0.f};   // FUSE: column sums of this lane's 4 columns over every row it stores
     gemm_f32x4acc csq = {0.f, 0.f, 0.f, 0.f};    // FUSE 2: sums of squares (of the shifted values)
     gemm_f32x4acc shift4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (FUSE == 2) shift4 = *reinterpret_cast<const gemm_f32x4acc *>(fu.ymask + n0 + wn * 64 + 4 * (lane & 15));
+    if constexpr (FUSE == 2)
+        if (okc) shift4 = *reinterpret_cast<const gemm_f32x4acc *>(fu.ymask + n0 + wn * 64 + 4 * (lane & 15));
     const uint32_t offy = FUSE == 1 ? (uint32_t)((wm * 64 + (lane >> 4)) * fu.ldy + wn * 64 + 4 * (lane & 15)) * 4u : 0u;
     int64_t mt = blockIdx.y;
     if (mt < m_tiles) issue(0, mt, 0);
@@ -622,12 +629,13 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
                 if (alpha != 1.0f) v = v * alpha;
                 asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ep_wr), "v"(v), "i"(64 * j) : "memory");
             }
-            gemm_f32x4acc ym[4];
+            gemm_f32x4acc ym[4] = {};
             if constexpr (FUSE == 1) {   // issued behind the LDS writes (block row i's accumulators are dead by now: their registers
                                     // take the mask values) and in flight during the LDS round trip below
                 const char *yrow = ytile + (int64_t)(16 * i) * fu.ldy * 4;
 #pragma unroll
-                for (int p = 0; p < 4; p++) ym[p] = *reinterpret_cast<const gemm_f32x4acc *>(yrow + (int64_t)(4 * p) * fu.ldy * 4 + offy);
+                for (int p = 0; p < 4; p++)
+                    if (okc) ym[p] = *reinterpret_cast<const gemm_f32x4acc *>(yrow + (int64_t)(4 * p) * fu.ldy * 4 + offy);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             gemm_f32x4acc o[4];
@@ -647,7 +655,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
                     csum += d;
                     csq += d * d;
                 }
-                *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * 4 + offc) = o[p];
+                if (okc) *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * 4 + offc) = o[p];
             }
         }
     }
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
         __syncthreads();
         red[wave * 64 + lane] = csum;
         __syncthreads();
-        if (tid < BN / 4) {   // thread t: columns 4t..4t+3 of the tile = column group t / 16, 16-byte column t % 16
+        if (tid < BN / 4 && (!NG || 4 * tid + 4 <= n_left)) {   // thread t: columns 4t..4t+3 of the tile = column group t / 16, 16-byte column t % 16
             const int cg = tid >> 4, c16 = tid & 15;
             gemm_f32x4acc sum = {0.f, 0.f, 0.f, 0.f};
             for (int w = 0; w < GEO::WM; w++)
@@ -671,7 +679,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
             __syncthreads();
             red[wave * 64 + lane] = csq;
             __syncthreads();
-            if (tid < BN / 4) {
+            if (tid < BN / 4 && (!NG || 4 * tid + 4 <= n_left)) {
                 const int cg = tid >> 4, c16 = tid & 15;
                 gemm_f32x4acc sum = {0.f, 0.f, 0.f, 0.f};
                 for (int w = 0; w < GEO::WM; w++)
@@ -1032,7 +1040,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_tn_kernel(GemmArgs g)
 
 bool dma_shape_ok(int64_t M, int64_t N, int64_t K)
 {
-    return K % 64 == 0 && N % 128 == 0 && M >= 8 * 256;
+    return K % 64 == 0 && N % 4 == 0 && N >= 64 && M >= 8 * 256;   // N off the 128 grid: guarded last column tile (NG)
 }
 
 // dynamic-LDS opt-in of a kernel: once per kernel AND device (bit d of the caller's mask; thread-safe)
@@ -1048,14 +1056,14 @@ int lds_opt_in(K kernel, size_t lds, std::atomic<uint64_t> &done)
     return GNNX_OK;
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool NG>
 int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse, int64_t *partial_rows, int fuse_mode)
 {
     using GEO = DmaGeo<WM, WN>;
     constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK;
     if ((int64_t)BM * g.lda >= (1ll << 28) || (int64_t)BK * g.ldb >= (1ll << 28) || (int64_t)BM * g.ldc >= (1ll << 28))
         return GNNX_OK;  // per-lane BYTE offsets are 32-bit
-    const int64_t m_tiles = g.M / BM, cols = g.N / BN;
+    const int64_t m_tiles = g.M / BM, cols = ceil_div(g.N, (int64_t)BN);
     int64_t gy = ceil_div((int64_t)kNumCU, cols);
     if (gy > m_tiles) gy = m_tiles;
     constexpr size_t lds = GEO::LDS_BYTES;   // 4 x 4: 2 x (32 KB + 34 KB) = 132 KB; 4 x 2: 2 x (32 KB + 16 KB) = 96 KB
@@ -1064,20 +1072,20 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
     const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
     if (fuse && fuse_mode == 2) {
         if (!aligned16(fuse->ymask)) return GNNX_OK;
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 2>, lds, done_stats);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 2, NG>, lds, done_stats);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 2>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 2, NG>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else if (fuse) {
         if (fuse->ldy % 4 || !aligned16(fuse->ymask) || (int64_t)BM * fuse->ldy >= (1ll << 28)) return GNNX_OK;
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 1>, lds, done_fuse);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 1, NG>, lds, done_fuse);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 1>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 1, NG>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else {
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0>, lds, done_plain);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0, NG>, lds, done_plain);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0, NG>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
     }
     GNNX_LAUNCH_CHECK();
     *rows_done = m_tiles * BM;
@@ -1091,8 +1099,9 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const Gemm
     *rows_done = 0;
     if (!dma_shape_ok(g.M, g.N, g.K)) return GNNX_OK;
     if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return GNNX_OK;
-    if (g.N % 256 == 0) return launch_dma_geo<4, 4>(g, st, rows_done, fuse, partial_rows, fuse_mode);
-    return launch_dma_geo<4, 2>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    if (g.N % 256 == 0) return launch_dma_geo<4, 4, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    if (g.N % 128 == 0) return launch_dma_geo<4, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    return launch_dma_geo<4, 2, true>(g, st, rows_done, fuse, partial_rows, fuse_mode);
 }
 
 bool dma_tn_shape_ok(int64_t M, int64_t N, int64_t K) { return M % 128 == 0 && N % 128 == 0 && K % 64 == 0 && K >= 64 * 1024; }

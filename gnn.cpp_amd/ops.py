@@ -460,27 +460,78 @@ def sgd_step(param, grad, lr, weight_decay=0.0):
 
 class GcnStack:
     """L GCN layers on one graph: h_{l+1} = act( norm (.) (A . (h_l W_l^T)) + b_l ), ReLU between layers, none after the
-    last.  forward / backward / SGD step, every op a C-ABI call; activations are kept for backward."""
+    last.  forward / backward / SGD step, every op a C-ABI call; activations are kept for backward.
 
-    def __init__(self, g, dims, seed=0, device="cuda"):
+    Layout for widths off the 128 grid (pad_streamed; automatic for widths >= 64 on graphs of >= 100 000 nodes: the
+    products-shaped F = 100): matrices whose rows are only STREAMED by the dense products -- layer inputs / outputs Y_l, dH_l,
+    W_l, dW_l -- are stored with every width rounded up to 128 floats, pad columns zero (they stay zero: the aggregations write
+    the logical columns only, the products of zero columns are zero), so the products run on the LDS-DMA kernels; matrices
+    whose rows are GATHERED by the aggregations -- H_l = h_l W_l^T and the gradients G_l -- keep their own width (a 512-byte
+    stride there costs the gather more than the products gain).  Zero columns add exact zeros at the end of
+    every fmaf chain: the logical columns have the same bits in both layouts (dW: up to how split-K cuts the rows)."""
+
+    def __init__(self, g, dims, seed=0, device="cuda", pad_streamed=None):
         self.g = g
-        self.W = [uniform_pm1(seed + 2 * l, (dims[l + 1], dims[l]), scale=dims[l] ** -0.5, device=device) for l in range(len(dims) - 1)]
-        self.b = [torch.zeros(dims[l + 1], dtype=torch.float32, device=device) for l in range(len(dims) - 1)]
-        self.dW = [torch.zeros_like(w) for w in self.W]
+        self.dims = list(dims)
+        L = len(dims) - 1
+        if pad_streamed is None:
+            pad_streamed = g.n >= 100_000
+        self.P = [-(-d // 128) * 128 if (pad_streamed and d % 128 and d >= 64) else d for d in dims]
+        self.padded = self.P != self.dims
+        self.Wp = [torch.zeros((self.P[l + 1], self.P[l]), dtype=torch.float32, device=device) for l in range(L)]
+        self.dWp = [torch.zeros_like(w) for w in self.Wp]
+        self.W = [self.Wp[l][:dims[l + 1], :dims[l]] for l in range(L)]     # the logical matrices (views)
+        self.dW = [self.dWp[l][:dims[l + 1], :dims[l]] for l in range(L)]
+        for l in range(L):
+            self.W[l].copy_(uniform_pm1(seed + 2 * l, (dims[l + 1], dims[l]), scale=dims[l] ** -0.5, device=device))
+        self.b = [torch.zeros(dims[l + 1], dtype=torch.float32, device=device) for l in range(L)]
         self.db = [torch.zeros_like(b) for b in self.b]
         self._saved = None
+        self._buf = {}
+
+    def _zeros(self, key, shape, device):
+        """persistent zero-initialised buffer (padded layout: pad columns are written once, here)"""
+        t = self._buf.get(key)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._buf[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+        return t
+
+    def pad_input(self, X):
+        """[n, P0] zero-padded copy of the layer-0 input (call once for static features; forward() accepts its [:, :d0] view)."""
+        if self.P[0] == self.dims[0]:
+            return X
+        Xp = torch.zeros((X.shape[0], self.P[0]), dtype=torch.float32, device=X.device)
+        Xp[:, :self.dims[0]] = X
+        return Xp[:, :self.dims[0]]
 
     def forward(self, X):
-        saved, h = [], X
         L = len(self.W)
+        if not self.padded:
+            saved, h = [], X
+            for l in range(L):
+                H = linear_fwd(h, self.W[l])
+                # the ReLU between layers rides in the aggregation's epilogue: only relu(Z) is stored (its sign is the mask)
+                Y = aggregate_fwd(self.g, H, self.b[l], relu_out=l + 1 < L)
+                saved.append((h, Y))
+                h = Y
+            self._saved = saved
+            return h
+        n, d, P = X.shape[0], self.dims, self.P
+        if P[0] != d[0]:
+            if X.stride(0) != P[0] or X.stride(1) != 1:   # not a view of a padded buffer (pad_input): pad a copy
+                X = self.pad_input(X)
+            hp = torch.as_strided(X, (n, P[0]), (P[0], 1))
+        else:
+            hp = X
+        saved = []
         for l in range(L):
-            H = linear_fwd(h, self.W[l])
-            # the ReLU between layers rides in the aggregation's epilogue: only relu(Z) is stored (its sign is the mask)
-            Y = aggregate_fwd(self.g, H, self.b[l], relu_out=l + 1 < L)
-            saved.append((h, Y))
-            h = Y
+            H = linear_fwd(hp, self.Wp[l][:d[l + 1]])                 # K = P[l] (zero pads), N = d[l+1]: gathered, own width
+            Yp = self._zeros(("Y", l), (n, P[l + 1]), X.device)
+            aggregate_fwd(self.g, H, self.b[l], out=Yp[:, :d[l + 1]], relu_out=l + 1 < L)
+            saved.append((hp, Yp))
+            hp = Yp
         self._saved = saved
-        return h
+        return hp[:, :d[L]]
 
     def backward(self, dOut, fused=True, input_grad=True, have_last_bias_grad=False):
         """fused: the ReLU mask of the layer below and its bias gradient ride in the epilogue of dH . W
@@ -490,22 +541,30 @@ class GcnStack:
         (softmax_ce(..., colsum_out=net.db[-1]))."""
         G = dOut
         L = len(self.W)
+        d, P = self.dims, self.P
         if not have_last_bias_grad:
             colsum(G, out=self.db[L - 1])
         for l in reversed(range(L)):
             h, Y = self._saved[l]
-            dH = aggregate_bwd(self.g, G)
-            gemm(dH, h, transA=True, out=self.dW[l])          # dW_l = dH^T . h
-            if l == 0:
-                G = gemm(dH, self.W[l]) if input_grad else None  # dX of the first layer: no ReLU below it
-            elif fused:
-                G, _ = gemm_relu_colsum(dH, self.W[l], h, colsum_out=self.db[l - 1])   # h = Y_{l-1} = relu output of the layer below
+            if self.padded:
+                dH = self._zeros(("dH", P[l + 1]), (G.shape[0], P[l + 1]), G.device)   # streamed: padded width
+                aggregate_bwd(self.g, G, out=dH[:, :d[l + 1]])
+                Wl, hl = self.Wp[l][:, :d[l]], h[:, :d[l]]            # [P_out, d_in] (ld P_in); the layer input, logical width
+                gemm(dH, h, transA=True, out=self.dWp[l])             # dW_l = dH^T . h on the padded widths
             else:
-                G = gemm(dH, self.W[l])
-                G, _, _ = bn_relu_bwd(h, h, G, relu=True)
+                dH = aggregate_bwd(self.g, G)
+                Wl, hl = self.W[l], h
+                gemm(dH, h, transA=True, out=self.dW[l])          # dW_l = dH^T . h
+            if l == 0:
+                G = gemm(dH, Wl) if input_grad else None             # dX of the first layer: no ReLU below it
+            elif fused:
+                G, _ = gemm_relu_colsum(dH, Wl, hl, colsum_out=self.db[l - 1])   # h = Y_{l-1} = relu output of the layer below
+            else:
+                G = gemm(dH, Wl)
+                G, _, _ = bn_relu_bwd(hl, hl, G, relu=True)
                 colsum(G, out=self.db[l - 1])
         return G
 
     def step(self, lr, weight_decay=0.0):
-        for p, gr in zip(self.W + self.b, self.dW + self.db):
+        for p, gr in zip(self.Wp + self.b, self.dWp + self.db):   # padded storage: pads are 0 - lr * (0 + wd * 0) = 0
             sgd_step(p, gr, lr, weight_decay)

@@ -370,6 +370,45 @@ def test_gcn_stack_backward_fused_equals_unfused(env):
         assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
 
 
+@pytest.mark.parametrize("dims", [[100, 100, 100, 100], [100, 72, 47]])
+def test_gcn_stack_padded_streamed_layout_same_bits(env, dims):
+    """Widths off the 128 grid: the stack that stores its streamed matrices (Y_l, dH_l, W_l, dW_l) on 128-float strides and keeps
+    the gathered ones (H_l, G_l) at their own width gives the same logits and input gradient bit for bit as the
+    stack on packed storage (dW, db: to the rounding of split-K / of the column-sum order), pads stay zero through forward, backward and an SGD step."""
+    ops, torch = env["ops"], env["torch"]
+    n, e = 120_000, 1_000_000
+    src, dst, rp, ci, g = make_graph(env, n, e, seed=43)
+    X = ops.uniform_pm1(93, (n, dims[0]), device=env["dev"])
+    dOut = ops.uniform_pm1(94, (n, dims[-1]), device=env["dev"])
+    nets = [ops.GcnStack(g, dims, seed=9, device=env["dev"], pad_streamed=ps) for ps in (True, False)]
+    assert nets[0].padded and not nets[1].padded and nets[0].P[0] == 128
+    res = []
+    for net in nets:
+        for l in range(len(dims) - 1):
+            net.b[l].copy_(ops.uniform_pm1(95 + l, (dims[l + 1],), scale=0.2, device=env["dev"]))
+        out = net.forward(net.pad_input(X)).clone()
+        gin = net.backward(dOut).clone()
+        res.append((out, gin, [w.clone() for w in net.dW], [b.clone() for b in net.db]))
+    (oa, ga, dWa, dba), (ob, gb, dWb, dbb) = res
+    assert torch.equal(oa, ob) and torch.equal(ga, gb)
+    for a, b in zip(dba[:-1], dbb[:-1]):   # column sums from the fused epilogue vs the separate pass: different (fixed) orders
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+    assert torch.equal(dba[-1], dbb[-1])
+    for a, b in zip(dWa, dWb):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+    net = nets[0]
+    # a plain (unpadded) input is accepted too, same result
+    assert torch.equal(net.forward(X), oa)
+    net.backward(dOut)
+    net.step(lr=0.01, weight_decay=1e-4)
+    for l in range(len(dims) - 1):
+        do, di = dims[l + 1], dims[l]
+        for t in (net.Wp[l], net.dWp[l]):
+            assert not t[do:].any() and not t[:, di:].any(), "pads of W / dW must stay zero"
+    for (hp, Yp), l in zip(net._saved, range(len(dims) - 1)):
+        assert not Yp[:, dims[l + 1]:].any() and not hp[:, dims[l]:].any()
+
+
 def test_gemm_beta_accumulate(env):
     ops = env["ops"]
     A = synth.uniform_pm1(71, (300, 40))
@@ -1057,7 +1096,8 @@ def test_bf16_feature_storage(env, n, e, F, chunk):
 
 
 # ---- the resident streaming GEMM kernel (tall products with whole tiles; the ragged remainder goes to the generic kernel) --
-@pytest.mark.parametrize("M,N,K", [(300077, 256, 256), (2 * 131072 + 1, 128, 128), (262144 + 255, 256, 64), (600000, 512, 32)])
+@pytest.mark.parametrize("M,N,K", [(300077, 256, 256), (2 * 131072 + 1, 128, 128), (262144 + 255, 256, 64), (600000, 512, 32),
+                                   (300077, 100, 128), (262144 + 255, 200, 64), (100000, 68, 192), (100003, 380, 128)])
 def test_gemm_streaming_kernel_tall_products(env, M, N, K):
     """X.W^T and dH.W on hundreds of thousands of rows take gemm_stream_kernel for the whole 256-row (128-row) tiles and
     gemm_kernel for the rest: every row -- first tile, tile seams, the ragged tail -- against float64, and bit-identical to
@@ -1082,6 +1122,44 @@ def test_gemm_streaming_kernel_tall_products(env, M, N, K):
         assert torch.equal(short, H[s:s + 1000])
         short2 = ops.gemm(X[s:s + 1000].contiguous(), Wn)
         assert torch.equal(short2, H2[s:s + 1000])
+
+
+@pytest.mark.parametrize("N", [100, 68, 132, 252])
+def test_gemm_guarded_last_column_tile(env, N):
+    """Widths off the 128 grid (the products-shaped F = 100) on the LDS-DMA kernel: the last column tile is guarded (B lanes past
+    column N do not load, C lanes past it do not store).  C is a column slice of a wider buffer filled with a sentinel: nothing
+    outside the N columns may change; every variant (plain NN / NT, fused mask + column sums, fused BN statistics) against the
+    same call on a short slice / the separate passes."""
+    ops, torch = env["ops"], env["torch"]
+    dev_ = env["dev"]
+    M, K = 70000 + 13, 128
+    A = ops.uniform_pm1(1200 + N, (M, K), device=dev_)
+    W = ops.uniform_pm1(1201 + N, (N, K), scale=K ** -0.5, device=dev_)
+    Wn = W.t().contiguous()
+    for transB, B in ((True, W), (False, Wn)):
+        Cw = torch.full((M, N + 60), 123.0, dtype=torch.float32, device=dev_)
+        Cv = Cw[:, 28:28 + N]
+        ops.gemm(A, B, transB=transB, out=Cv)
+        assert float((Cw[:, :28] - 123.0).abs().max()) == 0.0 and float((Cw[:, 28 + N:] - 123.0).abs().max()) == 0.0
+        ref = A[:3000].double() @ W.double().t()
+        assert (Cv[:3000].double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+        for s0 in (0, 255 * 100, M - 1000):
+            short = ops.gemm(A[s0:s0 + 1000].contiguous(), B, transB=transB)
+            assert torch.equal(short, Cv[s0:s0 + 1000])
+    # fused: mask + column sums (dH . W of a stacked layer) vs the separate passes
+    Y = torch.relu(ops.uniform_pm1(1202 + N, (M, N), device=dev_))
+    db = torch.empty(N, dtype=torch.float32, device=dev_)
+    Gf, _ = ops.gemm_relu_colsum(A, Wn, Y, colsum_out=db)
+    Gs = ops.gemm(A, Wn)
+    Gs, _, _ = ops.bn_relu_bwd(Y, Y, Gs, relu=True)
+    assert torch.equal(Gf, Gs)
+    ref_db = Gs.double().sum(0)
+    assert (db.double() - ref_db).abs().max().item() <= 1e-5 * max(1.0, Gs.double().abs().sum(0).max().item())
+    # fused BN statistics (opt-in) vs float64 statistics of the same H
+    H, mean, var = ops.linear_fwd_bn_stats(A, W)
+    assert torch.equal(H, ops.gemm(A, W, transB=True))
+    assert (mean.double() - H.double().mean(0)).abs().max().item() <= 1e-5
+    assert (var.double() - H.double().var(0, unbiased=False)).abs().max().item() <= 1e-5 * max(1.0, float(H.double().var(0).max()))
 
 
 def test_leading_dimensions_wider_than_the_matrices(env):
