@@ -347,9 +347,8 @@ class SingleGpu:
             if not hasattr(self, "Hb"):
                 self.Hb = torch.empty(self.H.shape, dtype=torch.bfloat16, device=self.H.device)
                 self.Gb = torch.empty(self.G.shape, dtype=torch.bfloat16, device=self.G.device)
-                self.names = ["gemm_xwT", "to_bf16_H", "spmm_fwd", "colsum", "to_bf16_G", "spmm_bwd", "gemm_dX", "gemm_dW"]
-            run(lambda: ops.linear_fwd(self.X, self.W, out=self.H))
-            run(lambda: ops.to_bf16(self.H, out=self.Hb))
+                self.names = ["gemm_xwT_bf16out", "spmm_fwd", "colsum", "to_bf16_G", "spmm_bwd", "gemm_dX", "gemm_dW"]
+            run(lambda: ops.linear_fwd_bf16(self.X, self.W, out=self.Hb))   # the product's epilogue stores bf16 H
             run(lambda: ops.aggregate_fwd(g, self.Hb, self.bias, out=self.out))
             run(lambda: ops.colsum(self.G, out=self.dbias))
             run(lambda: ops.to_bf16(self.G, out=self.Gb))

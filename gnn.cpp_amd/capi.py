@@ -117,6 +117,8 @@ _SIGS = {
                                   _vp],
     "gnnx_bn_relu_bwd_apply_f32": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _vp, _i64, _vp,
                                    _i64, _vp, _sz, _vp],
+    "gnnx_gemm_nt_bf16out_workspace": [_i64, _i64, _i64, C.POINTER(_sz)],
+    "gnnx_gemm_nt_bf16out_f32": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _sz, _vp],
     "gnnx_softmax_ce_workspace": [_i64, C.POINTER(_sz)],
     "gnnx_softmax_ce_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _sz, _vp],
     "gnnx_softmax_ce_colsum_workspace": [_i64, _i32, C.POINTER(_sz)],

@@ -574,7 +574,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
                            (uint32_t)((q ^ (r16 & 3)) << 4);   // + 64 j
     // reader: lane L reads 16 B at byte L*16 of a piece = row L/16, 16-B column L%16 (stored at column ^ (row & 3))
     const uint32_t ep_rd = (uint32_t)((lane >> 4) * 256) + (uint32_t)(((lane & 15) ^ (lane >> 4)) << 4);
-    const uint32_t offc = (uint32_t)((wm * 64 + (lane >> 4)) * g.ldc + wn * 64 + 4 * (lane & 15)) * 4u;  // bytes: row L/16, col 4 (L%16)
+    constexpr int ES = FUSE == 3 ? 2 : 4;   // bytes per stored element (FUSE 3: C is bf16, ldc in bf16 elements)
+    const uint32_t offc = (uint32_t)((wm * 64 + (lane >> 4)) * g.ldc + wn * 64 + 4 * (lane & 15)) * (uint32_t)ES;  // bytes: row L/16, col 4 (L%16)
 
     gemm_f32x4acc acc[4][4];
     float a[2][4], b[2][4];
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
             continue;
         }
         const float alpha = g.alpha;
-        char *ctile = reinterpret_cast<char *>(g.C + mt * BM * g.ldc + n0);
+        char *ctile = reinterpret_cast<char *>(g.C) + (mt * BM * g.ldc + n0) * ES;
         const char *ytile = FUSE == 1 ? reinterpret_cast<const char *>(fu.ymask + mt * BM * fu.ldy + n0) : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
 #pragma unroll
             for (int p = 0; p < 4; p++) asm volatile("ds_read_b128 %0, %1" : "=v"(o[p]) : "v"(ep_rd + ep[p]) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])::"memory");
-            char *crow = ctile + (int64_t)(16 * i) * g.ldc * 4;   // wave-uniform
+            char *crow = ctile + (int64_t)(16 * i) * g.ldc * ES;   // wave-uniform
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 if constexpr (FUSE == 1) {
@@ -655,11 +656,20 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
                     csum += d;
                     csq += d * d;
                 }
-                if (okc) *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * 4 + offc) = o[p];
+                if constexpr (FUSE == 3) {   // round to nearest even, as gnnx_f32_to_bf16: 8 bytes per lane, 128-byte row segments
+                    union { __bf16 h[4]; uint2 u; } ob;
+                    ob.h[0] = (__bf16)o[p][0];
+                    ob.h[1] = (__bf16)o[p][1];
+                    ob.h[2] = (__bf16)o[p][2];
+                    ob.h[3] = (__bf16)o[p][3];
+                    if (okc) *reinterpret_cast<uint2 *>(crow + (int64_t)(4 * p) * g.ldc * ES + offc) = ob.u;
+                } else {
+                    if (okc) *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * ES + offc) = o[p];
+                }
             }
         }
     }
-    if constexpr (FUSE != 0) {
+    if constexpr (FUSE == 1 || FUSE == 2) {
         // column sums of the workgroup: lanes with equal (lane & 15) in the WM wavefronts of a column group wn hold the same 4
         // columns.  Everything is parked in LDS (the operand stages are dead: every DMA was waited for, the last K-tile
         // ended with a barrier) and added in a fixed order: wm 0..WM-1, lane group 0..3.
@@ -1070,7 +1080,12 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
     static std::atomic<uint64_t> done_plain{0}, done_fuse{0}, done_stats{0};
     static const int ablate = [] { const char *e = experiment_env("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
-    if (fuse && fuse_mode == 2) {
+    if (fuse_mode == 3) {
+        static std::atomic<uint64_t> done_bf16{0};
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 3, NG>, lds, done_bf16);
+        if (rc) return rc;
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 3, NG>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
+    } else if (fuse && fuse_mode == 2) {
         if (!aligned16(fuse->ymask)) return GNNX_OK;
         int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 2, NG>, lds, done_stats);
         if (rc) return rc;
@@ -1099,6 +1114,7 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const Gemm
     *rows_done = 0;
     if (!dma_shape_ok(g.M, g.N, g.K)) return GNNX_OK;
     if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return GNNX_OK;
+    if (fuse_mode == 3 && g.alpha != 1.0f) return GNNX_OK;
     if (g.N % 256 == 0) return launch_dma_geo<4, 4, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
     if (g.N % 128 == 0) return launch_dma_geo<4, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
     return launch_dma_geo<4, 2, true>(g, st, rows_done, fuse, partial_rows, fuse_mode);
@@ -1340,6 +1356,48 @@ GNNX_API int gnnx_gemm_bn_stats_f32(int64_t M, int64_t N, int64_t K, const float
     }
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((uint32_t)ceil_div(N, 256)), dim3(256), 0, st, partial, prow, N, M, shift, d_mean, d_var);
     GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+// ---- opt-in: H = X . W^T stored as bf16 (the feature storage of gnnx_spmm_csr_bf16_f32) straight from the product's epilogue ------
+GNNX_API int gnnx_gemm_nt_bf16out_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes)
+{
+    GNNX_REQUIRE(bytes && M >= 0 && N >= 0 && K >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    *bytes = sizeof(float) * ((size_t)K * N + (size_t)256 * N) + 64;   // W^T [K][N] + f32 rows of the ragged tail
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_gemm_nt_bf16out_f32(int64_t M, int64_t N, int64_t K, const float *d_X, int64_t ldx, const float *d_W, int64_t ldw,
+                                      uint16_t *d_H_bf16, int64_t ldh, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(M > 0 && N > 0 && K > 0 && N < (1ll << 31), GNNX_ERR_INVALID_ARG, "bad sizes");
+    GNNX_REQUIRE(d_X && d_W && d_H_bf16 && ldx >= K && ldw >= K && ldh >= N, GNNX_ERR_INVALID_ARG, "null pointer or ld");
+    GNNX_REQUIRE(dma_shape_ok(M, N, K) && ldx % 4 == 0 && ldh % 4 == 0 && aligned16(d_X) && aligned16(d_H_bf16),
+                 GNNX_ERR_SHAPE, "bf16-output product: needs K %% 64 == 0, N %% 4 == 0, N >= 64, M >= 2048, 16-byte aligned rows "
+                 "(use gnnx_gemm_f32 + gnnx_f32_to_bf16 for other shapes)");
+    size_t need = 0;
+    gnnx_gemm_nt_bf16out_workspace(M, N, K, &need);
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need && aligned16(d_workspace), GNNX_ERR_WORKSPACE, "workspace %zu < required %zu",
+                 workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    float *wt = static_cast<float *>(d_workspace);
+    float *tail = wt + (size_t)K * N;
+    hipLaunchKernelGGL(gemm_transpose_w_kernel, dim3((uint32_t)ceil_div(K, 32), (uint32_t)ceil_div(N, 32)), dim3(256), 0, st, d_W, ldw, N, K, wt, N);
+    GNNX_LAUNCH_CHECK();
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.A = d_X; g.lda = ldx; g.B = wt; g.ldb = N; g.C = reinterpret_cast<float *>(d_H_bf16); g.ldc = ldh;
+    g.alpha = 1.f; g.beta = 0.f; g.k_per_split = K;
+    int64_t rows = 0;
+    int rc = launch_dma(g, st, &rows, nullptr, nullptr, 3);
+    if (rc) return rc;
+    GNNX_REQUIRE(rows > 0, GNNX_ERR_SHAPE, "bf16-output product: shape not taken by the LDS-DMA kernel");
+    if (rows < M) {   // ragged tail (< 256 rows): f32 product, then the same rounding
+        const int64_t mr = M - rows;
+        rc = gnnx_gemm_f32(0, 0, mr, N, K, 1.f, d_X + rows * ldx, ldx, wt, N, 0.f, tail, N, nullptr, 0, stream);
+        if (rc) return rc;
+        rc = gnnx_f32_to_bf16(tail, N, mr, (int32_t)N, d_H_bf16 + rows * ldh, ldh, stream);
+        if (rc) return rc;
+    }
     return GNNX_OK;
 }
 

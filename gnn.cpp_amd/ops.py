@@ -126,6 +126,23 @@ def to_bf16(X, out=None):
     return out
 
 
+def linear_fwd_bf16(X, W, out=None):
+    """OPT-IN (bf16 feature storage): H = X . W^T as a torch.bfloat16 tensor.  gnnx_gemm_nt_bf16out_f32 (the product's epilogue
+    rounds and stores bf16) on the LDS-DMA kernel's shapes, else the product followed by to_bf16: the same bits either way."""
+    M, K = X.shape
+    N = W.shape[0]
+    out = torch.empty((M, N), dtype=torch.bfloat16, device=X.device) if out is None else out
+    ok = (K % 64 == 0 and N % 4 == 0 and N >= 64 and M >= 2048 and _ld(X) % 4 == 0 and _ld(out) % 4 == 0 and X.data_ptr() % 16 == 0
+          and out.data_ptr() % 16 == 0)
+    if not ok:
+        return to_bf16(gemm(X, W, transB=True), out=out)
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_gemm_nt_bf16out_workspace", M, N, K, C.byref(wsb))
+    ws = _workspace(wsb.value, X.device, "gemm_bf16out")
+    capi.call("gnnx_gemm_nt_bf16out_f32", M, N, K, _ptr(X), _ld(X), _ptr(W), _ld(W), _ptr(out), _ld(out), _ptr(ws), wsb.value, _stream())
+    return out
+
+
 DIAG_KEEP, DIAG_STRIP, DIAG_FILL = 0, 1, 2
 CSR_KEEP_DUPLICATES, CSR_DROP_TRUNCATED_ZERO = 2, 4
 

@@ -198,6 +198,13 @@ int gnnx_spmm_csr_bf16_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const
                            const float *d_vals, const float *d_colscale, const float *d_rowscale, const float *d_bias,
                            const uint16_t *d_X_bf16, int64_t ldx, float beta, float *d_Y, int64_t ldy,
                            const gnnx_spmm_plan *plan, void *stream);
+/* H = X . W^T (X [M,K], W [N,K]: the layer's transform, nn.cpp:205-211) written as bf16 by the product's own epilogue -- the same
+ * round-to-nearest-even as gnnx_f32_to_bf16, so the result equals gnnx_gemm_f32 followed by gnnx_f32_to_bf16 bit for bit, without
+ * the 4 M N-byte f32 round trip.  LDS-DMA kernel shapes only (K % 64 == 0, N % 4 == 0, N >= 64, M >= 2048, 16-byte aligned rows):
+ * GNNX_ERR_SHAPE otherwise.  ldh in bf16 elements. */
+int gnnx_gemm_nt_bf16out_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes);
+int gnnx_gemm_nt_bf16out_f32(int64_t M, int64_t N, int64_t K, const float *d_X, int64_t ldx, const float *d_W, int64_t ldw,
+                             uint16_t *d_H_bf16, int64_t ldh, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ hot path: transform ---------- */
 /*

@@ -1162,6 +1162,27 @@ def test_gemm_guarded_last_column_tile(env, N):
     assert (var.double() - H.double().var(0, unbiased=False)).abs().max().item() <= 1e-5 * max(1.0, float(H.double().var(0).max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(300077, 256, 256), (70013, 100, 128), (5000, 128, 64), (2048, 64, 64), (1000, 50, 30)])
+def test_transform_with_bf16_output_epilogue(env, M, N, K):
+    """Opt-in bf16 feature storage: X . W^T stored as bf16 by the product's epilogue (gnnx_gemm_nt_bf16out_f32) equals the f32
+    product followed by gnnx_f32_to_bf16 bit for bit (same fmaf chain, same round-to-nearest-even) -- whole tiles, the ragged
+    tail, a guarded last column tile and (last case) the two-step fallback of a shape the kernel does not take; the output is a
+    column slice of a wider bf16 buffer: nothing outside it changes."""
+    ops, torch = env["ops"], env["torch"]
+    X = ops.uniform_pm1(1300, (M, K), device=env["dev"])
+    W = ops.uniform_pm1(1301, (N, K), scale=K ** -0.5, device=env["dev"])
+    ref = ops.to_bf16(ops.gemm(X, W, transB=True))
+    wide = torch.full((M, N + 24), 3.0, dtype=torch.bfloat16, device=env["dev"])
+    out = ops.linear_fwd_bf16(X, W, out=wide[:, 8:8 + N])
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    assert bool((wide[:, :8] == 3.0).all()) and bool((wide[:, 8 + N:] == 3.0).all())
+    if M >= 2048 and K % 64 == 0 and N % 4 == 0 and N >= 64:   # the C-ABI entry refuses other shapes loudly
+        with pytest.raises(env["capi"].GnnxError):
+            import ctypes as C
+            capi = env["capi"]
+            capi.call("gnnx_gemm_nt_bf16out_f32", 100, N, K, ops._ptr(X), K, ops._ptr(W), K, ops._ptr(out), N + 24, None, 0, ops._stream())
+
+
 def test_leading_dimensions_wider_than_the_matrices(env):
     """Every hot entry point takes leading dimensions: operands that are column slices of wider buffers (ld > width) must give
     the same bits as packed copies -- streaming GEMM + its ragged tail, fused / bf16 / plain SpMM."""
