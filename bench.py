@@ -323,7 +323,7 @@ class SingleGpu:
         self.H, self.out, self.dH, self.dX, self.dW = (self.Hp[:, :F], self.outp[:, :F], self.dHp[:, :F], self.dXp[:, :F],
                                                         self.dWp[:F, :F])
         self.dbias = torch.empty(F, dtype=torch.float32, device=dev)
-        self.names = ["gemm_xwT", "spmm_fwd", "colsum", "spmm_bwd", "gemm_dX", "gemm_dW"]
+        self.names = ["colsum", "spmm_bwd", "gemm_dX", "gemm_dW", "gemm_xwT", "spmm_fwd"]   # launch order of step()
         self.ev = []  # per timed step: list of (start, stop) HIP events on the launch stream
 
     def step(self, timed=False):
@@ -347,24 +347,29 @@ class SingleGpu:
             if not hasattr(self, "Hb"):
                 self.Hb = torch.empty(self.H.shape, dtype=torch.bfloat16, device=self.H.device)
                 self.Gb = torch.empty(self.G.shape, dtype=torch.bfloat16, device=self.G.device)
-                self.names = ["gemm_xwT_bf16out", "spmm_fwd", "colsum", "to_bf16_G", "spmm_bwd", "gemm_dX", "gemm_dW"]
-            run(lambda: ops.linear_fwd_bf16(self.X, self.W, out=self.Hb))   # the product's epilogue stores bf16 H
-            run(lambda: ops.aggregate_fwd(g, self.Hb, self.bias, out=self.out))
+                self.names = ["colsum", "to_bf16_G", "spmm_bwd", "gemm_dX", "gemm_dW", "gemm_xwT_bf16out", "spmm_fwd"]
             run(lambda: ops.colsum(self.G, out=self.dbias))
             run(lambda: ops.to_bf16(self.G, out=self.Gb))
             run(lambda: ops.aggregate_bwd(g, self.Gb, out=self.dH))
             run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
             run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+            run(lambda: ops.linear_fwd_bf16(self.X, self.W, out=self.Hb))   # the product's epilogue stores bf16 H
+            run(lambda: ops.aggregate_fwd(g, self.Hb, self.bias, out=self.out))
             if timed:
                 self.ev.append(evs)
             return
         split = getattr(self, "split_gemm", False)
-        run(lambda: ops.gemm_split(self.X, self.W, transB=True, out=self.H) if split else ops.linear_fwd(self.Xp, self.Wp[:self.F], out=self.H))
-        run(lambda: ops.aggregate_fwd_sym(g, self.H, self.bias, out=self.out) if sym else ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
+        # X and the upstream gradient G are both inputs of the layer step, so its two chains (G -> aggregate^T -> dH.W, dH^T.X and
+        # X.W^T -> aggregate) may run in either order.  The backward chain goes first so that the three dense products are
+        # consecutive: measured (scripts/exp_gemm_in_step.py), the f32 MFMA product takes 9.4 ms behind another product but 10.6 ms
+        # behind an aggregation and 11.6 ms after 50 ms of idle -- the core clock has to come back up after a memory-bound
+        # kernel -- so one such transition per step instead of two.
         run(lambda: ops.colsum(self.G, out=self.dbias))
         run(lambda: ops.aggregate_bwd_sym(g, self.G, out=self.dH) if sym else ops.aggregate_bwd(g, self.G, out=self.dH))
         run(lambda: ops.gemm_split(self.dH, self.W, transB=False, out=self.dX) if split else ops.gemm(self.dHp, self.Wp, out=self.dXp))
         run(lambda: ops.gemm(self.dHp, self.Xp, transA=True, out=self.dWp))
+        run(lambda: ops.gemm_split(self.X, self.W, transB=True, out=self.H) if split else ops.linear_fwd(self.Xp, self.Wp[:self.F], out=self.H))
+        run(lambda: ops.aggregate_fwd_sym(g, self.H, self.bias, out=self.out) if sym else ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
         if timed:
             self.ev.append(evs)
 
@@ -385,7 +390,8 @@ class SingleGpu:
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                 "traffic_source": tr[1] if tr else None,
                 "algorithmic_bytes_per_launch": B, "bytes_per_edge": B / max(1, self.g.nnz), "avg_launch_ms": ms,
-                "median_launch_ms": float(np.median([st[1][0].elapsed_ms(st[1][1]) for st in self.ev])) if self.ev else None,
+                "median_launch_ms": float(np.median([st[self.names.index("spmm_fwd")][0].elapsed_ms(st[self.names.index("spmm_fwd")][1])
+                                                     for st in self.ev])) if self.ev else None,
                 # the cache-perfect lower bound (every feature row read once) beside the gather figure
                 "cache_perfect_bytes": 4 * (self.n + 1) + 4 * self.g.nnz + 4 * self.n + 8 * self.F * self.n,
                 "frac_of_measured_copy_ceiling_6290": achieved / 6290.0}
