@@ -174,6 +174,132 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *X, int64_t ldx
     }
 }
 
+// ---- 16 bytes per lane forms of the two backward passes (widths that are multiples of 4 up to 1024) ---------------------------
+// Thread -> (row slot rr, quad of columns cq); the column constants (mean, 1/sigma, sigma, gamma, beta and, for the apply pass, the
+// scaled sums) live in registers, four rows per thread are in flight.  The element arithmetic is the scalar kernels' (the ReLU
+// decision without a stored forward output redoes the forward's sub / div / mul / add on x, each separately rounded); only the
+// ORDER of the column sums differs (rows of a slot in order, slots in order, blocks in order: fixed, deterministic).
+struct BnBwdVecArgs {
+    const float *X, *Y, *dY, *mean, *var, *gamma, *beta;
+    int64_t ldx, ldy, ldd, n_rows, rows_per_block;
+    int32_t n_feat;
+    int relu, quirk;
+    float eps, inv_n;
+    float *partial0, *partial1;        // MODE 0: [blocks][n_feat] sums of g and of g * xhat
+    const float *dbeta, *dgamma;       // MODE 1
+    float *dX;
+    int64_t ldo;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_vec_kernel(BnBwdVecArgs p)
+{
+    __shared__ float red[MODE == 0 ? 2 * 256 * 4 : 1];
+    const int q = p.n_feat >> 2, rpp = 256 / q;
+    const int cq = threadIdx.x % q, rr = threadIdx.x / q;
+    const bool live = rr < rpp;
+    const int32_t f = 4 * cq;
+    float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f}, sd[4] = {1.f, 1.f, 1.f, 1.f}, gm[4] = {1.f, 1.f, 1.f, 1.f},
+          bt[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool stats = p.mean != nullptr;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (stats) {
+            mean[c] = p.mean[f + c];
+            sd[c] = sqrtf(__fadd_rn(p.var[f + c], p.eps));      // (var + eps)->pow(0.5), the forward's divisor
+            rstd[c] = 1.0f / sqrtf(p.var[f + c] + p.eps);
+            if (p.gamma) gm[c] = p.gamma[f + c];
+            if (p.beta) bt[c] = p.beta[f + c];
+            if (MODE == 1 && !p.quirk) {
+                db[c] = p.dbeta[f + c] * p.inv_n;
+                dg[c] = p.dgamma[f + c];
+            }
+        }
+    }
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+    const int64_t r1 = r0 + p.rows_per_block < p.n_rows ? r0 + p.rows_per_block : p.n_rows;
+    if (live) {
+        for (int64_t rb = r0 + rr; rb < r1; rb += 4 * (int64_t)rpp) {
+            float4 x[4], g[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t r = rb + u * (int64_t)rpp;
+                if (r < r1) {
+                    x[u] = *reinterpret_cast<const float4 *>(p.X + r * p.ldx + f);
+                    g[u] = *reinterpret_cast<const float4 *>(p.dY + r * p.ldd + f);
+                    if (p.relu && p.Y) y[u] = *reinterpret_cast<const float4 *>(p.Y + r * p.ldy + f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t r = rb + u * (int64_t)rpp;
+                if (r >= r1) break;
+                const float xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                float gs[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+                const float ys[4] = {y[u].x, y[u].y, y[u].z, y[u].w};
+                float o[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    if (p.relu) {
+                        bool pass;
+                        if (p.Y) pass = ys[c] > 0.f;
+                        else {
+                            float v = xs[c];
+                            if (stats) {
+                                v = __fdiv_rn(__fsub_rn(v, mean[c]), sd[c]);
+                                if (p.gamma) v = __fmul_rn(v, gm[c]);
+                                if (p.beta) v = __fadd_rn(v, bt[c]);
+                            }
+                            pass = v > 0.f;
+                        }
+                        if (!pass) gs[c] = 0.f;
+                    }
+                    if (MODE == 0) {
+                        const float xhat = (xs[c] - mean[c]) * rstd[c];
+                        a0[c] += gs[c];
+                        a1[c] += gs[c] * xhat;
+                    } else {
+                        float v = gs[c];
+                        if (stats && p.quirk) {
+                            if (p.gamma) v = __fmul_rn(v, gm[c]);
+                            v = __fdiv_rn(v, sd[c]);
+                        } else if (stats) {
+                            const float xhat = (xs[c] - mean[c]) * rstd[c];
+                            v = gm[c] * rstd[c] * (v - db[c] - xhat * dg[c] * p.inv_n);   // the scalar kernel's association
+                        }
+                        o[c] = v;
+                    }
+                }
+                if (MODE == 1) *reinterpret_cast<float4 *>(p.dX + r * p.ldo + f) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    if (MODE == 0) {
+        float4 *r0v = reinterpret_cast<float4 *>(red), *r1v = r0v + 256;
+        r0v[threadIdx.x] = make_float4(a0[0], a0[1], a0[2], a0[3]);
+        r1v[threadIdx.x] = make_float4(a1[0], a1[1], a1[2], a1[3]);
+        __syncthreads();
+        if (rr == 0) {
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+            for (int k = 0; k < rpp; k++) {
+                const float4 u0 = r0v[k * q + cq], u1 = r1v[k * q + cq];
+                s0.x += u0.x; s0.y += u0.y; s0.z += u0.z; s0.w += u0.w;
+                s1.x += u1.x; s1.y += u1.y; s1.z += u1.z; s1.w += u1.w;
+            }
+            *reinterpret_cast<float4 *>(p.partial0 + (int64_t)blockIdx.x * p.n_feat + f) = s0;
+            *reinterpret_cast<float4 *>(p.partial1 + (int64_t)blockIdx.x * p.n_feat + f) = s1;
+        }
+    }
+}
+
+inline bool bn_vec_ok(int32_t n_feat, const void *a, int64_t lda, const void *b, int64_t ldb, const void *c, int64_t ldc, const void *d,
+                      int64_t ldd)
+{
+    auto al = [](const void *ptr, int64_t ld) { return !ptr || ((reinterpret_cast<uintptr_t>(ptr) & 15u) == 0 && ld % 4 == 0); };
+    return n_feat % 4 == 0 && n_feat <= 1024 && al(a, lda) && al(b, ldb) && al(c, ldc) && al(d, ldd);
+}
+
 int pick_fw(int32_t n_feat)
 {
     int fw = 1;
@@ -201,6 +327,22 @@ int reduce(OP op, int64_t n_rows, int32_t n_feat, float scale, float *out0, floa
         hipLaunchKernelGGL(colreduce_stage2, g2, dim3(256), 0, st, p1, nb, n_feat, scale, out1);
         GNNX_LAUNCH_CHECK();
     }
+    return GNNX_OK;
+}
+
+int launch_bn_apply_vec(const float *d_X, int64_t ldx, const float *d_Y, int64_t ldy, const float *d_dY, int64_t ldd, int64_t n_rows,
+                        int32_t n_feat, const float *d_mean, const float *d_var, float eps, const float *d_gamma, const float *d_beta, int relu,
+                        const float *d_dgamma, const float *d_dbeta, float inv_n, int quirk, float *d_dX, int64_t ldo, hipStream_t st)
+{
+    const int rows_pass = 4 * (256 / (n_feat / 4));   // rows one workgroup has in flight
+    int64_t nb = ceil_div(n_rows, (int64_t)rows_pass);
+    if (nb > 8192) nb = 8192;
+    BnBwdVecArgs p{};
+    p.X = d_X; p.Y = d_Y; p.dY = d_dY; p.mean = d_mean; p.var = d_var; p.gamma = d_gamma; p.beta = d_beta;
+    p.ldx = ldx; p.ldy = ldy; p.ldd = ldd; p.n_rows = n_rows; p.rows_per_block = ceil_div(n_rows, nb); p.n_feat = n_feat;
+    p.relu = relu; p.quirk = quirk; p.eps = eps; p.inv_n = inv_n; p.dbeta = d_dbeta; p.dgamma = d_dgamma; p.dX = d_dX; p.ldo = ldo;
+    hipLaunchKernelGGL(bn_bwd_vec_kernel<1>, dim3((uint32_t)nb), dim3(256), 0, st, p);
+    GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }
 
@@ -291,6 +433,21 @@ GNNX_API int gnnx_bn_relu_bwd_sums_f32(const float *d_X, int64_t ldx, const floa
     hipStream_t st = as_stream(stream);
     float *ws = static_cast<float *>(d_workspace);
     float *rstd = ws + (size_t)2 * n_blocks_for(n_rows) * n_feat;
+    if (bn_vec_ok(n_feat, d_X, ldx, d_Y, ldy, d_dY, ldd, ws, 4)) {
+        const int nb = n_blocks_for(n_rows);
+        BnBwdVecArgs p{};
+        p.X = d_X; p.Y = d_Y; p.dY = d_dY; p.mean = d_mean; p.var = d_var; p.gamma = d_gamma; p.beta = d_beta;
+        p.ldx = ldx; p.ldy = ldy; p.ldd = ldd; p.n_rows = n_rows; p.rows_per_block = ceil_div(n_rows, nb); p.n_feat = n_feat;
+        p.relu = relu; p.eps = eps; p.partial0 = ws; p.partial1 = ws + (size_t)nb * n_feat;
+        hipLaunchKernelGGL(bn_bwd_vec_kernel<0>, dim3(nb), dim3(256), 0, st, p);
+        GNNX_LAUNCH_CHECK();
+        dim3 g2((uint32_t)ceil_div(n_feat, 64));
+        hipLaunchKernelGGL(colreduce_stage2, g2, dim3(256), 0, st, p.partial0, nb, n_feat, 1.0f, d_dbeta);
+        GNNX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colreduce_stage2, g2, dim3(256), 0, st, p.partial1, nb, n_feat, 1.0f, d_dgamma);
+        GNNX_LAUNCH_CHECK();
+        return GNNX_OK;
+    }
     hipLaunchKernelGGL(rstd_kernel, dim3((uint32_t)ceil_div(n_feat, 256)), dim3(256), 0, st, d_var, eps, n_feat, rstd);
     GNNX_LAUNCH_CHECK();
     return reduce(OpBnBwd{d_X, d_Y, d_dY, d_mean, rstd, ldx, ldy, ldd, relu, d_var, d_gamma, d_beta, eps}, n_rows, n_feat, 1.0f, d_dbeta,
@@ -307,6 +464,8 @@ GNNX_API int gnnx_bn_relu_bwd_apply_f32(const float *d_X, int64_t ldx, const flo
     GNNX_REQUIRE(d_dX && ldo >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld");
     GNNX_REQUIRE(!d_mean || (d_dgamma && d_dbeta && n_total >= n_rows), GNNX_ERR_INVALID_ARG, "dgamma / dbeta sums and n_total are required");
     hipStream_t st = as_stream(stream);
+    if (bn_vec_ok(n_feat, d_X, ldx, d_Y, ldy, d_dY, ldd, d_dX, ldo)) return launch_bn_apply_vec(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat,
+            d_mean, d_var, eps, d_gamma, d_beta, relu, d_dgamma, d_dbeta, d_mean ? 1.0f / (float)n_total : 0.f, 0, d_dX, ldo, st);
     int64_t blocks = ceil_div(n_rows * n_feat, 256);
     if (blocks > 4096) blocks = 4096;
     const float *rstd = nullptr;
@@ -338,6 +497,9 @@ GNNX_API int gnnx_bn_relu_bwd_quirk_f32(const float *d_X, int64_t ldx, const flo
     rc = bn_bwd_check(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, d_var, d_workspace, workspace_bytes);
     if (rc) return rc;
     GNNX_REQUIRE(d_dX && ldo >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld");
+    if (bn_vec_ok(n_feat, d_X, ldx, d_Y, ldy, d_dY, ldd, d_dX, ldo))
+        return launch_bn_apply_vec(d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat, d_mean, d_var, eps, d_gamma, d_beta, relu, d_dgamma, d_dbeta,
+                                   0.f, 1, d_dX, ldo, as_stream(stream));
     int64_t blocks = ceil_div(n_rows * n_feat, 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bn_bwd_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, d_Y, ldy, d_dY, ldd, n_rows, n_feat,

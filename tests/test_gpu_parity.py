@@ -668,6 +668,51 @@ def test_batchnorm_relu_backward_vs_float64(env, n, F, relu, bn):
         assert np.array_equal(host(dX), g.astype(np.float32))
 
 
+@pytest.mark.parametrize("n,F", [(50001, 256), (7000, 100), (4099, 1024), (3000, 8)])
+def test_batchnorm_backward_vector_kernels_equal_the_scalar_ones(env, n, F):
+    """The 16-bytes-per-lane forms of the two backward passes (taken for 16-byte aligned operands, F % 4 == 0) against the scalar
+    kernels (forced by an odd leading dimension): dX bit for bit -- the element arithmetic is the same, given the same sums --
+    dgamma / dbeta to the rounding of a different (fixed) summation order; with and without the stored forward output, and the
+    mask-only and the reference-quirk forms."""
+    ops, torch = env["ops"], env["torch"]
+    dev_ = env["dev"]
+    X = ops.uniform_pm1(1400, (n, F), device=dev_) * 2.0 + 0.3
+    dY = ops.uniform_pm1(1401, (n, F), device=dev_)
+    gamma = ops.uniform_pm1(1402, (F,), device=dev_) + 1.5
+    beta = ops.uniform_pm1(1403, (F,), scale=0.3, device=dev_)
+    odd = lambda t: torch.cat([t, torch.zeros((t.shape[0], 1), dtype=t.dtype, device=dev_)], 1)[:, :F]   # ld = F + 1: scalar kernels
+    mean, var = ops.bn_stats(X)
+    Y = ops.bn_relu_fwd(X, mean, var, gamma, beta, relu=True)
+    for Yv in (Y, None):
+        for quirk in (False, True):
+            a = ops.bn_relu_bwd(X, Yv, dY, mean, var, gamma, relu=True, beta=beta, reference_quirk=quirk)
+            b = ops.bn_relu_bwd(odd(X), None if Yv is None else odd(Yv), odd(dY), mean, var, gamma, relu=True, beta=beta, reference_quirk=quirk)
+            g64 = (dY.double() * (Y > 0)).abs().sum(0)
+            for k in (1, 2):   # dgamma, dbeta
+                assert float((a[k].double() - b[k].double()).abs().max()) <= 1e-5 * max(1.0, float(g64.max()) * 4.0)
+            if quirk:
+                assert torch.equal(a[0], b[0])   # no sums in the element formula
+            else:           # same element formula on sums that differ by rounding
+                torch.testing.assert_close(a[0], b[0], rtol=1e-4, atol=1e-5 * max(1.0, float(b[0].abs().max())))
+    # given the SAME sums the apply pass is bit-identical: the sharded halves take the sums as inputs
+    shard_sums = ops.bn_relu_bwd(odd(X), None, odd(dY), mean, var, gamma, relu=True, beta=beta)
+    import ctypes as C
+    capi = env["capi"]
+    outs = []
+    for Xv, dYv in ((X, dY), (odd(X), odd(dY))):
+        dX = torch.empty((n, F), dtype=torch.float32, device=dev_)
+        wsb = C.c_size_t(0)
+        capi.call("gnnx_bn_workspace", n, F, C.byref(wsb))
+        ws = torch.empty(wsb.value, dtype=torch.uint8, device=dev_)
+        capi.call("gnnx_bn_relu_bwd_apply_f32", ops._ptr(Xv), Xv.stride(0), None, 0, ops._ptr(dYv), dYv.stride(0), n, F, ops._ptr(mean),
+                  ops._ptr(var), 1e-5, ops._ptr(gamma), ops._ptr(beta), 1, ops._ptr(shard_sums[1]), ops._ptr(shard_sums[2]), n, ops._ptr(dX), F,
+                  ops._ptr(ws), wsb.value, ops._stream())
+        outs.append(dX)
+    assert torch.equal(outs[0], outs[1])
+    # mask only (the ReLU between stacked layers)
+    assert torch.equal(ops.bn_relu_bwd(Y, Y, dY, relu=True)[0], ops.bn_relu_bwd(odd(Y), odd(Y), odd(dY), relu=True)[0])
+
+
 def test_native_rccl_comm_single_rank(env):
     """gnnx_comm_* / gnnx_halo_exchange_f32 / gnnx_allreduce_sum_f32 on a one-rank communicator (all this box has):
     the self-exchange must copy the packed rows into the halo tail and the all-reduce must be the identity."""
