@@ -212,17 +212,48 @@ __global__ __launch_bounds__(256) void binary_bcast_kernel(const float *A, int64
     }
 }
 
+// The same, 4 columns (16 bytes) per thread: every operand is either column-contiguous (col stride 1, rows and base 16-byte
+// aligned) or column-broadcast (col stride 0: one value per row, or one value in all).  Same single rounding per element.
+template <int OP>
+__global__ __launch_bounds__(256) void binary_bcast_vec_kernel(const float *A, int64_t ars, int acs, const float *B, int64_t brs, int bcs,
+                                                                int64_t n_rows, int32_t quads, float *Y, int64_t ldy)
+{
+    const int64_t total = n_rows * quads;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / quads;
+        const int32_t c = 4 * (int32_t)(i - r * quads);
+        float4 a, b, y;
+        if (acs) a = *reinterpret_cast<const float4 *>(A + r * ars + c);
+        else { const float t = A[r * ars]; a = make_float4(t, t, t, t); }
+        if (bcs) b = *reinterpret_cast<const float4 *>(B + r * brs + c);
+        else { const float t = B[r * brs]; b = make_float4(t, t, t, t); }
+#define GNNX_B1(u) y.u = OP == 0 ? __fadd_rn(a.u, b.u) : OP == 1 ? __fsub_rn(a.u, b.u) : OP == 2 ? __fmul_rn(a.u, b.u) : __fdiv_rn(a.u, b.u)
+        GNNX_B1(x); GNNX_B1(y); GNNX_B1(z); GNNX_B1(w);
+#undef GNNX_B1
+        *reinterpret_cast<float4 *>(Y + r * ldy + c) = y;
+    }
+}
+
 // out[r] = sum_c X[r][c], ascending c (functional::sum walks UP, reference functional.h:267-296); one wavefront per row
+template <bool VEC>
 __global__ __launch_bounds__(256) void rowsum_kernel(const float *X, int64_t ldx, int64_t n_rows, int32_t n_cols, float *out)
 {
     int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= n_rows) return;
     // lane l owns the contiguous slice [l*w, (l+1)*w): partial sums combine left to right, so a row of <= 64 columns
-    // is summed in exactly the reference's order
+    // is summed in exactly the reference's order.  VEC (w % 4 == 0, 16-byte aligned rows): the slice is read 16 bytes at a time
+    // and added in the same ascending order.
     const int32_t w = (n_cols + 63) / 64;
     float acc = 0.f;
-    for (int32_t c = lane * w; c < (lane + 1) * w && c < n_cols; c++) acc = __fadd_rn(acc, X[r * ldx + c]);
+    if (VEC) {
+        for (int32_t c = lane * w; c < (lane + 1) * w && c < n_cols; c += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(X + r * ldx + c);
+            acc = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc, v.x), v.y), v.z), v.w);
+        }
+    } else {
+        for (int32_t c = lane * w; c < (lane + 1) * w && c < n_cols; c++) acc = __fadd_rn(acc, X[r * ldx + c]);
+    }
     __shared__ float part[4][64];
     part[threadIdx.x >> 6][lane] = acc;
     __syncthreads();
@@ -369,6 +400,8 @@ GNNX_API int gnnx_rowscale_f32(const float *d_X, int64_t ldx, const float *d_v, 
     GNNX_REQUIRE(n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
     if (n_rows == 0 || n_feat == 0) return GNNX_OK;
     GNNX_REQUIRE(d_X && d_v && d_Y && ldx >= n_feat && ldy >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    if (n_feat > 1)   // Y = X * v[row]: the broadcast kernel (16 bytes per thread when the rows allow it)
+        return gnnx_binary_bcast_f32(GNNX_OP_MUL, n_rows, n_feat, d_X, ldx, 1, d_v, 1, 0, d_Y, ldy, stream);
     int64_t blocks = ceil_div(n_rows * n_feat, 256);
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     hipLaunchKernelGGL(rowwise_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, d_v, n_rows,
@@ -383,6 +416,8 @@ GNNX_API int gnnx_bias_add_f32(const float *d_X, int64_t ldx, const float *d_b, 
     GNNX_REQUIRE(n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
     if (n_rows == 0 || n_feat == 0) return GNNX_OK;
     GNNX_REQUIRE(d_X && d_b && d_Y && ldx >= n_feat && ldy >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    if (n_feat > 1 && n_rows > 1)   // Y = X + b[col]
+        return gnnx_binary_bcast_f32(GNNX_OP_ADD, n_rows, n_feat, d_X, ldx, 1, d_b, 0, 1, d_Y, ldy, stream);
     int64_t blocks = ceil_div(n_rows * n_feat, 256);
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     hipLaunchKernelGGL(rowwise_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_X, ldx, d_b, n_rows,
@@ -401,10 +436,31 @@ GNNX_API int gnnx_binary_bcast_f32(int op, int64_t n_rows, int64_t n_cols, const
     GNNX_REQUIRE(d_A && d_B && d_Y && ldy >= n_cols, GNNX_ERR_INVALID_ARG, "null pointer or ldy < n_cols");
     GNNX_REQUIRE(a_row_stride >= 0 && a_col_stride >= 0 && b_row_stride >= 0 && b_col_stride >= 0, GNNX_ERR_INVALID_ARG,
                  "negative stride");
+    hipStream_t st = as_stream(stream);
+    auto vec_operand = [](const float *ptr, int64_t rs, int64_t cs) {   // column-contiguous and 16-byte aligned rows, or column-broadcast
+        return cs == 0 || (cs == 1 && rs % 4 == 0 && (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0);
+    };
+    if (n_cols % 4 == 0 && ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(d_Y) & 15u) == 0 && vec_operand(d_A, a_row_stride, a_col_stride) &&
+        vec_operand(d_B, b_row_stride, b_col_stride)) {
+        const int32_t quads = (int32_t)(n_cols / 4);
+        int64_t vb = ceil_div(n_rows * quads, 256);
+        if (vb > 16384) vb = 16384;
+        dim3 vg((uint32_t)vb), vt(256);
+#define GNNX_BINV(OPV) hipLaunchKernelGGL(binary_bcast_vec_kernel<OPV>, vg, vt, 0, st, d_A, a_row_stride, (int)a_col_stride, d_B, \
+                                          b_row_stride, (int)b_col_stride, n_rows, quads, d_Y, ldy)
+        switch (op) {
+        case GNNX_OP_ADD: GNNX_BINV(0); break;
+        case GNNX_OP_SUB: GNNX_BINV(1); break;
+        case GNNX_OP_MUL: GNNX_BINV(2); break;
+        default: GNNX_BINV(3); break;
+        }
+#undef GNNX_BINV
+        GNNX_LAUNCH_CHECK();
+        return GNNX_OK;
+    }
     int64_t blocks = ceil_div(n_rows * n_cols, 256);
     if (blocks > 8192) blocks = 8192;
     dim3 g((uint32_t)blocks), b(256);
-    hipStream_t st = as_stream(stream);
 #define GNNX_BIN(OPV) hipLaunchKernelGGL(binary_bcast_kernel<OPV>, g, b, 0, st, d_A, a_row_stride, a_col_stride, d_B, b_row_stride, \
                                          b_col_stride, n_rows, n_cols, d_Y, ldy)
     switch (op) {
@@ -423,8 +479,9 @@ GNNX_API int gnnx_rowsum_f32(const float *d_X, int64_t ldx, int64_t n_rows, int3
     GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0, GNNX_ERR_INVALID_ARG, "negative size");
     if (n_rows == 0) return GNNX_OK;
     GNNX_REQUIRE(d_X && d_out && ldx >= n_cols, GNNX_ERR_INVALID_ARG, "null pointer or ldx < n_cols");
-    hipLaunchKernelGGL(rowsum_kernel, dim3((uint32_t)ceil_div(n_rows, 4)), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_cols,
-                       d_out);
+    const bool vec = ((n_cols + 63) / 64) % 4 == 0 && n_cols % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(d_X) & 15u) == 0;
+    if (vec) hipLaunchKernelGGL(rowsum_kernel<true>, dim3((uint32_t)ceil_div(n_rows, 4)), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_cols, d_out);
+    else hipLaunchKernelGGL(rowsum_kernel<false>, dim3((uint32_t)ceil_div(n_rows, 4)), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_cols, d_out);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }

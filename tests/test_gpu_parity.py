@@ -713,6 +713,41 @@ def test_batchnorm_backward_vector_kernels_equal_the_scalar_ones(env, n, F):
     assert torch.equal(ops.bn_relu_bwd(Y, Y, dY, relu=True)[0], ops.bn_relu_bwd(odd(Y), odd(Y), odd(dY), relu=True)[0])
 
 
+@pytest.mark.parametrize("n,F", [(40003, 256), (9000, 100), (513, 1024), (3000, 8)])
+def test_streaming_elementwise_vector_kernels_equal_the_scalar_ones(env, n, F):
+    """The 16-bytes-per-thread forms of the broadcast binary ops (rowscale / bias-add are two of them), the row sum and the
+    BatchNorm forward apply, against the scalar kernels (forced by an odd leading dimension or a misaligned base): bit for bit."""
+    ops, torch = env["ops"], env["torch"]
+    dev_ = env["dev"]
+    X = ops.uniform_pm1(1500, (n, F), device=dev_) * 3.0
+    Y = ops.uniform_pm1(1501, (n, F), device=dev_) + 2.0
+    v = ops.uniform_pm1(1502, (n,), device=dev_) + 1.5
+    b = ops.uniform_pm1(1503, (F,), device=dev_) + 1.5
+    wide = torch.zeros((n, F + 1), dtype=torch.float32, device=dev_)
+    wide[:, :F] = X
+    Xo = wide[:, :F]                                    # ld = F + 1: scalar kernels
+    assert torch.equal(ops.rowscale(X, v), ops.rowscale(Xo, v))
+    assert torch.equal(ops.bias_add(X, b), ops.bias_add(Xo, b))
+    assert torch.equal(ops.rowsum(X), ops.rowsum(Xo))
+    # the broadcast op on [N,F] (op) {[N,F], [N,1], [F], scalar}: vector form vs the scalar form on a base shifted by 4 bytes
+    flat = torch.zeros(n * F + 1, dtype=torch.float32, device=dev_)
+    flat[1:] = X.reshape(-1)
+    Xm = flat[1:].view(n, F)                            # contiguous but not 16-byte aligned: scalar kernel
+    one = torch.full((1,), 1.25, dtype=torch.float32, device=dev_)
+    for op in ("add", "sub", "mul", "div"):
+        for other in (Y, v.reshape(n, 1).contiguous(), b, one):
+            assert torch.equal(ops.binary(op, X, other), ops.binary(op, Xm, other)), (op, tuple(other.shape))
+            assert torch.equal(ops.binary(op, other, X), ops.binary(op, other, Xm)), (op, tuple(other.shape), "swapped")
+    ref = X.double() * v.double()[:, None]
+    assert float((ops.rowscale(X, v).double() - ref).abs().max()) <= 1e-6 * float(ref.abs().max())
+    mean, var = ops.bn_stats(X)
+    for kw in (dict(), dict(gamma=b), dict(gamma=b, beta=v[:F].contiguous() if n >= F else b)):
+        a1 = ops.bn_relu_fwd(X, mean, var, relu=True, **kw)
+        a2 = ops.bn_relu_fwd(Xo, mean, var, relu=True, **kw)
+        assert torch.equal(a1, a2)
+    assert torch.equal(ops.bn_relu_fwd(X, relu=True), ops.bn_relu_fwd(Xo, relu=True))
+
+
 def test_native_rccl_comm_single_rank(env):
     """gnnx_comm_* / gnnx_halo_exchange_f32 / gnnx_allreduce_sum_f32 on a one-rank communicator (all this box has):
     the self-exchange must copy the packed rows into the halo tail and the all-reduce must be the identity."""
