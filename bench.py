@@ -90,6 +90,12 @@ def main():
     ap.add_argument("--train-layers", type=int, default=0,
                     help="N=1 only: time a whole training step of an L-layer GCN instead (forward, softmax-CE, backward, SGD); "
                          "value counts L*nnz edges per step")
+    ap.add_argument("--vertex-order", default="auto", choices=["auto", "scrambled", "as-generated"],
+                    help="scrambled: the graph builder stores vertex v at row (v * 2654435761) mod n -- R-MAT puts its hubs on the ids "
+                         "with few one-bits, and with a power-of-two row stride their feature rows alias to the same cache sets; every "
+                         "vertex's result has the same bits, at another row.  as-generated: vertex v at row v (round 1).  auto (default): "
+                         "scrambled when a feature row is a multiple of 512 bytes (F = 256: aggregation 19 -> 13.7 ms; F = 128: -3 %%), "
+                         "as-generated otherwise (F = 100: 400-byte rows do not alias, the scramble costs 2 %%)")
     ap.add_argument("--no-pad-features", action="store_true",
                     help="store feature rows at their own width even when it is not a multiple of 128 floats (default: pad the stride)")
     ap.add_argument("--sym", action="store_true",
@@ -112,7 +118,7 @@ def main():
     ap.add_argument("--schedule", default="overlap", choices=["overlap", "sequential"],
                     help="N>1: overlap = both halo exchanges asynchronous, each chain's compute under the other's exchange (same "
                          "bits); sequential = GEMM -> exchange -> SpMM ... on one stream")
-    ap.add_argument("--partition", default="deal", choices=["deal", "contiguous"],
+    ap.add_argument("--partition", default="deal", choices=["deal", "deal-ascending", "contiguous"],
                     help="N>1: deal = degree-sorted snake deal (equal rows / non-zeros / per-link volume); contiguous = ranges of "
                          "original ids balanced on degree (round 1)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
@@ -168,12 +174,13 @@ def main():
     capi = importlib.import_module("gnncpp_amd.capi")
 
     n, e, F, abc, seed = WORKLOADS[args.workload]
+    relabel = "scramble" if args.vertex_order == "scrambled" or (args.vertex_order == "auto" and (4 * F) % 512 == 0) else None
     t_build0 = time.time()
     if world == 1 and not args.force_sharded and args.train_layers > 0:
-        runner = TrainStep(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk, args.train_layers)
+        runner = TrainStep(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk, args.train_layers, relabel=relabel)
         runner.workload = args.workload
     elif world == 1 and not args.force_sharded:
-        runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk, pad=not args.no_pad_features)
+        runner = SingleGpu(ops, capi, pkg, dev, n, e, F, abc, seed, args.chunk, pad=not args.no_pad_features, relabel=relabel)
         runner.workload = args.workload
         runner.sym = args.sym
         runner.bf16_features = args.bf16_features
@@ -253,6 +260,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": runner.nnz_total,
                        "features": F, "layer": f"{F}->{F}", "feature_row_stride": getattr(runner, "Fp", F),
+                       "vertex_order": getattr(runner, "vertex_order", "dealt by degree, spread inside every rank's range"),
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd of every parameter, SGD; no input gradient); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 and not args.force_sharded else
@@ -277,8 +285,9 @@ def main():
 class SingleGpu:
     """Whole graph on one MI355X.  All buffers are allocated here, outside the timed region."""
 
-    def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk, pad=True):
+    def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk, pad=True, relabel="scramble"):
         self.ops, self.capi, self.F, self.n = ops, capi, F, n
+        self.vertex_order = "scrambled" if relabel else "as-generated"
         # When the width is not a multiple of 128 floats (the products-shaped F = 100) the rows that are only STREAMED -- X, dH, dX,
         # and W / dW -- are stored with a 128-float stride (pad columns zero, and they stay zero), so the two backward products run
         # as 128-wide ones on the LDS-DMA kernels (zero columns add exact zeros at the end of every fmaf chain: the same bits in
@@ -292,7 +301,9 @@ class SingleGpu:
             src, dst = torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)
         else:
             src, dst = ops.rmat_edges(seed, n, e, *abc, device=dev)
-        self.g = g = ops.CsrGraph.from_coo(src, dst, n)
+        # X and G below are synthetic rows drawn directly in the graph's row order (to compare with an as-generated run, move
+        # them with g.to_new_order / g.to_vertex_order: tests/test_gpu_parity.py::test_vertex_relabelling_same_bits)
+        self.g = g = ops.CsrGraph.from_coo(src, dst, n, relabel=relabel)
         del src, dst
         ops._ws_cache.clear()
         torch.cuda.empty_cache()
@@ -394,7 +405,13 @@ class SingleGpu:
                                                      for st in self.ev])) if self.ev else None,
                 # the cache-perfect lower bound (every feature row read once) beside the gather figure
                 "cache_perfect_bytes": 4 * (self.n + 1) + 4 * self.g.nnz + 4 * self.n + 8 * self.F * self.n,
-                "frac_of_measured_copy_ceiling_6290": achieved / 6290.0}
+                "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
+                "vertex_order": self.vertex_order,
+                "note": ("achieved = ALGORITHMIC bytes (one feature row per non-zero) / time; it can exceed the HBM peak because the hub "
+                         "rows of a power-law graph are served by the 256 MiB Infinity Cache.  `traffic` (PMC: 2 FETCH_SIZE + WRITE_SIZE) "
+                         "counts what leaves L2 towards the fabric -- Infinity-Cache hits included -- and stays at 0.96 x algorithmic in "
+                         "either vertex order; in the as-generated order the hub rows (ids with few one-bits, 1-KiB rows) alias to the "
+                         "same Infinity-Cache sets and evict each other, the scrambled order keeps them resident (DESIGN.md section 5)")}
 
 
     def mfma_roofline(self):
@@ -415,8 +432,8 @@ class TrainStep(SingleGpu):
     """Whole training step of an L-layer GCN (ops.GcnStack): forward with ReLU between layers, softmax cross-entropy
     against synthetic labels, backward, SGD.  Reuses SingleGpu's graph / plans / roofline bookkeeping."""
 
-    def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk, layers):
-        super().__init__(ops, capi, pkg, dev, n, e, F, abc, seed, chunk, pad=False)
+    def __init__(self, ops, capi, pkg, dev, n, e, F, abc, seed, chunk, layers, relabel="scramble"):
+        super().__init__(ops, capi, pkg, dev, n, e, F, abc, seed, chunk, pad=False, relabel=relabel)
         for nm in ("H", "out", "dH", "dX", "G", "Hp", "outp", "dHp", "dXp", "Gp"):
             setattr(self, nm, None)  # free the single-layer buffers
         torch.cuda.empty_cache()

@@ -131,6 +131,7 @@ _SIGS = {
     "gnnx_comm_destroy": [_vp],
     "gnnx_vertex_weights": [_vp, _vp, _i64, _i32, _i32, _vp, _vp],
     "gnnx_partition_deal": [_vp, _i32, C.c_int, _vp, _vp, C.POINTER(_i64), _vp],
+    "gnnx_partition_scramble": [_vp, _i32, C.c_int, _vp, _vp, _vp],
     "gnnx_shard_select_edges": [_vp, _vp, _i64, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, C.POINTER(_i64), _vp],
     "gnnx_halo_plan_create": [_vp, _i64, _vp, _i32, C.c_int, C.c_int, C.POINTER(_i64), _vp, C.POINTER(_vp), _vp],
     "gnnx_halo_plan_destroy": [_vp],

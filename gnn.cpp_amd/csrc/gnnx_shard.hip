@@ -257,6 +257,39 @@ GNNX_API int gnnx_partition_deal(const int32_t *d_weight, int32_t n_nodes, int w
     return GNNX_OK;
 }
 
+// Spread a rank's rows over its new-id range: position k (ascending original id) of rank p's n_p vertices moves to
+// (k * 2654435761) mod n_p.  2654435761 is prime and larger than any n_p, so the map is a bijection of [0, n_p).
+namespace {
+constexpr uint64_t kScrambleMul = 2654435761ull;
+__global__ __launch_bounds__(256) void scramble_nid_kernel(const int32_t *owner, int32_t n, const int64_t *cuts, int32_t *nid)
+{
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const int p = owner ? owner[v] : 0;
+    const int64_t lo = cuts[p], cnt = cuts[p + 1] - lo;
+    const uint64_t k = (uint64_t)((int64_t)nid[v] - lo);
+    nid[v] = (int32_t)(lo + (int64_t)((k * kScrambleMul) % (uint64_t)cnt));
+}
+}  // namespace
+
+GNNX_API int gnnx_partition_scramble(const int32_t *d_owner, int32_t n_nodes, int world, const int64_t *cuts, int32_t *d_nid, void *stream)
+{
+    GNNX_REQUIRE(n_nodes >= 0 && world >= 1 && cuts && (n_nodes == 0 || d_nid), GNNX_ERR_INVALID_ARG, "bad arguments");
+    GNNX_REQUIRE(world == 1 || d_owner, GNNX_ERR_INVALID_ARG, "owner is required for more than one rank");
+    if (n_nodes == 0) return GNNX_OK;
+    for (int p = 0; p < world; p++)
+        GNNX_REQUIRE(cuts[p] <= cuts[p + 1] && cuts[0] == 0 && cuts[world] == n_nodes, GNNX_ERR_INVALID_ARG, "cuts are not a partition of [0, n)");
+    hipStream_t st = as_stream(stream);
+    DevBuf dcuts;
+    GNNX_HIP_CHECK(dcuts.alloc(sizeof(int64_t) * (size_t)(world + 1)));
+    GNNX_HIP_CHECK(hipMemcpyAsync(dcuts.p, cuts, sizeof(int64_t) * (size_t)(world + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(scramble_nid_kernel, dim3((uint32_t)ceil_div((int64_t)n_nodes, (int64_t)256)), dim3(256), 0, st, world == 1 ? nullptr : d_owner,
+                       n_nodes, dcuts.as<int64_t>(), d_nid);
+    GNNX_LAUNCH_CHECK();
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));   // dcuts is released on return
+    return GNNX_OK;
+}
+
 GNNX_API int gnnx_shard_select_edges(const int32_t *d_src, const int32_t *d_dst, int64_t n_edges, const int32_t *d_owner,
                                      const int32_t *d_nid, int rank, int64_t lo, int transpose, int32_t *d_rows, int32_t *d_cols,
                                      int64_t *n_selected, void *stream)

@@ -58,7 +58,7 @@ public:
     size_t num_local() const { return (size_t)_n_local; }
     int64_t nnz_local() const { return fwd.nnz; }
     const std::vector<int64_t> &cuts() const { return _cuts; }
-    std::vector<int> local_vertices();                            // original ids of my rows, ascending == local row order
+    std::vector<int> local_vertices();                            // original id of local row k (rows are spread inside the rank's range)
     cyg::tptr<float> take_rows(const cyg::tptr<float> &full);     // my rows of a replicated [N,F] tensor (device gather)
 
     struct Side {

@@ -93,6 +93,9 @@ Partition::Partition(const tensor<int> &edge_index, size_t num_nodes, std::share
         gx(gnnx_malloc(&_nid, sizeof(int32_t) * std::max<size_t>(_n, 1)), "partition");
         _cuts.assign((size_t)world + 1, 0);
         gx(gnnx_partition_deal(w.as<int32_t>(), (int32_t)_n, world, (int32_t *)_owner, (int32_t *)_nid, _cuts.data(), st), "partition");
+        // spread every rank's rows inside its range: synthetic power-law hubs sit on ids with few one-bits, whose feature rows
+        // alias to the same cache sets (include/gnnx.h, gnnx_partition_scramble)
+        gx(gnnx_partition_scramble((const int32_t *)_owner, (int32_t)_n, world, _cuts.data(), (int32_t *)_nid, st), "partition");
     }
     _lo = _cuts[rank];
     _n_local = _cuts[rank + 1] - _cuts[rank];
@@ -160,13 +163,15 @@ void Partition::exchange(const Side &s, float *d_buf, int32_t n_feat)
 
 std::vector<int> Partition::local_vertices()
 {
-    std::vector<int32_t> owner(_n);
-    if (_n) gx(gnnx_memcpy_d2h(owner.data(), _owner, sizeof(int32_t) * _n, current_stream()), "partition");
-    std::vector<int> out;
-    out.reserve((size_t)_n_local);
+    std::vector<int32_t> owner(_n), nid(_n);
+    if (_n) {
+        gx(gnnx_memcpy_d2h(owner.data(), _owner, sizeof(int32_t) * _n, current_stream()), "partition");
+        gx(gnnx_memcpy_d2h(nid.data(), _nid, sizeof(int32_t) * _n, current_stream()), "partition");
+    }
+    std::vector<int> out((size_t)_n_local, -1);
     const int rank = comm->rank();
     for (size_t v = 0; v < _n; v++)
-        if (owner[v] == rank) out.push_back((int)v);
+        if (owner[v] == rank) out[(size_t)(nid[v] - _lo)] = (int)v;   // local row k holds the vertex whose new id is lo + k
     return out;
 }
 

@@ -79,6 +79,7 @@ class CsrGraph:
         self.nnz = int(colidx.numel())
         self.s = self.norm = None
         self.plan = self.plan_t = None
+        self.nid = None
 
     @staticmethod
     def csr_from_coo(src, dst, n_nodes, flags=0):
@@ -93,15 +94,51 @@ class CsrGraph:
                   C.byref(nnz), _ptr(ws), ws.numel(), _stream())
         return rowptr, colidx[: nnz.value].clone()
 
+    SCRAMBLE_MUL = 2654435761   # prime above any vertex count: v -> (v * SCRAMBLE_MUL) mod n is a bijection (gnnx_partition_scramble)
+
     @classmethod
-    def from_coo(cls, src, dst, n_nodes, transpose=True, norm=True):
-        rowptr, colidx = cls.csr_from_coo(src, dst, n_nodes)
-        g = cls(n_nodes, rowptr, colidx)
-        if transpose:
-            g.rowptr_t, g.colidx_t = cls.csr_from_coo(dst, src, n_nodes)
+    def from_coo(cls, src, dst, n_nodes, transpose=True, norm=True, relabel=None):
+        """relabel: None (vertex v is row v), "scramble" (row nid[v] = (v * SCRAMBLE_MUL) mod n: spreads the hubs of a synthetic
+        power-law graph, whose ids have few one-bits, over the cache sets) or an int32 [n] permutation nid.  With a relabelling the
+        CSR is built exactly as a one-rank shard is (shard.ShardPlan / gnnx_shard_select_edges + gnnx_halo_plan_create): rows are
+        new ids, a row's entries are sorted by ORIGINAL column id -- the reference's summation order -- and only then renumbered,
+        so every vertex's result has the same bits as without the relabelling and is stored at row g.nid[v]."""
+        if relabel is None:
+            rowptr, colidx = cls.csr_from_coo(src, dst, n_nodes)
+            g = cls(n_nodes, rowptr, colidx)
+            if transpose:
+                g.rowptr_t, g.colidx_t = cls.csr_from_coo(dst, src, n_nodes)
+            g.nid = None
+        else:
+            dev = src.device
+            if isinstance(relabel, str):
+                assert relabel == "scramble"
+                nid = ((torch.arange(n_nodes, dtype=torch.int64, device=dev) * cls.SCRAMBLE_MUL) % max(n_nodes, 1)).to(torch.int32)
+            else:
+                nid = relabel.to(torch.int32)
+            keep = src != dst                       # self loops are dropped on ORIGINAL ids (rows are renumbered below)
+            s_, d_ = src[keep], dst[keep]
+            rowptr, ci = cls.csr_from_coo(nid[s_.long()], d_, n_nodes, flags=1)        # flags = 1: keep the diagonal as given
+            g = cls(n_nodes, rowptr, nid[ci.long()])
+            if transpose:
+                rowptr_t, cit = cls.csr_from_coo(nid[d_.long()], s_, n_nodes, flags=1)
+                g.rowptr_t, g.colidx_t = rowptr_t, nid[cit.long()]
+            g.nid = nid
         if norm:
             g.compute_norm()
         return g
+
+    def to_new_order(self, X):
+        """Rows of X (vertex v at row v) in this graph's row order (vertex v at row nid[v])."""
+        if self.nid is None:
+            return X
+        out = torch.empty_like(X)
+        out[self.nid.long()] = X
+        return out
+
+    def to_vertex_order(self, Y):
+        """The inverse: Y has vertex v at row nid[v]; returns it with vertex v at row v."""
+        return Y if self.nid is None else Y[self.nid.long()]
 
     def compute_norm(self):
         dev = self.rowptr.device

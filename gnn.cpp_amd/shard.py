@@ -52,18 +52,38 @@ def balanced_cuts(weight, world):
     return cuts
 
 
-def deal_partition(weight, world):
+SCRAMBLE_MUL = 2654435761   # prime, larger than any per-rank row count: k -> (k * SCRAMBLE_MUL) mod n_p is a bijection of [0, n_p)
+
+
+def scramble_nid(owner, nid, cuts):
+    """Second relabelling inside every rank's new-id range (mirrors gnnx_partition_scramble): position k of rank p's n_p rows
+    moves to (k * SCRAMBLE_MUL) mod n_p.  R-MAT (and most synthetic power-law generators) put the hubs on the vertex ids with few
+    one-bits -- feature rows whose ADDRESSES have few one-bits, which alias to the same L2 / Infinity-Cache sets, so the hottest
+    rows evict each other; spreading them is worth 28 % of the aggregation at 10 M / 100 M (19.0 -> 13.7 ms).  Row contents and
+    the order of a row's entries are untouched: every vertex's result has the same bits, stored at row nid[v]."""
+    cuts_t = torch.tensor(cuts, dtype=torch.int64, device=nid.device)
+    o = owner.to(torch.int64)
+    lo = cuts_t[o]
+    cnt = cuts_t[o + 1] - lo
+    k = nid.to(torch.int64) - lo
+    # k < 2^31 and SCRAMBLE_MUL < 2^32: the product fits in int64
+    return (lo + (k * SCRAMBLE_MUL) % cnt).to(torch.int32)
+
+
+def deal_partition(weight, world, scramble=True):
     """Snake-deal the vertices, heaviest first, to `world` ranks.
 
     weight: int64 [n] (>= 0).  Returns (owner int32 [n], nid int32 [n], cuts list[world+1]):
     position k of the stable descending-weight order (ties: ascending id) goes to rank j = k % world in even rounds
-    k // world and to world-1-j in odd rounds; nid numbers rank p's vertices cuts[p].. in ascending original id.
-    Mirrors gnnx_partition_deal (csrc/gnnx_shard.hip)."""
+    k // world and to world-1-j in odd rounds; nid numbers rank p's vertices cuts[p].. in ascending original id and, with
+    `scramble`, then spreads them inside the range (scramble_nid).  Mirrors gnnx_partition_deal (+ gnnx_partition_scramble)."""
     n = int(weight.numel())
     dev = weight.device
     if world == 1 or n == 0:
-        return (torch.zeros(n, dtype=torch.int32, device=dev), torch.arange(n, dtype=torch.int32, device=dev),
-                [0] + [n] * world)
+        owner = torch.zeros(n, dtype=torch.int32, device=dev)
+        nid = torch.arange(n, dtype=torch.int32, device=dev)
+        cuts = [0] + [n] * world
+        return owner, (scramble_nid(owner, nid, cuts) if scramble and n else nid), cuts
     w = weight.to(torch.int64)
     key = int(w.max().item()) - w                      # ascending stable sort == descending weight, ties by id
     order = torch.sort(key, stable=True).indices
@@ -80,6 +100,8 @@ def deal_partition(weight, world):
     for p in range(world):
         m = owner == p
         nid[m] = torch.arange(cuts[p], cuts[p + 1], dtype=torch.int32, device=dev)
+    if scramble:
+        nid = scramble_nid(owner, nid, cuts)
     return owner, nid, cuts
 
 
@@ -272,7 +294,8 @@ class ShardPlan:
     reference's adjacency semantics (dedupe, self-loop strip, (src,dst) order): gnnx_csr_from_coo on the GPU.
     Rows are LOCAL ids, columns are ORIGINAL ids in the builder (so a row's entries are stored in the reference's order)
     and are mapped to new ids, then to [local | halo], afterwards.
-    partition: "deal" (default), "contiguous", or a ready (owner, nid, cuts) triple.
+    partition: "deal" (default: degree-sorted snake deal, rows spread inside every rank's range), "deal-ascending" (the same
+    owners, a rank's rows in ascending original id), "contiguous", or a ready (owner, nid, cuts) triple.
     """
 
     def __init__(self, src, dst, n_nodes, rank, world, dist, csr_builder, partition="deal", row_weight=1):
@@ -283,13 +306,18 @@ class ShardPlan:
             # unit per incident edge for the two aggregations (4 F bytes each): row_weight ~ 0.08 F on MI355X
             w = torch.bincount(src.to(torch.int64), minlength=n_nodes) + torch.bincount(dst.to(torch.int64), minlength=n_nodes) \
                 + int(row_weight)
-            partition = (deal_partition if partition == "deal" else contiguous_partition)(w, world)
+            if partition == "deal":
+                partition = deal_partition(w, world)
+            elif partition == "deal-ascending":
+                partition = deal_partition(w, world, scramble=False)
+            else:
+                partition = contiguous_partition(w, world)
         self.owner, self.nid, self.cuts = partition
         cuts = self.cuts
         lo, hi = cuts[rank], cuts[rank + 1]
         self.lo, self.hi, self.n_local = lo, hi, hi - lo
-        self.verts = torch.nonzero(self.owner == rank).reshape(-1)  # original ids of my rows, ascending == local order
         nid = self.nid
+        self.verts = self.orig_ids(torch.arange(lo, hi, dtype=torch.int64, device=dev))   # original id of local row k
         # self loops must be dropped on GLOBAL ids (rows are renumbered below), duplicates collapse in the builder
         keep = src != dst
         mine = keep & (self.owner[src.long()] == rank)

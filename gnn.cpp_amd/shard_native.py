@@ -97,6 +97,7 @@ class NativeShardPlan:
         self.nid = torch.empty(n_nodes, dtype=torch.int32, device=dev)
         ccuts = (C.c_int64 * (world + 1))()
         capi.call("gnnx_partition_deal", ops._ptr(w), n_nodes, world, ops._ptr(self.owner), ops._ptr(self.nid), ccuts, ops._stream())
+        capi.call("gnnx_partition_scramble", ops._ptr(self.owner), n_nodes, world, ccuts, ops._ptr(self.nid), ops._stream())
         self.cuts = list(ccuts)
         self.rank, self.world = rank, world
         self.lo, self.hi = self.cuts[rank], self.cuts[rank + 1]

@@ -66,7 +66,9 @@ def main():
     nl = plan.n_local
     mine = plan.verts.numpy()  # original ids of this rank's rows, in local order
     assert plan.cuts[0] == 0 and plan.cuts[-1] == n and all(a <= b for a, b in zip(plan.cuts, plan.cuts[1:]))
-    assert len(mine) == nl and np.all(np.diff(mine) > 0)
+    assert len(mine) == nl and len(np.unique(mine)) == nl
+    if os.environ.get("PARTITION", "deal") != "deal":
+        assert np.all(np.diff(mine) > 0)   # un-scrambled partitions keep a rank's rows in ascending original id
     assert np.array_equal(plan.nid.numpy()[mine], np.arange(plan.lo, plan.hi)), "new ids are not rank-contiguous"
     counts = torch.tensor([nl], dtype=torch.int64)
     dist.all_reduce(counts)

@@ -748,6 +748,95 @@ def test_streaming_elementwise_vector_kernels_equal_the_scalar_ones(env, n, F):
     assert torch.equal(ops.bn_relu_fwd(X, relu=True), ops.bn_relu_fwd(Xo, relu=True))
 
 
+@pytest.mark.parametrize("n,e,F,abc", [(200_000, 2_000_000, 256, (0.57, 0.19, 0.19)), (50_001, 400_000, 100, (0.57, 0.19, 0.19)),
+                                       (3000, 20_000, 64, None)])
+def test_vertex_relabelling_same_bits(env, n, e, F, abc):
+    """CsrGraph.from_coo(relabel="scramble") -- vertex v stored at row (v * 2654435761) mod n, what bench.py runs by default -- gives
+    every vertex the SAME BITS as the as-generated order, in norm, forward and backward aggregation (exact mode and with the
+    load-balancing plan, whose chunks cut a hub row at the same entries) and through a whole layer step; and both equal the oracle
+    on the original labels.  The C-ABI relabelling (gnnx_partition_scramble with one rank) is the same permutation."""
+    ops, capi, torch = env["ops"], env["capi"], env["torch"]
+    dev_ = env["dev"]
+    if abc is None:
+        s_np, d_np = synth.uniform_edges(51, n, e)
+        src, dst = dev(env, s_np), dev(env, d_np)
+    else:
+        src, dst = ops.rmat_edges(51, n, e, *abc, device=dev_)
+    g0 = ops.CsrGraph.from_coo(src, dst, n)
+    g1 = ops.CsrGraph.from_coo(src, dst, n, relabel="scramble")
+    nid = g1.nid.long()
+    assert sorted(g1.nid.tolist()) == list(range(n)) if n <= 5000 else int(torch.unique(nid).numel()) == n
+    import ctypes as C
+    nid_c = torch.arange(n, dtype=torch.int32, device=dev_)
+    cuts = (C.c_int64 * 2)(0, n)
+    capi.call("gnnx_partition_scramble", None, n, 1, cuts, ops._ptr(nid_c), ops._stream())
+    assert torch.equal(nid_c, g1.nid)
+    assert g0.nnz == g1.nnz
+    assert torch.equal(g1.to_vertex_order(g1.norm), g0.norm) and torch.equal(g1.to_vertex_order(g1.s), g0.s)
+    H = ops.uniform_pm1(52, (n, F), device=dev_)
+    G = ops.uniform_pm1(53, (n, F), device=dev_)
+    bias = ops.uniform_pm1(54, (F,), device=dev_)
+    H1, G1 = g1.to_new_order(H), g1.to_new_order(G)
+    assert torch.equal(g1.to_vertex_order(H1), H)
+    for use_plan in (False, True):
+        if use_plan:
+            g0.make_plans(64, F)
+            g1.make_plans(64, F)
+        a0 = ops.aggregate_fwd(g0, H, bias, use_plan=use_plan)
+        a1 = ops.aggregate_fwd(g1, H1, bias, use_plan=use_plan)
+        assert torch.equal(g1.to_vertex_order(a1), a0), f"forward, plan={use_plan}"
+        b0 = ops.aggregate_bwd(g0, G, use_plan=use_plan)
+        b1 = ops.aggregate_bwd(g1, G1, use_plan=use_plan)
+        assert torch.equal(g1.to_vertex_order(b1), b0), f"backward, plan={use_plan}"
+    if n <= 60_000:   # and the oracle on the original labels
+        rp, ci = oracle.coo_to_csr(host(src), host(dst), n)
+        ref = oracle.aggregate_fwd(rp, ci, host(H), host(g0.norm), host(bias))
+        assert same(host(g1.to_vertex_order(ops.aggregate_fwd(g1, H1, bias, use_plan=False))), ref)
+    # a whole layer step (transform, aggregate, both gradients): rows are independent in the dense products
+    W = ops.uniform_pm1(55, (F, F), scale=F ** -0.5, device=dev_)
+    o0 = ops.aggregate_fwd(g0, ops.linear_fwd(H, W), bias)
+    o1 = ops.aggregate_fwd(g1, ops.linear_fwd(H1, W), bias)
+    assert torch.equal(g1.to_vertex_order(o1), o0)
+    dX0 = ops.gemm(ops.aggregate_bwd(g0, G), W)
+    dX1 = ops.gemm(ops.aggregate_bwd(g1, G1), W)
+    assert torch.equal(g1.to_vertex_order(dX1), dX0)
+    dW0 = ops.gemm(ops.aggregate_bwd(g0, G), H, transA=True)
+    dW1 = ops.gemm(ops.aggregate_bwd(g1, G1), H1, transA=True)      # sums over the rows in another order: rounding only
+    assert float((dW0 - dW1).abs().max()) <= 1e-5 * max(1.0, float(dW0.abs().max()))
+
+
+def test_headline_config_relabelled_equals_as_generated(env):
+    """BASELINE configs[3] (R-MAT 10M / 100M, F = 256) in the row order bench.py runs by default (vertex v at row
+    (v * 2654435761) mod n) against the as-generated order, whose aggregation is pinned bit-exact to the oracle by
+    test_headline_config_whole_graph_vs_oracle: norm, forward and backward aggregation (planned mode, chunk 4096 as in the
+    bench), every row bit for bit."""
+    ops, torch = env["ops"], env["torch"]
+    dev_ = env["dev"]
+    n, e, F = 10_000_000, 100_000_000, 256
+    src, dst = ops.rmat_edges(0, n, e, 0.57, 0.19, 0.19, device=dev_)
+    g0 = ops.CsrGraph.from_coo(src, dst, n)
+    g1 = ops.CsrGraph.from_coo(src, dst, n, relabel="scramble")
+    del src, dst
+    ops._ws_cache.clear()
+    torch.cuda.empty_cache()
+    assert g0.nnz == g1.nnz and torch.equal(g1.to_vertex_order(g1.norm), g0.norm)
+    g0.make_plans(4096, F)
+    g1.make_plans(4096, F)
+    H = ops.uniform_pm1(10, (n, F), device=dev_)
+    bias = ops.uniform_pm1(11, (F,), device=dev_)
+    H1 = g1.to_new_order(H)
+    a0 = ops.aggregate_fwd(g0, H, bias)
+    a1 = ops.aggregate_fwd(g1, H1, bias)
+    assert torch.equal(g1.to_vertex_order(a1), a0)
+    del a0
+    ops.aggregate_bwd(g1, H1, out=a1)
+    b0 = ops.aggregate_bwd(g0, H)
+    assert torch.equal(g1.to_vertex_order(a1), b0)
+    del a1, b0, H, H1, g0, g1
+    ops._ws_cache.clear()
+    torch.cuda.empty_cache()
+
+
 def test_native_rccl_comm_single_rank(env):
     """gnnx_comm_* / gnnx_halo_exchange_f32 / gnnx_allreduce_sum_f32 on a one-rank communicator (all this box has):
     the self-exchange must copy the packed rows into the halo tail and the all-reduce must be the identity."""

@@ -59,11 +59,18 @@ def test_deal_partition_balances_rows_and_weight():
         loads = torch.zeros(world, dtype=torch.int64).index_add_(0, owner.long(), w)
         assert float(loads.max()) / float(loads.float().mean()) < 1.02
         assert sorted(nid.tolist()) == list(range(w.numel()))  # a permutation
-        for p in range(world):  # rank-contiguous new ids, ascending original order inside a rank
+        _, nid_asc, _ = shard.deal_partition(w, world, scramble=False)
+        for p in range(world):  # rank-contiguous new ids; un-scrambled: ascending original order inside a rank; scrambled: spread
             mine = torch.nonzero(owner == p).reshape(-1)
-            assert nid[mine].tolist() == list(range(cuts[p], cuts[p + 1]))
-    owner, nid, cuts = shard.deal_partition(w, 1)
+            assert nid_asc[mine].tolist() == list(range(cuts[p], cuts[p + 1]))
+            assert sorted(nid[mine].tolist()) == list(range(cuts[p], cuts[p + 1]))
+            k = nid_asc[mine].long() - cuts[p]
+            assert torch.equal(nid[mine].long(), cuts[p] + (k * shard.SCRAMBLE_MUL) % (cuts[p + 1] - cuts[p]))
+    owner, nid, cuts = shard.deal_partition(w, 1, scramble=False)
     assert nid.tolist() == list(range(w.numel())) and cuts == [0, w.numel()]
+    owner, nid, cuts = shard.deal_partition(w, 1)      # one rank: the single-GPU relabelling
+    n1 = w.numel()
+    assert nid.tolist() == [(v * shard.SCRAMBLE_MUL) % n1 for v in range(n1)] and sorted(nid.tolist()) == list(range(n1))
     # ties are dealt by ascending id, heaviest first: weights 5 5 1 1 over 2 ranks -> snake 0 1 1 0
     owner, _, _ = shard.deal_partition(torch.tensor([1, 5, 1, 5]), 2)
     assert owner.tolist() == [1, 0, 0, 1]
