@@ -1,6 +1,9 @@
 // API-level benchmark: the GCN layer through the C++ mirror of the reference API (graph::GCNConv on graph::Data),
 // forward + backward, to show what a user of the reference's call sites gets on an MI355X.
-//   bench_host_api [n_nodes=1000000] [n_edges=10000000] [features=128] [steps=5] [hot_path_only=1]
+//   bench_host_api [n_nodes=1000000] [n_edges=10000000] [features=128] [steps=5] [hot_path_only=1] [scramble_labels=0]
+// scramble_labels: the data set's vertex ids are multiplied by 2654435761 mod n (an isomorphic graph) before the API sees them --
+// what a user would do once at load time: R-MAT's hubs are the ids with few one-bits, and 1-KiB feature rows at such ids alias in
+// the Infinity Cache; the API itself keeps the caller's vertex order.
 // Edges: R-MAT from the same SplitMix64 stream as gnn.cpp_amd/synth.py (seed 1, a,b,c = 0.57,0.19,0.19).
 #include <chrono>
 #include <cstdio>
@@ -30,6 +33,7 @@ int main(int argc, char **argv)
     const size_t F = argc > 3 ? atol(argv[3]) : 128;
     const int steps = argc > 4 ? atoi(argv[4]) : 5;
     const bool hot = argc > 5 ? atoi(argv[5]) != 0 : true;
+    const bool scramble = argc > 6 ? atoi(argv[6]) != 0 : false;
     int scale = 1;
     while ((1l << scale) < n) scale++;
     const uint64_t key = splitmix64(1), G = 0x9E3779B97F4A7C15ull;
@@ -44,8 +48,14 @@ int main(int argc, char **argv)
             s = (s << 1) | (r >= tb);
             d = (d << 1) | (((r >= ta) & (r < tb)) | (r >= tc));
         }
-        src[i] = (int)(s % n);
-        dst[i] = (int)(d % n);
+        s %= (uint64_t)n;
+        d %= (uint64_t)n;
+        if (scramble) {
+            s = (s * 2654435761ull) % (uint64_t)n;
+            d = (d * 2654435761ull) % (uint64_t)n;
+        }
+        src[i] = (int)s;
+        dst[i] = (int)d;
     }
     double t_gen = now_s() - t0;
 
