@@ -96,6 +96,8 @@ def main():
                          "vertex's result has the same bits, at another row.  as-generated: vertex v at row v (round 1).  auto (default): "
                          "scrambled when a feature row is a multiple of 512 bytes (F = 256: aggregation 19 -> 13.7 ms; F = 128: -3 %%), "
                          "as-generated otherwise (F = 100: 400-byte rows do not alias, the scramble costs 2 %%)")
+    ap.add_argument("--no-order-control", action="store_true",
+                    help="skip the informational re-run of a few steps on the as-generated vertex order (vertex_order_control)")
     ap.add_argument("--no-pad-features", action="store_true",
                     help="store feature rows at their own width even when it is not a multiple of 128 floats (default: pad the stride)")
     ap.add_argument("--sym", action="store_true",
@@ -239,6 +241,12 @@ def main():
         roof["achieved"] = float(t.item())
         roof["frac"] = roof["achieved"] / roof["peak"]
 
+    # control for the vertex order (informational, outside the timed region above): the same runner on the as-generated labels
+    order_control = None
+    if (world == 1 and not args.force_sharded and not args.train_layers and relabel and graph is None and not args.no_order_control
+            and isinstance(runner, SingleGpu)):
+        order_control = runner.as_generated_control(pkg, n, e, abc, seed, args.chunk)
+
     cpu = cpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pkg, args, F, abc, seed)
@@ -271,6 +279,7 @@ def main():
                        "gemm": "split-bf16 x6 for X.W^T and dH.W (opt-in, NOT the parity path)" if args.split_gemm else "f32 MFMA"},
             "roofline": roof,
             "roofline_mfma": runner.mfma_roofline() if hasattr(runner, "mfma_roofline") else None,
+            "vertex_order_control": order_control,
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,
             "kernels_ms": runner.kernel_times(),
@@ -383,6 +392,37 @@ class SingleGpu:
         run(lambda: ops.aggregate_fwd_sym(g, self.H, self.bias, out=self.out) if sym else ops.aggregate_fwd(g, self.H, self.bias, out=self.out))
         if timed:
             self.ev.append(evs)
+
+    def as_generated_control(self, pkg, n, e, abc, seed, chunk, steps=5, warmup=2):
+        """A few steps of the SAME runner (same buffers, same kernels) on the graph in its as-generated vertex order: the number the
+        default order is to be compared with.  Restores the runner afterwards."""
+        ops = self.ops
+        if abc is None:
+            s_, d_ = pkg.synth.uniform_edges(seed, n, e)
+            src, dst = torch.from_numpy(s_).to(self.X.device), torch.from_numpy(d_).to(self.X.device)
+        else:
+            src, dst = ops.rmat_edges(seed, n, e, *abc, device=self.X.device)
+        g2 = ops.CsrGraph.from_coo(src, dst, n)
+        del src, dst
+        if chunk > 0:
+            g2.make_plans(chunk, self.F)
+        keep_g, keep_ev = self.g, self.ev
+        self.g, self.ev = g2, []
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(timed=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        kt = self.kernel_times()
+        self.g, self.ev = keep_g, keep_ev
+        del g2
+        ops._ws_cache.clear()
+        torch.cuda.empty_cache()
+        return {"order": "as-generated", "steps": steps, "ms_per_step": ms, "spmm_fwd_ms": kt.get("spmm_fwd"), "spmm_bwd_ms": kt.get("spmm_bwd"),
+                "note": "same per-vertex bits as the default order (tests/test_gpu_parity.py::test_headline_config_relabelled_equals_as_generated)"}
 
     def kernel_times(self):
         out = {}
