@@ -11,10 +11,10 @@ OUT="$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 run_set() {  # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_${name}_stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline "$@" > "$OUT/prof_${TAG}_${name}_stats.log" 2>&1
-  rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/prof_${TAG}_${name}_fetch.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/prof_${TAG}_${name}_write.log" 2>&1
-  (cd "$ROOT" && WORKLOAD="${WL:-rmat10m_100m_f256}" PROFILE_CMD="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $*" \
+  rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_${name}_stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-order-control "$@" > "$OUT/prof_${TAG}_${name}_stats.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control "$@" > "$OUT/prof_${TAG}_${name}_fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control "$@" > "$OUT/prof_${TAG}_${name}_write.log" 2>&1
+  (cd "$ROOT" && WORKLOAD="${WL:-rmat10m_100m_f256}" PROFILE_CMD="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-order-control $*" \
      python3 scripts/summarize_profile.py "${TAG}_bench_${name}" "$OUT/prof_${TAG}_${name}_stats" "$OUT/prof_${TAG}_${name}_fetch" "$OUT/prof_${TAG}_${name}_write")
   echo "profiled $name"
 }
