@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--partition", default="deal", choices=["deal", "deal-ascending", "contiguous"],
                     help="N>1: deal = degree-sorted snake deal (equal rows / non-zeros / per-link volume); contiguous = ranges of "
                          "original ids balanced on degree (round 1)")
+    ap.add_argument("--replicate-input-halo", action="store_true",
+                    help="N>1, OPT-IN, valid for a FIRST layer only (its input is data, the same every step): fetch the halo rows of X once "
+                         "and compute their X.W^T locally every step (same bits) -- one halo exchange per step instead of two")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1: nccl (= RCCL over xGMI, the measured path) or gloo = REHEARSAL: device tensors staged through host "
                          "memory over a CPU process group, so that the whole multi-process job can run on a box with one GPU")
@@ -190,7 +193,7 @@ def main():
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
         runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm,
-                                    schedule=args.schedule, partition=args.partition)
+                                    schedule=args.schedule, partition=args.partition, replicate_input_halo=args.replicate_input_halo)
     torch.cuda.synchronize()
     t_build = time.time() - t_build0
 
@@ -273,6 +276,7 @@ def main():
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd of every parameter, SGD; no input gradient); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 and not args.force_sharded else
                        f"1-D vertex shard x{world} ({args.partition}), halo all-to-all-v, schedule {args.schedule}" +
+                       (", input halo replicated (first-layer form: one exchange per step)" if args.replicate_input_halo else "") +
                        (" -- REHEARSAL: gloo through host memory, all ranks on GPU 0: not a measurement" if args.dist_backend == "gloo" else ""),
                        "plan_chunk": args.chunk, "hip_graph": graph is not None, "mode": "SYM" if args.sym else "REF",
                        "feature_storage": "bf16 for the aggregations (opt-in, NOT the parity path)" if args.bf16_features else "f32",

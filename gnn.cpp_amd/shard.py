@@ -371,7 +371,7 @@ class ShardedBench:
     """bench.py runner for N > 1 ranks: same synthetic graph as the single-GPU workload, sharded."""
 
     def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, native_comm=False,
-                 global_inputs=False, schedule="overlap", partition="deal"):
+                 global_inputs=False, schedule="overlap", partition="deal", replicate_input_halo=False):
         import ctypes as C
         self.C = C
         self.native = NativeComm(capi, ops, dist, rank, world, dev) if native_comm else None
@@ -429,13 +429,26 @@ class ShardedBench:
         # one send buffer per direction: in the overlap schedule both exchanges are in flight at once
         self.send_f = torch.empty((max(int(p.fwd.send_idx.numel()), 1), F), dtype=torch.float32, device=dev)
         self.send_b = torch.empty((max(int(p.bwd.send_idx.numel()), 1), F), dtype=torch.float32, device=dev)
+        # OPT-IN, first-layer only (the layer input is DATA, the same rows every step): the halo rows of X are fetched once, here,
+        # and H = X . W^T is computed for [local | halo] rows on every rank -- the halo rows' products are the very fmaf chains
+        # their owners compute (same bits) -- so the step has ONE exchange (the upstream gradient) instead of two.
+        self.replicate = bool(replicate_input_halo)
+        if self.replicate:
+            self.Xext = torch.empty((nl + p.fwd.n_halo, F), dtype=torch.float32, device=dev)
+            self.Xext[:nl] = self.X
+            if world > 1:
+                exchange_rows(dist, p.fwd, self.Xext, F, self.pack, self.send_f, self.native)
+            torch.cuda.synchronize()
         self.set_schedule(schedule)
         self.ev = []
 
     def set_schedule(self, schedule):
         assert schedule in ("overlap", "sequential")
         self.schedule = schedule
-        if schedule == "sequential":
+        if getattr(self, "replicate", False):
+            self.names = ["pack_send_bwd", "gemm_xwT_local_and_halo", "spmm_fwd", "colsum", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
+                          "allreduce"]
+        elif schedule == "sequential":
             self.names = ["gemm_xwT", "halo_fwd", "spmm_fwd", "colsum", "halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW", "allreduce"]
         else:
             self.names = ["pack_send_bwd", "gemm_xwT", "pack_send_fwd", "colsum", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
@@ -470,7 +483,18 @@ class ShardedBench:
                                   plan=self.plan_f, n_rows=nl)
         spmm_b = lambda: ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext, out=self.dH, vals=self.norm_nz_bwd,  # noqa: E731
                                   plan=self.plan_b, n_rows=nl)
-        if self.schedule == "sequential":
+        if self.replicate:
+            # one exchange (G, asynchronous); the whole forward chain -- transform of local AND halo rows, aggregation -- under it
+            _, hb = run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True))
+            run(lambda: ops.linear_fwd(self.Xext, self.W, out=self.Hext))
+            run(spmm_f)
+            run(lambda: ops.colsum(Gl, out=self.dbias))
+            run(hb.wait)
+            run(spmm_b)
+            run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
+            run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+            run(self._reduce_params)
+        elif self.schedule == "sequential":
             run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
             run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native))
             run(spmm_f)

@@ -57,7 +57,8 @@ def main():
         def rank_main(rank):
             try:
                 torch.cuda.set_device(0)
-                r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 4096)
+                r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 4096,
+                                       replicate_input_halo="--replicate-input-halo" in sys.argv)
                 r.step()
                 torch.cuda.synchronize()
                 runners[rank] = r

@@ -75,7 +75,8 @@ class _RankDist:
 
 
 @pytest.mark.parametrize("world,schedule,partition", [(2, "overlap", "deal"), (4, "overlap", "deal"), (8, "overlap", "deal"),
-                                                      (4, "sequential", "deal"), (8, "sequential", "contiguous")])
+                                                      (4, "sequential", "deal"), (8, "sequential", "contiguous"),
+                                                      (4, "replicate-input-halo", "deal"), (8, "replicate-input-halo", "deal")])
 def test_sharded_step_equals_single_gpu(world, schedule, partition):
     import torch
     if not torch.cuda.is_available():
@@ -105,8 +106,9 @@ def test_sharded_step_equals_single_gpu(world, schedule, partition):
     def rank_main(rank):
         try:
             torch.cuda.set_device(0)
+            rep = schedule == "replicate-input-halo"   # opt-in first-layer form: X halo fetched once, one exchange per step
             r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 0, global_inputs=True,
-                                   schedule=schedule, partition=partition)
+                                   schedule="overlap" if rep else schedule, partition=partition, replicate_input_halo=rep)
             r.step()
             r.step(timed=True)  # a second step reuses every buffer (send buffers, halo tails) while nothing is in flight
             torch.cuda.synchronize()
