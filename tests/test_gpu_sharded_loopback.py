@@ -151,6 +151,24 @@ def test_sharded_step_equals_single_gpu(world, schedule, partition):
         assert max(sends) <= 1.35 * (sum(sends) / len(sends)), "per-link send volume is unbalanced"
 
 
+def test_cabi_one_rank_plan_is_the_single_gpu_relabelled_csr():
+    """The single-GPU vertex relabelling behind the C-ABI: gnnx_partition_deal + gnnx_partition_scramble + gnnx_shard_select_edges +
+    gnnx_csr_from_coo + gnnx_halo_plan_create with ONE rank produce exactly the CSR pair that ops.CsrGraph.from_coo(relabel=
+    "scramble") -- what bench.py runs -- builds with torch index ops: same nid, same rowptr / colidx for A and A^T."""
+    import torch
+    ops = importlib.import_module("gnncpp_amd.ops")
+    sn = importlib.import_module("gnncpp_amd.shard_native")
+    dev = torch.device("cuda:0")
+    n, e = 50_000, 600_000
+    src, dst = ops.rmat_edges(21, n, e, device=dev)
+    g = ops.CsrGraph.from_coo(src, dst, n, relabel="scramble")
+    pn = sn.NativeShardPlan(src, dst, n, 0, 1, None)
+    assert pn.cuts == [0, n] and torch.equal(pn.nid, g.nid)
+    assert pn.fwd.n_halo == 0 and pn.bwd.n_halo == 0
+    assert torch.equal(pn.fwd.rowptr, g.rowptr) and torch.equal(pn.fwd.colidx, g.colidx)
+    assert torch.equal(pn.bwd.rowptr, g.rowptr_t) and torch.equal(pn.bwd.colidx, g.colidx_t)
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_cabi_plan_equals_shard_py_plan_and_drives_a_step(world):
     """The partition + halo plan behind the C-ABI (gnnx_vertex_weights / gnnx_partition_deal / gnnx_shard_select_edges /
