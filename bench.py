@@ -92,10 +92,10 @@ def main():
                          "value counts L*nnz edges per step")
     ap.add_argument("--vertex-order", default="auto", choices=["auto", "scrambled", "as-generated"],
                     help="scrambled: the graph builder stores vertex v at row (v * 2654435761) mod n -- R-MAT puts its hubs on the ids "
-                         "with few one-bits, and with a power-of-two row stride their feature rows alias to the same cache sets; every "
+                         "with few one-bits, and with a power-of-two row stride their feature rows pile onto a few memory channels; every "
                          "vertex's result has the same bits, at another row.  as-generated: vertex v at row v (round 1).  auto (default): "
                          "scrambled when a feature row is a multiple of 512 bytes (F = 256: aggregation 19 -> 13.7 ms; F = 128: -3 %%), "
-                         "as-generated otherwise (F = 100: 400-byte rows do not alias, the scramble costs 2 %%)")
+                         "as-generated otherwise (F = 100: 400-byte rows spread by themselves, the scramble costs 2 %%)")
     ap.add_argument("--no-order-control", action="store_true",
                     help="skip the informational re-run of a few steps on the as-generated vertex order (vertex_order_control)")
     ap.add_argument("--no-pad-features", action="store_true",
@@ -454,8 +454,9 @@ class SingleGpu:
                 "note": ("achieved = ALGORITHMIC bytes (one feature row per non-zero) / time; it can exceed the HBM peak because the hub "
                          "rows of a power-law graph are served by the 256 MiB Infinity Cache.  `traffic` (PMC: 2 FETCH_SIZE + WRITE_SIZE) "
                          "counts what leaves L2 towards the fabric -- Infinity-Cache hits included -- and stays at 0.96 x algorithmic in "
-                         "either vertex order; in the as-generated order the hub rows (ids with few one-bits, 1-KiB rows) alias to the "
-                         "same Infinity-Cache sets and evict each other, the scrambled order keeps them resident (DESIGN.md section 5)")}
+                         "either vertex order; in the as-generated order the hub rows (ids with few one-bits, 1-KiB rows) pile onto a few "
+                         "memory channels / cache slices (twice the DRAM-credit stall cycles at the L2 read interface), the scrambled order "
+                         "spreads them (DESIGN.md section 5, profiles/r02_vertex_order_counters.json)")}
 
 
     def mfma_roofline(self):

@@ -94,7 +94,7 @@ Partition::Partition(const tensor<int> &edge_index, size_t num_nodes, std::share
         _cuts.assign((size_t)world + 1, 0);
         gx(gnnx_partition_deal(w.as<int32_t>(), (int32_t)_n, world, (int32_t *)_owner, (int32_t *)_nid, _cuts.data(), st), "partition");
         // spread every rank's rows inside its range: synthetic power-law hubs sit on ids with few one-bits, whose feature rows
-        // alias to the same cache sets (include/gnnx.h, gnnx_partition_scramble)
+        // pile onto a few memory channels (include/gnnx.h, gnnx_partition_scramble)
         gx(gnnx_partition_scramble((const int32_t *)_owner, (int32_t)_n, world, _cuts.data(), (int32_t *)_nid, st), "partition");
     }
     _lo = _cuts[rank];

@@ -58,8 +58,9 @@ SCRAMBLE_MUL = 2654435761   # prime, larger than any per-rank row count: k -> (k
 def scramble_nid(owner, nid, cuts):
     """Second relabelling inside every rank's new-id range (mirrors gnnx_partition_scramble): position k of rank p's n_p rows
     moves to (k * SCRAMBLE_MUL) mod n_p.  R-MAT (and most synthetic power-law generators) put the hubs on the vertex ids with few
-    one-bits -- feature rows whose ADDRESSES have few one-bits, which alias to the same L2 / Infinity-Cache sets, so the hottest
-    rows evict each other; spreading them is worth 28 % of the aggregation at 10 M / 100 M (19.0 -> 13.7 ms).  Row contents and
+    one-bits -- feature rows whose ADDRESSES have few one-bits, so the bits that select the L2 channel / memory channel / Infinity-
+    Cache slice are mostly zero and the hottest rows pile onto a few channels (DRAM-credit stalls of the L2 read interface 234 M vs
+    129 M cycles per launch, profiles/r02_vertex_order_counters.json); spreading them is worth 28 % of the aggregation at 10 M / 100 M (19.0 -> 13.7 ms).  Row contents and
     the order of a row's entries are untouched: every vertex's result has the same bits, stored at row nid[v]."""
     cuts_t = torch.tensor(cuts, dtype=torch.int64, device=nid.device)
     o = owner.to(torch.int64)

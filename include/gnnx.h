@@ -430,7 +430,7 @@ int gnnx_allreduce_sum_f32(gnnx_comm *comm, float *d_buf, int64_t n, void *strea
  *   gnnx_partition_scramble a second relabelling INSIDE every rank's range: position k of rank p's n_p vertices moves to
  *                           (k * 2654435761) mod n_p (a bijection: the multiplier is a prime above every n_p).  Synthetic power-law
  *                           generators (R-MAT) put the hubs on the ids with few one-bits, i.e. feature rows whose addresses have few
- *                           one-bits: they alias to the same L2 / Infinity-Cache sets and the hottest rows evict each other
+ *                           one-bits: the address bits that select the memory channel / cache slice are mostly zero and the hottest rows pile onto a few
  *                           (10 M / 100 M, F = 256: aggregation 19.0 -> 13.7 ms once the labels are scrambled).  world == 1 with
  *                           d_nid = 0..n-1 gives the single-GPU relabelling.  Row contents and summation order are untouched
  *                           (see above): every vertex's result has the same bits, stored at row nid[v].  Synchronises.

@@ -2,8 +2,8 @@
 // forward + backward, to show what a user of the reference's call sites gets on an MI355X.
 //   bench_host_api [n_nodes=1000000] [n_edges=10000000] [features=128] [steps=5] [hot_path_only=1] [scramble_labels=0]
 // scramble_labels: the data set's vertex ids are multiplied by 2654435761 mod n (an isomorphic graph) before the API sees them --
-// what a user would do once at load time: R-MAT's hubs are the ids with few one-bits, and 1-KiB feature rows at such ids alias in
-// the Infinity Cache; the API itself keeps the caller's vertex order.
+// what a user would do once at load time: R-MAT's hubs are the ids with few one-bits, and 1-KiB feature rows at such ids pile onto
+// a few memory channels; the API itself keeps the caller's vertex order.
 // Edges: R-MAT from the same SplitMix64 stream as gnn.cpp_amd/synth.py (seed 1, a,b,c = 0.57,0.19,0.19).
 #include <chrono>
 #include <cstdio>
