@@ -26,8 +26,8 @@ rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_train2_stats" -- py
 (cd "$ROOT" && python3 scripts/summarize_profile.py "${TAG}_bench_rmat10m_train2" "$OUT/prof_${TAG}_train2_stats")
 echo "profiled train2"
 # GEMM SQ counters (MFMA busy, waits, LDS conflicts) on the three 10M x 256 x 256 products
-FS=256 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -f csv \
+TALL_ONLY=1 FS=256 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -f csv \
   -d "$OUT/prof_${TAG}_gemm_sq" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm_sq.log" 2>&1
-FS=256 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_gemm_stats" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm_stats.log" 2>&1
+TALL_ONLY=1 FS=256 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_gemm_stats" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm_stats.log" 2>&1
 (cd "$ROOT" && python3 scripts/summarize_profile.py --sq "${TAG}_gemm_sq_counters" "$OUT/prof_${TAG}_gemm_sq" "$OUT/prof_${TAG}_gemm_stats")
 echo "profiled gemm sq"
