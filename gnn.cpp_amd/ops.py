@@ -116,6 +116,9 @@ class CsrGraph:
                 nid = ((torch.arange(n_nodes, dtype=torch.int64, device=dev) * cls.SCRAMBLE_MUL) % max(n_nodes, 1)).to(torch.int32)
             else:
                 nid = relabel.to(torch.int32)
+                if int(nid.numel()) != n_nodes or int(torch.unique(nid).numel()) != n_nodes or int(nid.min()) != 0 or \
+                        int(nid.max()) != n_nodes - 1:
+                    raise ValueError("relabel must be a permutation of 0..n_nodes-1")
             keep = src != dst                       # self loops are dropped on ORIGINAL ids (rows are renumbered below)
             s_, d_ = src[keep], dst[keep]
             rowptr, ci = cls.csr_from_coo(nid[s_.long()], d_, n_nodes, flags=1)        # flags = 1: keep the diagonal as given
@@ -575,6 +578,10 @@ class GcnStack:
             if X.stride(0) != P[0] or X.stride(1) != 1:   # not a view of a padded buffer (pad_input): pad a copy
                 X = self.pad_input(X)
             hp = torch.as_strided(X, (n, P[0]), (P[0], 1))
+            if getattr(self, "_checked_input", None) != (X.data_ptr(), n):   # a caller's own wide buffer: its pad columns must be zero
+                if bool(hp[:, d[0]:].any()):
+                    raise ValueError("the columns behind the input's logical width must be zero (use GcnStack.pad_input)")
+                self._checked_input = (X.data_ptr(), n)
         else:
             hp = X
         saved = []

@@ -397,8 +397,14 @@ def test_gcn_stack_padded_streamed_layout_same_bits(env, dims):
     for a, b in zip(dWa, dWb):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(b.abs().max()))
     net = nets[0]
-    # a plain (unpadded) input is accepted too, same result
+    # a plain (unpadded) input is accepted too, same result; a wide buffer with non-zero pad columns is refused
     assert torch.equal(net.forward(X), oa)
+    wide = torch.ones((n, net.P[0]), dtype=torch.float32, device=env["dev"])
+    wide[:, :dims[0]] = X
+    with pytest.raises(ValueError):
+        net.forward(wide[:, :dims[0]])
+    with pytest.raises(ValueError):
+        ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), n, relabel=torch.zeros(n, dtype=torch.int32, device=env["dev"]))
     net.backward(dOut)
     net.step(lr=0.01, weight_decay=1e-4)
     for l in range(len(dims) - 1):
