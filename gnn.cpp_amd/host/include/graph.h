@@ -24,6 +24,19 @@ class Partition;  // dist.h
 typedef enum DataType { TRAIN, VAL, TEST } DataType;
 
 cyg::tptr<int> vec_to_edge_list(std::vector<int> source, std::vector<int> destination);
+// (addition, not in the reference) new vertex id of v under the label scramble for synthetic data sets: (v * 2654435761) mod n, a
+// bijection of [0, n).  Generators that draw the bits of an id independently (R-MAT) put the hubs on ids with few one-bits; with
+// 1-KiB feature rows those pile onto a few memory channels.  Apply it once to the edge list AND to the row order of every [N, F]
+// input before building graph::Data; results come back at row scrambled_label(v, n).  DESIGN.md section 5.
+inline int scrambled_label(int v, size_t num_nodes)
+{
+    return (int)(((unsigned long long)v * 2654435761ull) % (unsigned long long)num_nodes);
+}
+inline void scramble_labels(std::vector<int> &source, std::vector<int> &destination, size_t num_nodes)
+{
+    for (int &v : source) v = scrambled_label(v, num_nodes);
+    for (int &v : destination) v = scrambled_label(v, num_nodes);
+}
 // n_nodes == 0 uses max(edge_index)+1 (the reference uses max(edge_index), which overflows its own buffer:
 // graph.cpp:25,40 -- SURVEY appendix A; pass n_nodes explicitly for identical behaviour)
 cyg::tptr<float> edge_to_adj_mat(const cyg::tensor<int> &edge_index, cyg::tensor<float> *edge_attr = nullptr, size_t n_nodes = 0);

@@ -50,12 +50,8 @@ int main(int argc, char **argv)
         }
         s %= (uint64_t)n;
         d %= (uint64_t)n;
-        if (scramble) {
-            s = (s * 2654435761ull) % (uint64_t)n;
-            d = (d * 2654435761ull) % (uint64_t)n;
-        }
-        src[i] = (int)s;
-        dst[i] = (int)d;
+        src[i] = scramble ? graph::scrambled_label((int)s, (size_t)n) : (int)s;
+        dst[i] = scramble ? graph::scrambled_label((int)d, (size_t)n) : (int)d;
     }
     double t_gen = now_s() - t0;
 

@@ -102,6 +102,14 @@ int main()
     auto ei = graph::vec_to_edge_list({1, 2, 3, 0, 4, 1, 2, 3}, {1, 2, 0, 1, 2, 2, 1, 1});
     CHECK((ei->shape() == vector<size_t>{2, 8}) && (*ei->data())[8] == 1 && (*ei->data())[3] == 0);
     CHECK(throws_with([&] { graph::vec_to_edge_list({1, 2}, {1}); }, "input vectors must be of same length"));
+    {   // (addition) label scramble for synthetic data sets: a bijection, applied to both ends of every edge
+        vector<int> s = {0, 1, 2, 3, 14}, d = {14, 0, 7, 7, 1}, seen(15, 0);
+        for (int v = 0; v < 15; v++) seen[graph::scrambled_label(v, 15)]++;
+        bool bij = true;
+        for (int c : seen) bij = bij && c == 1;
+        graph::scramble_labels(s, d, 15);
+        CHECK(bij && s[0] == 0 && s[1] == graph::scrambled_label(1, 15) && d[0] == s[4] && d[2] == d[3]);
+    }
     auto x = make_shared<tensor<float>>(vector<size_t>{15, 10}, 0.5f);
     graph::Data data(x, ei.get());
     CHECK(data.num_nodes() == 15 && data.num_node_features() == 10 && data.num_edges() == 8);
