@@ -190,6 +190,10 @@ def main():
         runner.sym = args.sym
         runner.bf16_features = args.bf16_features
         runner.split_gemm = args.split_gemm
+    elif args.train_layers > 0:
+        shard = importlib.import_module("gnncpp_amd.shard")
+        runner = shard.ShardedTrain(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, args.train_layers,
+                                    partition=args.partition)
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
         runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm,
@@ -243,6 +247,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         roof["achieved"] = float(t.item())
         roof["frac"] = roof["achieved"] / roof["peak"]
+        if args.train_layers:   # whole training steps: no single-kernel roofline line (see the default run)
+            roof["achieved"] = roof["frac"] = None
 
     # control for the vertex order (informational, outside the timed region above): the same runner on the as-generated labels
     order_control = None

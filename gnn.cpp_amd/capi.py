@@ -123,6 +123,7 @@ _SIGS = {
     "gnnx_softmax_ce_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _sz, _vp],
     "gnnx_softmax_ce_colsum_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_softmax_ce_colsum_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _vp, _sz, _vp],
+    "gnnx_softmax_ce_partial_f32": [_vp, _i64, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp, _sz, _vp],
     "gnnx_sgd_step_f32": [_vp, _vp, _i64, _f32, _f32, _vp],
     "gnnx_comm_unique_id": [_vp],
     "gnnx_comm_init": [C.POINTER(_vp), C.c_int, C.c_int, _vp],

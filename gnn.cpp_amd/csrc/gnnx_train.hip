@@ -220,11 +220,15 @@ GNNX_API int gnnx_softmax_ce_workspace(int64_t n_rows, size_t *bytes)
     return GNNX_OK;
 }
 
-GNNX_API int gnnx_softmax_ce_colsum_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes,
-                                        float *d_loss, float *d_dlogits, int64_t ldd, float *d_colsum, void *d_workspace,
-                                        size_t workspace_bytes, void *stream)
+// A shard's share of the loss over n_total rows: the mean's divisor is n_total (>= n_rows), so d_loss is THIS rank's term of the
+// mean (summed over the ranks by the caller) and dlogits / the column sums carry 1 / n_total -- the same expression per element as
+// the unsharded call with n_total rows.
+GNNX_API int gnnx_softmax_ce_partial_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes,
+                                         int64_t n_total, float *d_loss, float *d_dlogits, int64_t ldd, float *d_colsum,
+                                         void *d_workspace, size_t workspace_bytes, void *stream)
 {
     GNNX_REQUIRE(n_rows > 0 && n_classes > 0, GNNX_ERR_INVALID_ARG, "empty batch");
+    GNNX_REQUIRE(n_total >= n_rows, GNNX_ERR_INVALID_ARG, "n_total < n_rows");
     GNNX_REQUIRE(d_logits && d_target && ldx >= n_classes, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_classes");
     GNNX_REQUIRE(!d_dlogits || ldd >= n_classes, GNNX_ERR_INVALID_ARG, "ldd < n_classes");
     GNNX_REQUIRE(!d_colsum || d_dlogits, GNNX_ERR_INVALID_ARG, "column sums are those of dlogits: dlogits is null");
@@ -239,7 +243,7 @@ GNNX_API int gnnx_softmax_ce_colsum_f32(const float *d_logits, int64_t ldx, cons
     // column-sum partials: 16-byte aligned, behind the flag
     float *cpart = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(bad + 4) + 255u) & ~(uintptr_t)255u);
     GNNX_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int32_t), st));
-    const float inv_n = 1.0f / (float)n_rows;
+    const float inv_n = 1.0f / (float)n_total;
     const bool vec = n_classes % 4 == 0 && n_classes <= 1024 && ldx % 4 == 0 && (!d_dlogits || ldd % 4 == 0) &&
                      (reinterpret_cast<uintptr_t>(d_logits) & 15u) == 0 && (reinterpret_cast<uintptr_t>(d_dlogits) & 15u) == 0;
     if (vec) {
@@ -279,7 +283,7 @@ GNNX_API int gnnx_softmax_ce_colsum_f32(const float *d_logits, int64_t ldx, cons
     if (d_loss) {
         hipLaunchKernelGGL(sum_stage1, dim3(kSumBlocks), dim3(256), 0, st, row_loss, n_rows, partial);
         GNNX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(64), 0, st, partial, kSumBlocks, 1.0f / (float)n_rows, d_loss);
+        hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(64), 0, st, partial, kSumBlocks, 1.0f / (float)n_total, d_loss);
         GNNX_LAUNCH_CHECK();
     }
     int32_t h_bad = 0;
@@ -287,6 +291,14 @@ GNNX_API int gnnx_softmax_ce_colsum_f32(const float *d_logits, int64_t ldx, cons
     GNNX_HIP_CHECK(hipStreamSynchronize(st));
     GNNX_REQUIRE(!h_bad, GNNX_ERR_INDEX_RANGE, "target class out of range");
     return GNNX_OK;
+}
+
+GNNX_API int gnnx_softmax_ce_colsum_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes,
+                                        float *d_loss, float *d_dlogits, int64_t ldd, float *d_colsum, void *d_workspace,
+                                        size_t workspace_bytes, void *stream)
+{
+    return gnnx_softmax_ce_partial_f32(d_logits, ldx, d_target, n_rows, n_classes, n_rows, d_loss, d_dlogits, ldd, d_colsum, d_workspace,
+                                       workspace_bytes, stream);
 }
 
 GNNX_API int gnnx_softmax_ce_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes,

@@ -492,12 +492,14 @@ def gcn_layer_bwd(g, X, W, G):
 
 
 # ---- whole training step: multi-layer GCN + softmax cross-entropy + SGD ----------
-def softmax_ce(logits, target, want_grad=True, colsum_out=None):
+def softmax_ce(logits, target, want_grad=True, colsum_out=None, n_total=None, grad_out=None):
     """(mean loss as a 1-element device tensor, dlogits or None): gnnx_softmax_ce_f32 (reference forward nn.cpp:442-453).
-    colsum_out [C]: also the column sums of dlogits (the last layer's bias gradient), from the kernel that writes dlogits."""
+    colsum_out [C]: also the column sums of dlogits (the last layer's bias gradient), from the kernel that writes dlogits.
+    n_total: the rows are one shard of a batch of n_total (gnnx_softmax_ce_partial_f32: loss = this rank's term of the mean).
+    grad_out: where dlogits goes (e.g. the [:n_local] rows of a [local | halo] buffer)."""
     N, Cn = logits.shape
     loss = torch.empty(1, dtype=torch.float32, device=logits.device)
-    d = torch.empty_like(logits) if want_grad else None
+    d = (torch.empty_like(logits) if grad_out is None else grad_out) if want_grad else None
     wsb = C.c_size_t(0)
     if colsum_out is not None:
         assert want_grad and colsum_out.numel() == Cn and colsum_out.is_contiguous()
@@ -505,8 +507,8 @@ def softmax_ce(logits, target, want_grad=True, colsum_out=None):
     else:
         capi.call("gnnx_softmax_ce_workspace", N, C.byref(wsb))
     ws = _workspace(wsb.value, logits.device, "ce")
-    capi.call("gnnx_softmax_ce_colsum_f32", _ptr(logits), _ld(logits), _ptr(target), N, Cn, _ptr(loss), _ptr(d), _ld(d) if want_grad else 0,
-              _ptr(colsum_out), _ptr(ws), wsb.value, _stream())
+    capi.call("gnnx_softmax_ce_partial_f32", _ptr(logits), _ld(logits), _ptr(target), N, Cn, int(N if n_total is None else n_total), _ptr(loss),
+              _ptr(d), _ld(d) if want_grad else 0, _ptr(colsum_out), _ptr(ws), wsb.value, _stream())
     return loss, d
 
 

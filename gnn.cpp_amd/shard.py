@@ -368,6 +368,148 @@ class ShardPlan:
 
 
 # ---------------------------------------------------------------------------------------------------
+class ShardedGcnStack:
+    """The multi-layer training step (ops.GcnStack) on one rank's rows of a 1-D vertex partition: per layer one halo exchange forward
+    (rows of H = h W^T) and one backward (rows of the upstream gradient), the loss over the global batch (each rank's term of the
+    mean, 1 / N_total in the gradient), parameter gradients all-reduced, the same SGD step on every rank.  Per vertex the forward
+    values are the unsharded stack's bit for bit (same fmaf chains in the dense products, same summation order in the
+    aggregations); dW / db sum the ranks' contributions in rank order (rounding-level)."""
+
+    def __init__(self, ops, dist, plan, dims, seed=0, chunk=4096, native=None):
+        self.ops, self.dist, self.p, self.native = ops, dist, plan, native
+        dev = plan.fwd.rowptr.device
+        self.dims = list(dims)
+        L = len(dims) - 1
+        self.W = [ops.uniform_pm1(seed + 2 * l, (dims[l + 1], dims[l]), scale=dims[l] ** -0.5, device=dev) for l in range(L)]
+        self.b = [torch.zeros(dims[l + 1], dtype=torch.float32, device=dev) for l in range(L)]
+        self.dW = [torch.zeros_like(w) for w in self.W]
+        self.db = [torch.zeros_like(b) for b in self.b]
+        nl, p = plan.n_local, plan
+        self.pack = lambda rows, idx, out: ops.gather_rows(rows, idx, out=out)
+        if p.norm is None:
+            raise ValueError("ShardPlan.compute_norm must have run")
+        self.norm_nz_bwd = ops.gather_rows(p.norm_ext_bwd.reshape(-1, 1), p.bwd.colidx).reshape(-1)
+        fmax = max(dims[1:])
+        self.plan_f = ops.SpmmPlan(p.fwd.rowptr, chunk, fmax) if chunk > 0 else None
+        self.plan_b = ops.SpmmPlan(p.bwd.rowptr, chunk, fmax) if chunk > 0 else None
+        # [local | halo] buffers, one per layer output width and direction (re-used every step)
+        self.Hext = [torch.empty((nl + p.fwd.n_halo, dims[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
+        self.Gext = [torch.empty((nl + p.bwd.n_halo, dims[l + 1]), dtype=torch.float32, device=dev) for l in range(L)]
+        ns = max(int(p.fwd.send_idx.numel()), int(p.bwd.send_idx.numel()), 1)
+        self.send = torch.empty((ns, fmax), dtype=torch.float32, device=dev)
+        self._saved = None
+
+    def _exchange(self, side, buf, F):
+        if self.p.world > 1:
+            exchange_rows(self.dist, side, buf, F, self.pack, self.send.view(-1)[: self.send.shape[0] * F].view(-1, F), self.native)
+
+    def forward(self, X_local):
+        ops, p, nl = self.ops, self.p, self.p.n_local
+        L = len(self.W)
+        saved, h = [], X_local
+        for l in range(L):
+            F = self.dims[l + 1]
+            ops.linear_fwd(h, self.W[l], out=self.Hext[l][:nl])
+            self._exchange(p.fwd, self.Hext[l], F)
+            Y = ops.spmm(p.fwd.rowptr, p.fwd.colidx, self.Hext[l], rowscale=p.norm, bias=self.b[l], plan=self.plan_f, n_rows=nl,
+                         relu_out=l + 1 < L)
+            saved.append((h, Y))
+            h = Y
+        self._saved = saved
+        return h
+
+    def loss_and_backward(self, logits_local, target_local, n_total):
+        """softmax cross-entropy over the global batch + backward through the stack; returns the global mean loss (1-element
+        tensor, all-reduced).  Parameter gradients are all-reduced: every rank ends with the global dW / db."""
+        ops, p, nl, dist = self.ops, self.p, self.p.n_local, self.dist
+        L = len(self.W)
+        loss, G = ops.softmax_ce(logits_local, target_local, colsum_out=self.db[L - 1], n_total=n_total, grad_out=self.Gext[L - 1][:nl])
+        for l in reversed(range(L)):
+            F = self.dims[l + 1]
+            h, _ = self._saved[l]
+            self._exchange(p.bwd, self.Gext[l], F)
+            dH = ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext[l], vals=self.norm_nz_bwd, plan=self.plan_b, n_rows=nl)
+            ops.gemm(dH, h, transA=True, out=self.dW[l])
+            if l > 0:   # G_{l-1} = (dH . W_l) (.) (Y_{l-1} > 0) straight into the next exchange's buffer, db_{l-1} from the same epilogue
+                ops.gemm_relu_colsum(dH, self.W[l], h, out=self.Gext[l - 1][:nl], colsum_out=self.db[l - 1])
+        if p.world > 1:
+            for t in self.dW + self.db + [loss]:
+                if self.native is not None and t is not loss:
+                    self.native.allreduce(t)
+                else:
+                    dist.all_reduce(t)
+        return loss
+
+    def step(self, lr, weight_decay=0.0):
+        for prm, gr in zip(self.W + self.b, self.dW + self.db):
+            self.ops.sgd_step(prm, gr, lr, weight_decay)
+
+
+class ShardedTrain:
+    """bench.py runner for `--train-layers L` on N > 1 ranks: the L-layer training step (forward, softmax-CE over the global batch,
+    backward, parameter all-reduce, SGD) on the sharded graph -- ShardedGcnStack; exchanges are synchronous on the compute stream
+    (a layer's aggregation needs its own halo: no independent chain to put under the exchange inside one training step)."""
+
+    def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, layers, partition="deal"):
+        import ctypes as C
+        self.C, self.ops, self.capi, self.dist, self.F = C, ops, capi, dist, F
+        self.rank, self.world, self.layers = rank, world, layers
+        if abc is None:
+            s, d = pkg.synth.uniform_edges(seed, n, e)
+            src, dst = torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)
+        else:
+            src, dst = ops.rmat_edges(seed, n, e, *abc, device=dev)
+
+        def builder_once(s_, d_, n_rows, n_cols):
+            rp, ci = ops.CsrGraph.csr_from_coo(s_, d_, max(n_rows, n_cols), flags=1)
+            return rp[: n_rows + 1].contiguous(), ci
+
+        self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once, partition=partition, row_weight=max(1, round(0.078 * F)))
+        del src, dst
+        p.owner = p.nid = None
+        ops._ws_cache.clear()
+        torch.cuda.empty_cache()
+
+        def degree_norm(rowptr, colidx, n_rows, s_out, s_cols, norm_out):
+            capi.call("gnnx_degree_norm_f32", ops._ptr(rowptr), ops._ptr(colidx), n_rows, ops._ptr(s_out), ops._ptr(s_cols),
+                      ops._ptr(norm_out), ops._stream())
+
+        p.compute_norm(dist, degree_norm, lambda rows, idx, out: ops.gather_rows(rows, idx, out=out))
+        t = torch.tensor([p.nnz_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        self.nnz_total = int(t.item())
+        self.n_total = n
+        self.net = ShardedGcnStack(ops, dist, p, [F] * (layers + 1), seed=seed + 100, chunk=chunk)
+        nl = p.n_local
+        self.X = ops.uniform_pm1(seed + 10 + 1000 * rank, (nl, F), device=dev)
+        self.target = ((torch.arange(nl, device=dev, dtype=torch.int64) + p.lo) * 7 + 3).remainder(F).to(torch.int32)
+        self.names = ["train_step"]
+        self.ev = []
+
+    def step(self, timed=False):
+        stream = self.C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if timed:
+            a, b = self.capi.Event(), self.capi.Event()
+            a.record(stream)
+        logits = self.net.forward(self.X)
+        self.net.loss_and_backward(logits, self.target, self.n_total)
+        self.net.step(lr=1e-3)
+        if timed:
+            b.record(stream)
+            self.ev.append([(a, b)])
+
+    def kernel_times(self):
+        import numpy as np
+        return {"train_step": float(np.mean([s[0][0].elapsed_ms(s[0][1]) for s in self.ev])) if self.ev else None}
+
+    def roofline(self):
+        from bench import HBM_PEAK_GBS
+        p = self.plan
+        return {"bound": "hbm", "kernel": "n/a for --train-layers (see the default run)", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": 0.0, "traffic": None, "halo_rows_fwd": p.fwd.n_halo, "halo_rows_bwd": p.bwd.n_halo, "local_rows": p.n_local,
+                "schedule": "synchronous exchanges (training step)"}
+
+
 class ShardedBench:
     """bench.py runner for N > 1 ranks: same synthetic graph as the single-GPU workload, sharded."""
 

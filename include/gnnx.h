@@ -380,6 +380,11 @@ int gnnx_softmax_ce_colsum_workspace(int64_t n_rows, int32_t n_classes, size_t *
 int gnnx_softmax_ce_colsum_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes,
                                float *d_loss, float *d_dlogits, int64_t ldd, float *d_colsum, void *d_workspace,
                                size_t workspace_bytes, void *stream);
+/* A shard's share (1-D vertex partition): n_rows local rows of a batch of n_total; d_loss is this rank's term of the mean (the caller
+ * sums the ranks' terms), dlogits and the column sums carry 1 / n_total.  n_total == n_rows is gnnx_softmax_ce_colsum_f32. */
+int gnnx_softmax_ce_partial_f32(const float *d_logits, int64_t ldx, const int32_t *d_target, int64_t n_rows, int32_t n_classes,
+                                int64_t n_total, float *d_loss, float *d_dlogits, int64_t ldd, float *d_colsum, void *d_workspace,
+                                size_t workspace_bytes, void *stream);
 int gnnx_sgd_step_f32(float *d_param, const float *d_grad, int64_t n, float lr, float weight_decay, void *stream);
 
 /* ------------------------------------------------------------------ halo (multi-GPU) ------------- */

@@ -193,6 +193,9 @@ def test_bench_contract_single_gpu_and_sharded_rehearsal():
         s = _run_bench(["--workload", "tiny", "--steps", "2", "--warmup", "1", "--force-sharded", "--no-cpu-baseline", "--schedule", sched])
         assert s["n_gpus"] == 1 and "halo all-to-all-v" in s["config"]["parallelism"] and s["roofline"]["schedule"] == sched
         assert s["config"]["nnz"] == d["config"]["nnz"], "the sharded path must see the same graph"
+    t = _run_bench(["--workload", "tiny", "--steps", "2", "--warmup", "1", "--force-sharded", "--no-cpu-baseline", "--train-layers", "2"])
+    assert t["n_gpus"] == 1 and "training step" in t["config"]["step"] and t["roofline"]["frac"] is None
+    assert abs(t["value"] - 2 * t["config"]["nnz"] / (t["ms_per_step"] * 1e-3)) <= 1e-6 * t["value"]
 
 
 def test_multi_process_job_rehearsal_on_one_gpu():
