@@ -399,9 +399,11 @@ class ShardedGcnStack:
         self.send = torch.empty((ns, fmax), dtype=torch.float32, device=dev)
         self._saved = None
 
-    def _exchange(self, side, buf, F):
+    def _exchange(self, side, buf, F, async_op=False):
         if self.p.world > 1:
-            exchange_rows(self.dist, side, buf, F, self.pack, self.send.view(-1)[: self.send.shape[0] * F].view(-1, F), self.native)
+            return exchange_rows(self.dist, side, buf, F, self.pack, self.send.view(-1)[: self.send.shape[0] * F].view(-1, F), self.native,
+                                 async_op=async_op)[1]
+        return _Done()
 
     def forward(self, X_local):
         ops, p, nl = self.ops, self.p, self.p.n_local
@@ -424,14 +426,16 @@ class ShardedGcnStack:
         ops, p, nl, dist = self.ops, self.p, self.p.n_local, self.dist
         L = len(self.W)
         loss, G = ops.softmax_ce(logits_local, target_local, colsum_out=self.db[L - 1], n_total=n_total, grad_out=self.Gext[L - 1][:nl])
+        pending = self._exchange(p.bwd, self.Gext[L - 1], self.dims[L], async_op=True)
         for l in reversed(range(L)):
-            F = self.dims[l + 1]
             h, _ = self._saved[l]
-            self._exchange(p.bwd, self.Gext[l], F)
+            pending.wait()
             dH = ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext[l], vals=self.norm_nz_bwd, plan=self.plan_b, n_rows=nl)
-            ops.gemm(dH, h, transA=True, out=self.dW[l])
-            if l > 0:   # G_{l-1} = (dH . W_l) (.) (Y_{l-1} > 0) straight into the next exchange's buffer, db_{l-1} from the same epilogue
+            if l > 0:   # G_{l-1} = (dH . W_l) (.) (Y_{l-1} > 0) straight into the next exchange's buffer, db_{l-1} from the same epilogue;
+                # its exchange starts at once and the layer's weight gradient is computed under it
                 ops.gemm_relu_colsum(dH, self.W[l], h, out=self.Gext[l - 1][:nl], colsum_out=self.db[l - 1])
+                pending = self._exchange(p.bwd, self.Gext[l - 1], self.dims[l], async_op=True)
+            ops.gemm(dH, h, transA=True, out=self.dW[l])
         if p.world > 1:
             for t in self.dW + self.db + [loss]:
                 if self.native is not None and t is not loss:
