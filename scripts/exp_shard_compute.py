@@ -4,7 +4,7 @@ in-process loopback world of tests/test_gpu_sharded_loopback.py (real plans, rea
 every rank's step is timed ALONE with the exchange stubbed out (halo rows keep the values of the real exchange).
 Gives the compute side of DESIGN.md section 6's scaling model: what a rank does per step besides waiting for xGMI.
 
-    python scripts/exp_shard_compute.py [world ...] [--workload tiny]
+    python scripts/exp_shard_compute.py [world ...] [--workload tiny] [--replicate-input-halo] [--train-layers L]
 """
 import importlib
 import json
@@ -48,6 +48,10 @@ def main():
     if "--workload" in sys.argv:
         workload = sys.argv[sys.argv.index("--workload") + 1]
         args = [a for a in args if a != workload]
+    layers = 0
+    if "--train-layers" in sys.argv:
+        layers = int(sys.argv[sys.argv.index("--train-layers") + 1])
+        args = [a for a in args if a != str(layers)] if args.count(str(layers)) == 1 else args
     worlds = [int(a) for a in args] or [8]
     n, e, F, abc, seed = WORKLOADS[workload]
     for world in worlds:
@@ -57,8 +61,11 @@ def main():
         def rank_main(rank):
             try:
                 torch.cuda.set_device(0)
-                r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 4096,
-                                       replicate_input_halo="--replicate-input-halo" in sys.argv)
+                if layers:
+                    r = shard.ShardedTrain(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 4096, layers)
+                else:
+                    r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 4096,
+                                           replicate_input_halo="--replicate-input-halo" in sys.argv)
                 r.step()
                 torch.cuda.synchronize()
                 runners[rank] = r
@@ -77,7 +84,10 @@ def main():
             sys.exit(1)
         for r in runners:
             r.dist = NullDist()
-            r.set_schedule("overlap")
+            if layers:
+                r.net.dist = NullDist()
+            else:
+                r.set_schedule("overlap")
             for _ in range(2):
                 r.step()
             torch.cuda.synchronize()
