@@ -107,6 +107,9 @@ public:
 // (nn.cpp:442-453: -log(exp(x_t) / (sum_c exp(x_c) + 1e-20)), no max-subtraction); backward (softmax - onehot)/N
 // (the reference's own backward throws).
 cyg::tptr<float> cross_entropy_loss(const cyg::tptr<float> logits, const cyg::tptr<int> target);
+// (addition) a shard's share of the loss over a batch of n_total rows (1-D vertex partition): the value is this rank's term of the
+// mean -- sum the ranks' values for the loss -- and the gradient carries 1 / n_total, as the unsharded call on all rows would
+cyg::tptr<float> cross_entropy_loss(const cyg::tptr<float> logits, const cyg::tptr<int> target, size_t n_total);
 
 // Optimisers over device-resident parameters (reference nn.h:156-191).  SGD is the textbook update
 // p -= lr * (g + weight_decay * p) (+ momentum buffers); the reference's step() reads an empty velocity vector

@@ -459,6 +459,7 @@ namespace {
 class CrossEntropyOp : public cyg::Operation<tensor<float>> {
 public:
     tptr<int> target;
+    int64_t n_total = 0;   // > 0: the rows are one shard of a batch of n_total (sharded training: the caller sums the ranks' losses)
     CrossEntropyOp() { name = "CrossEntropy"; }
     tptr<float> forward(const tptr<float> &logits, const tptr<int> &tgt)
     {
@@ -470,8 +471,9 @@ public:
         size_t wsb = 0;
         detail::gx(gnnx_softmax_ce_workspace((int64_t)shp[0], &wsb), "cross_entropy");
         auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1}, logits->requires_grad());
-        detail::gx(gnnx_softmax_ce_f32(logits->device_data(), (int64_t)shp[1], tgt->device_data(), (int64_t)shp[0], (int32_t)shp[1],
-                                       out->device_out(), nullptr, 0, detail::workspace(wsb), wsb, detail::current_stream()),
+        detail::gx(gnnx_softmax_ce_partial_f32(logits->device_data(), (int64_t)shp[1], tgt->device_data(), (int64_t)shp[0], (int32_t)shp[1],
+                                               n_total > 0 ? n_total : (int64_t)shp[0], out->device_out(), nullptr, 0, nullptr,
+                                               detail::workspace(wsb), wsb, detail::current_stream()),
                    "cross_entropy");
         if (out->requires_grad()) context->save_for_backward({logits});
         return out;
@@ -487,8 +489,9 @@ public:
         detail::gx(gnnx_softmax_ce_workspace((int64_t)shp[0], &wsb), "cross_entropy");
         auto d = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
         void *st = detail::current_stream();
-        detail::gx(gnnx_softmax_ce_f32(logits->device_data(), (int64_t)shp[1], target->device_data(), (int64_t)shp[0], (int32_t)shp[1],
-                                       nullptr, d->device_out(), (int64_t)shp[1], detail::workspace(wsb), wsb, st), "cross_entropy");
+        detail::gx(gnnx_softmax_ce_partial_f32(logits->device_data(), (int64_t)shp[1], target->device_data(), (int64_t)shp[0], (int32_t)shp[1],
+                                               n_total > 0 ? n_total : (int64_t)shp[0], nullptr, d->device_out(), (int64_t)shp[1], nullptr,
+                                               detail::workspace(wsb), wsb, st), "cross_entropy");
         const float up = g->item();  // upstream scalar (1 for loss->backward())
         if (up != 1.0f) {
             auto scaled = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
@@ -500,6 +503,16 @@ public:
     }
 };
 }  // namespace
+
+tptr<float> cross_entropy_loss(const tptr<float> logits, const tptr<int> target, size_t n_total)
+{
+    auto op = std::make_unique<CrossEntropyOp>();
+    op->n_total = (int64_t)n_total;
+    if (n_total != 0 && n_total < logits->shape()[0]) throw std::runtime_error(ERROR_SIZE_MISMATCH);
+    auto out = op->forward(logits, target);
+    if (out->requires_grad()) out->grad_fn = std::move(op);
+    return out;
+}
 
 tptr<float> cross_entropy_loss(const tptr<float> logits, const tptr<int> target)
 {
