@@ -674,7 +674,7 @@ def test_batchnorm_relu_backward_vs_float64(env, n, F, relu, bn):
         assert np.array_equal(host(dX), g.astype(np.float32))
 
 
-@pytest.mark.parametrize("n,F", [(50001, 256), (7000, 100), (4099, 1024), (3000, 8)])
+@pytest.mark.parametrize("n,F", [(50001, 256), (7000, 100), (4099, 1024), (3000, 8), (2003, 1020), (5, 12)])
 def test_batchnorm_backward_vector_kernels_equal_the_scalar_ones(env, n, F):
     """The 16-bytes-per-lane forms of the two backward passes (taken for 16-byte aligned operands, F % 4 == 0) against the scalar
     kernels (forced by an odd leading dimension): dX bit for bit -- the element arithmetic is the same, given the same sums --
@@ -719,7 +719,7 @@ def test_batchnorm_backward_vector_kernels_equal_the_scalar_ones(env, n, F):
     assert torch.equal(ops.bn_relu_bwd(Y, Y, dY, relu=True)[0], ops.bn_relu_bwd(odd(Y), odd(Y), odd(dY), relu=True)[0])
 
 
-@pytest.mark.parametrize("n,F", [(40003, 256), (9000, 100), (513, 1024), (3000, 8)])
+@pytest.mark.parametrize("n,F", [(40003, 256), (9000, 100), (513, 1024), (3000, 8), (2003, 1020), (5, 12)])
 def test_streaming_elementwise_vector_kernels_equal_the_scalar_ones(env, n, F):
     """The 16-bytes-per-thread forms of the broadcast binary ops (rowscale / bias-add are two of them), the row sum and the
     BatchNorm forward apply, against the scalar kernels (forced by an odd leading dimension or a misaligned base): bit for bit."""
