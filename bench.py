@@ -73,6 +73,69 @@ def profiled_traffic(workload, kernel_substr):
     return best
 
 
+_ceil_lib = None
+
+
+def _ceilings_lib():
+    """bench_kernels/libbench_ceilings.so: the two measurement kernels (float4 copy, whole-row gather).  Measurement only."""
+    global _ceil_lib
+    if _ceil_lib is None:
+        path = os.path.join(ROOT, "bench_kernels", "libbench_ceilings.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _ceil_lib = C.CDLL(path)
+        _ceil_lib.ceil_copy_f4.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _ceil_lib.ceil_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    return _ceil_lib
+
+
+def _timed_ms(capi, fn, reps=5, warmup=2):
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(warmup):
+        fn(stream)
+    a, b = capi.Event(), capi.Event()
+    a.record(stream)
+    for _ in range(reps):
+        fn(stream)
+    b.record(stream)
+    b.sync()
+    return a.elapsed_ms(b) / reps
+
+
+def copy_ceiling(capi, dev, gib=4):
+    """float4 copy of `gib` GiB (read + written bytes / time), GB/s."""
+    L = _ceilings_lib()
+    n = gib * 2 ** 30 // 4
+    src = torch.full((n,), 1.0, dtype=torch.float32, device=dev)
+    dst = torch.empty_like(src)
+    ms = _timed_ms(capi, lambda st: L.ceil_copy_f4(src.data_ptr(), dst.data_ptr(), n * 4, st))
+    return 2 * n * 4 / (ms * 1e-3) / 1e9
+
+
+def gather_ceiling(capi, dev, table_mb=160, deg=8, gathered_gb=16):
+    """Sum of `deg` uniformly random whole 1-KiB rows of a `table_mb` MB table per streamed output row: (gathered + index + written)
+    bytes / time, GB/s.  With the table inside the 256 MiB Infinity Cache this is what the fabric behind L2 delivers to a row gather."""
+    L = _ceilings_lib()
+    rows = table_mb * 2 ** 20 // 1024
+    n_out = int(gathered_gb * 1e9 / 1024 / deg)
+    table = torch.full((rows, 256), 1.0, dtype=torch.float32, device=dev)
+    idx = torch.randint(0, rows, (n_out * deg,), dtype=torch.int32, device=dev)
+    out = torch.empty((n_out, 256), dtype=torch.float32, device=dev)
+    ms = _timed_ms(capi, lambda st: L.ceil_gather_rows(table.data_ptr(), idx.data_ptr(), n_out, deg, out.data_ptr(), st))
+    return (n_out * deg * 1024 + n_out * deg * 4 + n_out * 1024) / (ms * 1e-3) / 1e9
+
+
+def measure_ceilings(capi, dev, verbose=False):
+    """The in-run ceilings of the roofline line (N = 1, outside the timed region, a few ms of kernels each)."""
+    c = {"hbm_copy_GBps": copy_ceiling(capi, dev),
+         "fabric_gather_GBps": gather_ceiling(capi, dev, table_mb=160, deg=8),
+         "fabric_gather": "sum of 8 uniformly random 1-KiB rows of a 160 MB table (Infinity-Cache resident) per streamed output row; "
+                          "gathered + index + written bytes / time (bench_kernels/ceilings.hip)",
+         "hbm_copy": "float4 copy of 4 GiB, read + written bytes / time"}
+    torch.cuda.empty_cache()
+    return c
+
+
 def spmm_bytes(n_rows, n_cols_rows_written, nnz, F, bias=True):
     """Algorithmic bytes of one SpMM launch, Mode REF: rowptr + colidx + one neighbour
     row per edge + rowscale + Y write (+ bias)."""
@@ -85,7 +148,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="rmat10m_100m_f256", choices=sorted(WORKLOADS))
-    ap.add_argument("--chunk", type=int, default=4096, help="plan: split rows longer than this (0 = never)")
+    ap.add_argument("--chunk", type=int, default=1024,
+                    help="plan: rows longer than this go to the sequential hub kernel (one accumulator per feature, the reference's order; 0 = no plan)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-layers", type=int, default=0,
                     help="N=1 only: time a whole training step of an L-layer GCN instead (forward, softmax-CE, backward, SGD); "
@@ -432,7 +496,7 @@ class SingleGpu:
         ops._ws_cache.clear()
         torch.cuda.empty_cache()
         return {"order": "as-generated", "steps": steps, "ms_per_step": ms, "spmm_fwd_ms": kt.get("spmm_fwd"), "spmm_bwd_ms": kt.get("spmm_bwd"),
-                "note": "same per-vertex bits as the default order (tests/test_gpu_parity.py::test_headline_config_relabelled_equals_as_generated)"}
+                "note": "same per-vertex bits as the default order (tests/test_gpu_parity.py::test_headline_config_whole_graph_vs_oracle)"}
 
     def kernel_times(self):
         out = {}

@@ -10,7 +10,9 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgnnx_hip.so")
+# GNNX_HIP_LIB=exp selects the measurement build (`make -C gnn.cpp_amd/csrc EXPERIMENTS=1`: kernel variants and environment switches
+# for scripts/exp_*.py); tests, smoke and bench.py use the product library
+LIB_PATH = os.path.join(_HERE, "libgnnx_hip_exp.so" if os.environ.get("GNNX_HIP_LIB") == "exp" else "libgnnx_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "gnnx.h")
 
 _lib = None

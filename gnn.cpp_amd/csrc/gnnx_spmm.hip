@@ -14,11 +14,15 @@
 //     rounded fp32 adds => bit-identical to the reference's sequential dense dot product;
 //   * at G = 64 the row is wave-uniform: rowptr/colidx are fetched with scalar loads, the row base
 //     address lives in SGPRs and the VMEM unit sees only the feature traffic;
-//   * power-law rows: an optional plan cuts rows longer than `chunk` into chunks that are gathered by
-//     separate wavefronts into a partial slab and combined in fixed chunk order by a second tiny kernel
-//     (deterministic; no float atomics).  Chunk items are placed first in the grid.
+//   * power-law rows: an optional plan hands rows longer than `chunk` to spmm_hub_kernel -- one wavefront per (row,
+//     64-feature slab), the neighbour rows' slices in flight in an LDS ring filled by LDS-DMA, ONE accumulator per feature
+//     in the reference's order -- and cuts the remaining rows into non-zero-balanced blocks for the streaming kernel.
+//     A planned aggregation is bit-identical to the unplanned one on every row.
+#include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/device/device_scan.hpp>
 
@@ -32,13 +36,10 @@ using namespace gnnx;
 struct gnnx_spmm_plan {
     int32_t n_rows = 0;
     int32_t chunk = 0;
-    int32_t max_feat = 0;
-    int32_t n_split_rows = 0;   // rows with degree > chunk
-    int32_t n_chunks = 0;       // total chunk items
-    int4 *d_items = nullptr;    // [n_chunks] {row, first nz, end nz, partial slot}
-    int4 *d_rows = nullptr;     // [n_split_rows] {row, first slot, n_chunks, 0}
-    float *d_partial = nullptr; // [n_chunks, max_feat]
-    int32_t *d_counters = nullptr;
+    int32_t n_split_rows = 0;   // rows with degree > chunk (the hub rows)
+    int64_t n_hub_nnz = 0;      // their non-zeros
+    int32_t *d_hub_rows = nullptr;  // [n_split_rows] the hub rows, longest first: work list of spmm_hub_kernel
+    unsigned long long *d_counters = nullptr;
     // non-zero-balanced row blocks for the streaming kernel: block k owns rows [d_block_starts[k], [k+1])
     int32_t block_nnz = 0;
     int32_t n_blocks = 0;
@@ -61,12 +62,9 @@ struct SpmmArgs {
     float *Y;
     int64_t ldy;
     int32_t beta;           // 0 or 1
-    int32_t split_threshold; // rows with degree > this are left to the chunk items (0 = none)
-    // chunk items (plan)
-    const int4 *items;
-    int32_t n_items;
-    float *partial;
-    int32_t partial_ld;
+    int32_t split_threshold; // rows with degree > this are left to the hub kernel (0 = none)
+    const int32_t *hub_rows; // the plan's hub rows, longest first
+    int32_t n_hub_rows;
     // row blocks of the streaming kernel (plan): nullptr => fixed blocks of StreamCfg<G>::R rows
     const int32_t *block_starts;
     int32_t n_blocks;
@@ -275,9 +273,9 @@ __device__ __forceinline__ void epilogue_store_pre(typename Vec<VEC>::type acc, 
     *dst = acc;
 }
 
-// grid.x = n_item_blocks + n_row_blocks ; grid.y = feature tiles of G*VEC features.
+// grid.x = row blocks ; grid.y = feature tiles of G*VEC features.
 template <int G, int VEC, int U, int MODE, class XT>
-__global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_blocks)
+__global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a)
 {
     constexpr int GROUPS = 256 / G;
     const int tid = threadIdx.x;
@@ -289,30 +287,14 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_bl
     const XT *xf = reinterpret_cast<const XT *>(a.X) + (active ? f0 : 0);  // lanes past n_feat read feature 0 and never store
     const ProConst<VEC> pc = pro_load<VEC, MODE>(a, f0, active);
 
-    if ((int32_t)blockIdx.x < n_item_blocks) {
-        // ---- chunk item of a long row: partial sum into the plan's slab
-        int32_t it = blockIdx.x * GROUPS + grp;
-        if (it >= a.n_items) return;
-        int4 item = a.items[it];
-        if constexpr (G == 64) {
-            item.x = __builtin_amdgcn_readfirstlane(item.x);
-            item.y = __builtin_amdgcn_readfirstlane(item.y);
-            item.z = __builtin_amdgcn_readfirstlane(item.z);
-            item.w = __builtin_amdgcn_readfirstlane(item.w);
-        }
-        auto acc = gather_range<G, VEC, U, MODE>(item.y, item.z, xf, li, a, pc);
-        if (active) *reinterpret_cast<typename Vec<VEC>::type *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
-        return;
-    }
-
-    int32_t row = (blockIdx.x - n_item_blocks) * GROUPS + grp;
+    int32_t row = blockIdx.x * GROUPS + grp;
     if (row >= a.n_rows) return;
     int32_t b = a.rowptr[row], e = a.rowptr[row + 1];
     if constexpr (G == 64) {
         b = __builtin_amdgcn_readfirstlane(b);
         e = __builtin_amdgcn_readfirstlane(e);
     }
-    if (a.split_threshold > 0 && e - b > a.split_threshold) return;  // handled by chunk items + combine
+    if (a.split_threshold > 0 && e - b > a.split_threshold) return;  // a hub row: spmm_hub_kernel owns it
     auto acc = gather_range<G, VEC, U, MODE>(b, e, xf, li, a, pc);
     if (active) epilogue_store<VEC>(acc, row, f0, a);
 }
@@ -327,7 +309,7 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a, int32_t n_item_bl
 //   * rowptr of the block: one coalesced load, kept one entry per lane, read back with bcast();
 //   * colidx (+ colscale / vals): one coalesced load per G non-zeros, the next chunk prefetched;
 //   * no load is predicated (see gather_batch): the last batch of a block re-reads an in-range row;
-//   * rows longer than the plan's threshold are skipped here (chunk items + combine kernel own them): the
+//   * rows longer than the plan's threshold are skipped here (spmm_hub_kernel owns them): the
 //     block is cut into segments of consecutive non-hub rows with a ballot mask.
 // At G == 64 every control decision is wave-uniform (SALU + s_cbranch); at G == 32 the two half-waves
 // stream independent blocks under the EXEC mask.
@@ -454,7 +436,7 @@ struct Stream {
 };
 
 template <int G, int VEC, int B, int MODE, int TPB, class XT>
-__global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_item_blocks)
+__global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a)
 {
     constexpr int GROUPS = TPB / G;
     constexpr int R = StreamCfg<G>::R;
@@ -467,21 +449,7 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     const XT *xf = reinterpret_cast<const XT *>(a.X) + (active ? f0 : 0);
     const ProConst<VEC> pc = pro_load<VEC, MODE>(a, f0, active);
 
-    if ((int32_t)blockIdx.x < n_item_blocks) {  // chunk item of a hub row -> partial slab (same as spmm_kernel)
-        int32_t it = blockIdx.x * GROUPS + grp;
-        if (it >= a.n_items) return;
-        int4 item = a.items[it];
-        if constexpr (G == 64) {
-            item.y = __builtin_amdgcn_readfirstlane(item.y);
-            item.z = __builtin_amdgcn_readfirstlane(item.z);
-            item.w = __builtin_amdgcn_readfirstlane(item.w);
-        }
-        auto acc = gather_range<G, VEC, 8, MODE>(item.y, item.z, xf, li, a, pc);
-        if (active) *reinterpret_cast<typename Vec<VEC>::type *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
-        return;
-    }
-
-    const int32_t blk = (blockIdx.x - n_item_blocks) * GROUPS + grp;
+    const int32_t blk = blockIdx.x * GROUPS + grp;
     int32_t r0, nr;
     if (a.block_starts) {  // non-zero-balanced blocks of the plan (at most kPlanBlockRows <= R rows each)
         if (blk >= a.n_blocks) return;
@@ -504,7 +472,7 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     const float rs_l = a.rowscale ? a.rowscale[r0 + (li < nr ? li : nr - 1)] : 1.f;
     Stream<G, VEC, B, MODE, XT> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)], rs_l, bias_v, pc};
 
-    uint64_t hub = 0;  // bit l: local row l is a hub (left to the chunk items)
+    uint64_t hub = 0;  // bit l: local row l is a hub (left to spmm_hub_kernel)
     if (a.split_threshold > 0) {
         const int32_t nxt = __shfl(st.rp_l, (tid & 63) + 1, 64);  // lane li+1 (li < nr < G: inside the group)
         const uint64_t m = __ballot(li < nr && nxt - st.rp_l > a.split_threshold);
@@ -521,183 +489,261 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a, int32_t n_
     }
 }
 
-#ifdef GNNX_EXPERIMENTS
-// ---- LDS-staged variant (measurement only: GNNX_SPMM_VARIANT=lds, F = 256, forward mode) ---------------------------
-// Same streaming structure, but the neighbour rows land in LDS through LDS-DMA (global_load_lds_dwordx4: one 1-KiB
-// row per wave-instruction, per-lane source address = a row gather) and are summed from there, B = 16 rows per batch,
-// two batches of slots per wavefront (the BASELINE north_star's "LDS staging of feature tiles").  No VGPRs are spent on
-// rows in flight; a row is still consumed by one wavefront only, i.e. LDS adds a write + a read per byte and shares
-// nothing.  Kept to put a number on that choice.  LDS reads go through inline asm: behind a
-// pending LDS-DMA hipcc would otherwise insert s_waitcnt vmcnt(0) in front of every ds_read and drain the pipeline.
+
+// ---- hub rows in the reference's order ---------------------------------------------------------------------------------
+// A row of 10^4..10^5 non-zeros summed by ONE accumulator per feature, top column first -- the reference's
+// `(r_slice * l_slice).sum()` (functional.h:433-439) -- is a chain of dependent adds fed by a gather: with the 16 neighbour rows a
+// streaming wavefront keeps in flight in registers it is latency-bound (tens of ms for the longest row of the RMAT 10M graph).
+// Here nothing in flight lives in a register: a wavefront owns (hub row, 64-feature slab), lane l is feature slab*64 + l, and the
+// slab's 256-byte slices of the neighbour rows land in an LDS ring by LDS-DMA (global_load_lds_dwordx4: 16 lanes per slice, four
+// neighbours per wave-instruction, two whole 128-byte lines each), LAS sub-chunks of 16 neighbours ahead of the adds (LAS = 8:
+// 128 neighbours = 32 KB in flight per wavefront, 4 wavefronts per CU).  The consumer side is one conflict-free ds_read_b32 and one
+// add per neighbour, strictly in descending column order: bit-identical to the unsplit row whatever the degree.  Nothing is shared
+// between wavefronts: no barrier, no atomics, no partial slab, no combine pass.
+//   * indices (and per-entry values / gathered column scales) travel the same way: one 256-byte LDS-DMA per 64 neighbours (the
+//     index chunk) into a small ring, 2 DI + 1 chunks ahead of the adds, so that by the time a DMA lane reads its neighbour's
+//     column from LDS the chunk is older than every wait below;
+//   * every wait is counted by hand: s_waitcnt vmcnt(LAS * IPS) after an issue leaves the LAS youngest sub-chunks in flight
+//     (VMEM returns in order; the index DMAs in between only make the wait stricter), the tail drains with vmcnt(0);
+//   * all LDS reads go through inline asm: behind a pending LDS-DMA hipcc would put s_waitcnt vmcnt(0) in front of every ds_read,
+//     and a register load in flight across the loop's back edge gets copied (and waited for) by the register allocator.
+// Work items are (row, slab) pairs, rows longest first (gnnx_spmm_plan_create sorts them).
 typedef __attribute__((address_space(3))) void lds_void_t;
-typedef float f32x4_lds __attribute__((ext_vector_type(4)));
+constexpr int kHubSlab = 64;   // features per work item
+constexpr int kHubSub = 16;    // neighbours per sub-chunk: 4 KiB of LDS
+constexpr int kHubChunk = 64;  // neighbours per index chunk
 
-template <int B>
-__global__ __launch_bounds__(64) void spmm_lds_kernel(SpmmArgs a, int32_t n_item_blocks)
+template <int OFF, class T>
+__device__ __forceinline__ void hub_lds_read(T &dst, uint32_t addr)
 {
-    constexpr int G = 64, VEC = 4;
-    __shared__ float lds[2 * B * 256];
-    const int li = threadIdx.x;
-    const int32_t f0 = li * VEC;
-    const float *xf = a.X + f0;
-    if ((int32_t)blockIdx.x < n_item_blocks) {
-        int32_t it = blockIdx.x;
-        if (it >= a.n_items) return;
-        int4 item = a.items[it];
-        item.y = __builtin_amdgcn_readfirstlane(item.y);
-        item.z = __builtin_amdgcn_readfirstlane(item.z);
-        item.w = __builtin_amdgcn_readfirstlane(item.w);
-        auto acc = gather_range<G, VEC, 8, 0>(item.y, item.z, xf, li, a, ProConst<VEC>{});
-        *reinterpret_cast<float4 *>(a.partial + (int64_t)item.w * a.partial_ld + f0) = acc;
-        return;
-    }
-    const int32_t blk = blockIdx.x - n_item_blocks;
-    int32_t r0, nr;
-    if (a.block_starts) {
-        if (blk >= a.n_blocks) return;
-        r0 = __builtin_amdgcn_readfirstlane(a.block_starts[blk]);
-        nr = __builtin_amdgcn_readfirstlane(a.block_starts[blk + 1]) - r0;
-    } else {
-        constexpr int R = StreamCfg<G>::R;
-        const int64_t r0l = (int64_t)blk * R;
-        if (r0l >= a.n_rows) return;
-        r0 = (int32_t)r0l;
-        nr = a.n_rows - r0 < R ? a.n_rows - r0 : R;
-    }
-    const int32_t rp_l = a.rowptr[r0 + (li < nr ? li : nr)];
-    const float rs_l = a.rowscale ? a.rowscale[r0 + (li < nr ? li : nr - 1)] : 1.f;
-    float4 bias_v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a.bias) bias_v = *reinterpret_cast<const float4 *>(a.bias + f0);
-    auto rp = [&](int l) { return __builtin_amdgcn_readlane(rp_l, l); };
-    auto flush = [&](float4 &acc, int r) {
-        const float rs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rs_l), r));
-        epilogue_store_pre<VEC>(acc, r0 + r, f0, a, a.rowscale != nullptr, rs, a.bias != nullptr, bias_v);
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    uint64_t hub = 0;
-    if (a.split_threshold > 0) {
-        const int32_t nxt = __shfl(rp_l, li + 1, 64);
-        hub = __ballot(li < nr && nxt - rp_l > a.split_threshold);
-    }
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_void_t *)lds + (uint32_t)f0 * 4u;  // this lane's 16 bytes of slot 0
-    auto issue = [&](int buf, int32_t chunk_c, int k0) {
-#pragma unroll
-        for (int u = 0; u < B; u++) {
-            const int32_t c = __builtin_amdgcn_readlane(chunk_c, k0 + u);
-            __builtin_amdgcn_global_load_lds(xf + (int64_t)c * a.ldx, (lds_void_t *)(lds + (buf * B + u) * 256), 16, 0, 0);
-        }
-    };
-    int sa = 0;
-    while (sa < nr) {
-        const uint64_t rest = hub >> sa;
-        if (rest & 1) { sa++; continue; }
-        const int run = rest ? __builtin_ctzll(rest) : 64;
-        const int sb = sa + run < nr ? sa + run : nr;
-        const int32_t lo = rp(sa), hi = rp(sb);
-        const int32_t total = hi - lo;
-        int r = sb - 1;
-        int32_t rs = rp(r);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (total > 0) {
-            auto fetch = [&](int cidx) {
-                int32_t q = hi - 1 - (cidx * G + li);
-                return a.colidx[q < lo ? lo : q];
-            };
-            int32_t cur = fetch(0), nxt = fetch(1);
-            int cidx = 1, buf = 0;
-            issue(0, cur, 0);
-            for (int32_t e = 0; e < total; e += B) {
-                const int kn = (e + B) % G;
-                if (kn == 0) { cur = nxt; cidx++; nxt = fetch(cidx); }
-                issue(buf ^ 1, cur, kn);  // batch e+B in flight (clamped past the end: an in-range row, never added)
-                // all but the B DMAs just issued have completed: batch e is in LDS (and older stores have left)
-                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-#pragma unroll
-                for (int u0 = 0; u0 < B; u0 += 4) {
-                    f32x4_lds v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(v[j]) : "v"(lds_base + (uint32_t)((buf * B + u0 + j) * 1024)) : "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int u = u0 + j;
-                        if (e + u < total) {
-                            const int32_t q = hi - 1 - (e + u);
-                            while (q < rs) {
-                                flush(acc, r);
-                                r--;
-                                rs = rp(r);
-                            }
-                            acc = add_rn(acc, make_float4(v[j].x, v[j].y, v[j].z, v[j].w));
-                        }
-                    }
-                }
-                buf ^= 1;
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the over-issued tail batch must land before its slots are reused
-        }
-        while (r >= sa) {
-            flush(acc, r);
-            r--;
-        }
-        sa = sb;
-    }
+    static_assert(sizeof(T) == 4 && OFF >= 0 && OFF < 65536, "one dword, 16-bit immediate offset");
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
 }
-
-#endif  // GNNX_EXPERIMENTS
-
-// Combine the partial slabs of split rows in chunk order (chunk 0 holds the HIGHEST columns), then the
-// same epilogue as the main kernel.  One G-lane group per split row.
-template <int G, int VEC>
-__global__ __launch_bounds__(256) void spmm_combine_kernel(SpmmArgs a, const int4 *rows, int32_t n_split)
+// one feature of a neighbour's slice as stored: an f32 word, or a bf16 halfword (zero-extended; widened after the wait)
+template <int OFF, class XT>
+__device__ __forceinline__ void hub_lds_read_x(float &dst, uint32_t addr)
 {
-    constexpr int GROUPS = 256 / G;
-    const int li = threadIdx.x % G;
-    const int grp = threadIdx.x / G;
-    const int32_t f0 = (blockIdx.y * G + li) * VEC;
-    int32_t k = blockIdx.x * GROUPS + grp;
-    if (k >= n_split || f0 + VEC > a.n_feat) return;
-    using V = typename Vec<VEC>::type;
-    int4 r = rows[k];
-    V acc = ld_vec(reinterpret_cast<const V *>(a.partial + (int64_t)r.y * a.partial_ld + f0));
-    for (int32_t c = 1; c < r.z; c++)
-        acc = add_rn(acc, ld_vec(reinterpret_cast<const V *>(a.partial + (int64_t)(r.y + c) * a.partial_ld + f0)));
-    epilogue_store<VEC>(acc, r.x, f0, a);
+    if constexpr (sizeof(XT) == 4) hub_lds_read<OFF>(dst, addr);
+    else asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void hub_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+// DMA shapes (bytes per lane / lanes per 64-feature slice / neighbours per wave-instruction):
+//   f32 rows, 16-byte aligned (VEC 4): 16 / 16 / 4      f32 rows, any alignment (VEC 1): 4 / 64 / 1
+//   bf16 rows, 8-byte aligned (VEC 4):  4 / 32 / 2      bf16 rows, any alignment (VEC 1): 2 / 64 / 1
+template <int VEC, int MODE, int LAS, class XT>
+struct HubCfg {
+    static constexpr int EB = (int)sizeof(XT);          // bytes per stored feature
+    static constexpr int DS = VEC == 4 ? (EB == 4 ? 16 : 4) : EB;  // bytes per lane of one DMA instruction
+    static constexpr int SB = kHubSlab * EB;            // bytes of a neighbour's slice (= its stride in the ring)
+    static constexpr int EPI = 64 * DS / SB;            // neighbours per DMA wave-instruction
+    static constexpr int LPE = 64 / EPI;                // lanes per neighbour
+    static constexpr int FPL = DS / EB;                 // features per lane of a DMA instruction
+    static constexpr int IPS = kHubSub / EPI;           // DMA instructions per sub-chunk
+    static constexpr int IFLOATS = 64 * DS / 4;         // floats of LDS one DMA instruction fills
+    static constexpr int SUB_FLOATS = kHubSub * SB / 4; // floats of a ring slot
+    static constexpr int NS = LAS + 1;                  // ring slots: LAS in flight + the one being added
+    static constexpr int SUBS = kHubChunk / kHubSub;    // sub-chunks per index chunk
+    static constexpr int DI = (LAS + SUBS - 1) / SUBS;  // furthest index chunk (relative to the one being added) an issue reaches
+    static constexpr int NC = 2 * DI + 1;               // index chunks fetched ahead: DI whole iterations older than their first use
+    static constexpr int NI = NC + 1;                   // index ring slots (the chunk being added is still read for its values)
+    static constexpr int RING = NS * SUB_FLOATS;                          // floats
+    static constexpr int IR = RING;                                       // column indices
+    static constexpr int VR = IR + NI * kHubChunk;                        // per-entry values (MODE 2 / 6)
+    static constexpr int SR = VR + (has_val(MODE) ? NI * kHubChunk : 0);  // gathered column scales (MODE 1 / 6)
+    static constexpr int LDS_FLOATS = SR + (has_sc(MODE) ? NI * kHubChunk : 0);
+    static_assert(LAS * IPS <= 60, "vmcnt is a 6-bit counter");
+    static_assert(SUBS * DI * IPS >= LAS * IPS, "an index chunk must be older than the counted wait when it is first read");
+};
+
+template <int VEC, int MODE, int LAS, class XT>
+__global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t *hub_rows, int32_t n_slabs, int32_t n_groups)
+{
+    using K = HubCfg<VEC, MODE, LAS, XT>;
+    constexpr int EPI = K::EPI, IPS = K::IPS, NS = K::NS, SUBS = K::SUBS, DI = K::DI, NC = K::NC, NI = K::NI;
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    // a workgroup = the slabs of one row (up to 4 wavefronts, each with a ring of its own): nothing is shared and there is no
+    // barrier, but wavefronts that start together and do the same work ask for the pieces of a neighbour row at about the same time
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    float *lds = lds_all + wv * K::LDS_FLOATS;
+    const int lane = threadIdx.x & 63;
+    const int32_t row = __builtin_amdgcn_readfirstlane(hub_rows[blockIdx.x / n_groups]);
+    const int32_t slab = (int32_t)(blockIdx.x % n_groups) * (int32_t)(blockDim.x >> 6) + wv;
+    if (slab >= n_slabs) return;
+    const int32_t f_slab = slab * kHubSlab;
+    const int32_t lo = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
+    const int32_t hi = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
+    const int32_t total = hi - lo;
+    const int32_t nsub = (total + kHubSub - 1) / kHubSub;
+    const int32_t f = f_slab + lane;
+    const bool active = f < a.n_feat;
+    // DMA source of this lane: neighbour sub_e of the instruction, FPL features at feature foff.  Lanes past the row's width
+    // re-read the slab's first piece (never a byte outside the row); their LDS words are never stored.
+    const int sub_e = lane / K::LPE;
+    int32_t foff = f_slab + (lane % K::LPE) * K::FPL;
+    if (foff + K::FPL > a.n_feat) foff = f_slab;
+    const XT *xsrc = reinterpret_cast<const XT *>(a.X) + foff;
+    const ProConst<1> pc = pro_load<1, MODE>(a, active ? f : 0, active);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t *)lds;
+    const uint32_t ring_lane = lds0 + (uint32_t)lane * (uint32_t)K::EB;            // this lane's feature of slice 0, slot 0
+    const uint32_t col_lane = lds0 + (uint32_t)(K::IR + sub_e) * 4u;               // index slot 0, this lane's neighbour of instruction 0
+    const uint32_t val_lane = lds0 + (uint32_t)(K::VR + (lane & 15)) * 4u;         // one value per lane 0..15 (read back by v_readlane)
+    const uint32_t sc_lane = lds0 + (uint32_t)(K::SR + (lane & 15)) * 4u;
+
+    auto idx_dma = [&](int32_t chunk, int islot) {  // index chunk -> ring slot: lane i brings neighbour chunk*64 + i (clamped into the row)
+        int32_t q = hi - 1 - (chunk * kHubChunk + lane);
+        q = q < lo ? lo : q;
+        __builtin_amdgcn_global_load_lds(a.colidx + q, (lds_void_t *)(lds + K::IR + islot * kHubChunk), 4, 0, 0);
+        if constexpr (has_val(MODE)) __builtin_amdgcn_global_load_lds(a.vals + q, (lds_void_t *)(lds + K::VR + islot * kHubChunk), 4, 0, 0);
+    };
+    auto sc_dma = [&](int islot) {  // colscale[col] of an index chunk that has landed
+        int32_t c;
+        hub_lds_read<0>(c, lds0 + (uint32_t)(K::IR + islot * kHubChunk + lane) * 4u);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c)::"memory");
+        __builtin_amdgcn_global_load_lds(a.colscale + c, (lds_void_t *)(lds + K::SR + islot * kHubChunk), 4, 0, 0);
+    };
+    auto issue = [&](int slot, int islot, int k0) {  // sub-chunk = neighbours k0 .. k0+15 of the index chunk in ring slot islot
+        float *dst = lds + slot * K::SUB_FLOATS;
+        const uint32_t ca = col_lane + (uint32_t)(islot * kHubChunk + k0) * 4u;
+        int32_t c[16];  // IPS of them are used
+#define GNNX_HUB_RC(i) if constexpr ((i) < IPS) hub_lds_read<(i) * EPI * 4>(c[i], ca)
+        GNNX_HUB_RC(0); GNNX_HUB_RC(1); GNNX_HUB_RC(2); GNNX_HUB_RC(3); GNNX_HUB_RC(4); GNNX_HUB_RC(5); GNNX_HUB_RC(6); GNNX_HUB_RC(7);
+        GNNX_HUB_RC(8); GNNX_HUB_RC(9); GNNX_HUB_RC(10); GNNX_HUB_RC(11); GNNX_HUB_RC(12); GNNX_HUB_RC(13); GNNX_HUB_RC(14); GNNX_HUB_RC(15);
+#undef GNNX_HUB_RC
+        static_assert(IPS == 4 || IPS == 8 || IPS == 16, "DMA instructions per sub-chunk");
+        if constexpr (IPS == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])::"memory");
+        else if constexpr (IPS == 8)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7])::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]),
+                           "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15])::"memory");
+#pragma unroll
+        for (int i = 0; i < IPS; i++) {
+            const XT *srcp = xsrc + (int64_t)c[i] * a.ldx;
+            lds_void_t *dstp = (lds_void_t *)(dst + i * K::IFLOATS);
+            // (a source pointer of DEPENDENT type makes clang drop the whole instantiation without a diagnostic when the size is
+            // 16: the kernel's symbol stays undefined -- hence the casts; tests/test_cabi_cpu.py runs `ldd -r` on the library)
+            if constexpr (K::DS == 16) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(srcp), dstp, 16, 0, 0);
+            else if constexpr (K::DS == 4) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(srcp), dstp, 4, 0, 0);
+            else __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint16_t *>(srcp), dstp, 2, 0, 0);
+        }
+    };
+    float acc = 0.f;
+    auto add1 = [&](float x, float scv, float vv, int src) {
+        if constexpr (has_pro(MODE)) x = pro_apply<MODE>(x, pc);
+        if constexpr (has_sc(MODE)) x = mul_rn(x, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scv), src)));
+        if constexpr (has_val(MODE)) x = mul_rn(x, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), src)));
+        acc = add_rn(acc, x);
+    };
+    auto consume = [&](int slot, int islot, int32_t cnt, int k0) {
+        const uint32_t ad = ring_lane + (uint32_t)slot * (uint32_t)(K::SUB_FLOATS * 4);
+        float v[kHubSub], vv = 1.f, scv = 1.f;
+        if constexpr (has_val(MODE)) hub_lds_read<0>(vv, val_lane + (uint32_t)(islot * kHubChunk + k0) * 4u);
+        if constexpr (has_sc(MODE)) hub_lds_read<0>(scv, sc_lane + (uint32_t)(islot * kHubChunk + k0) * 4u);
+        hub_lds_read_x<0 * K::SB, XT>(v[0], ad);
+        hub_lds_read_x<1 * K::SB, XT>(v[1], ad);
+        hub_lds_read_x<2 * K::SB, XT>(v[2], ad);
+        hub_lds_read_x<3 * K::SB, XT>(v[3], ad);
+        hub_lds_read_x<4 * K::SB, XT>(v[4], ad);
+        hub_lds_read_x<5 * K::SB, XT>(v[5], ad);
+        hub_lds_read_x<6 * K::SB, XT>(v[6], ad);
+        hub_lds_read_x<7 * K::SB, XT>(v[7], ad);
+        hub_lds_read_x<8 * K::SB, XT>(v[8], ad);
+        hub_lds_read_x<9 * K::SB, XT>(v[9], ad);
+        hub_lds_read_x<10 * K::SB, XT>(v[10], ad);
+        hub_lds_read_x<11 * K::SB, XT>(v[11], ad);
+        hub_lds_read_x<12 * K::SB, XT>(v[12], ad);
+        hub_lds_read_x<13 * K::SB, XT>(v[13], ad);
+        hub_lds_read_x<14 * K::SB, XT>(v[14], ad);
+        hub_lds_read_x<15 * K::SB, XT>(v[15], ad);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(vv), "+v"(scv)::"memory");
+        if constexpr (sizeof(XT) == 2) {  // a bf16 is the top half of an f32: widening is exact
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++) v[j] = __uint_as_float(__float_as_uint(v[j]) << 16);
+        }
+        if (cnt >= kHubSub) {
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++) add1(v[j], scv, vv, j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++)
+                if (j < cnt) add1(v[j], scv, vv, j);
+        }
+    };
+    auto wrap = [](int x) { return x >= NI ? x - NI : x; };
+
+    // prologue: the first NC index chunks, then (once they have landed) their column scales and the first LAS sub-chunks
+#pragma unroll
+    for (int k = 0; k < NC; k++) idx_dma(k, k);
+    hub_wait_vm<0>();
+    if constexpr (has_sc(MODE)) {
+#pragma unroll
+        for (int k = 0; k <= DI; k++) sc_dma(k);
+    }
+#pragma unroll
+    for (int p = 0; p < LAS; p++)
+        if (p < nsub) issue(p, p / SUBS, (p % SUBS) * kHubSub);
+    int slot_i = LAS, slot_c = 0, islot_c = 0;  // LAS < NS
+    const int32_t nchunk = (nsub + SUBS - 1) / SUBS;
+    for (int32_t cc = 0; cc < nchunk; cc++) {
+#pragma unroll
+        for (int u = 0; u < SUBS; u++) {
+            const int32_t t = cc * SUBS + u;
+            if (t < nsub) {
+                if (t + LAS < nsub) {
+                    issue(slot_i, wrap(islot_c + (u + LAS) / SUBS), ((u + LAS) % SUBS) * kHubSub);
+                    slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
+                    hub_wait_vm<LAS * IPS>();  // sub-chunk t has landed; the LAS younger ones stay in flight
+                } else {
+                    hub_wait_vm<0>();
+                }
+                consume(slot_c, islot_c, total - t * kHubSub, u * kHubSub);
+                slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
+            }
+        }
+        // index chunk cc + NC into the slot chunk cc - 1 has left; column scales of chunk cc + DI + 1, whose indices landed DI
+        // iterations ago and whose adds are DI + 1 iterations away
+        idx_dma(cc + NC, wrap(islot_c + NC));
+        if constexpr (has_sc(MODE)) sc_dma(wrap(islot_c + DI + 1));
+        islot_c = wrap(islot_c + 1);
+    }
+    hub_wait_vm<0>();  // index DMAs past the end of the row
+    if (active) {  // the epilogue of epilogue_store<1>, same op order
+        float v = acc;
+        if (a.rowscale) v = mul_rn(v, a.rowscale[row]);
+        if (a.bias) v = add_rn(v, a.bias[f]);
+        float *dst = a.Y + (int64_t)row * a.ldy + f;
+        if (a.beta) v = add_rn(*dst, v);
+        if (a.relu_out) v = relu1(v);
+        *dst = v;
+    }
 }
 
 // ---- plan construction -------------------------------------------------------------------------
-__global__ void plan_count_kernel(const int32_t *rowptr, int32_t n_rows, int32_t chunk, int32_t *counters)
+// hub rows: count, then list as {row, degree} (positions by atomics; the host sorts the list, so its order does not matter)
+__global__ void plan_count_kernel(const int32_t *rowptr, int32_t n_rows, int32_t chunk, unsigned long long *counters)
 {
     int32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     int32_t deg = rowptr[row + 1] - rowptr[row];
     if (deg > chunk) {
-        atomicAdd(&counters[0], 1);
-        atomicAdd(&counters[1], (deg + chunk - 1) / chunk);
+        atomicAdd(&counters[0], 1ull);
+        atomicAdd(&counters[1], (unsigned long long)deg);
     }
 }
 
-__global__ void plan_fill_kernel(const int32_t *rowptr, int32_t n_rows, int32_t chunk, int32_t *counters, int4 *items,
-                                 int4 *rows)
+__global__ void plan_fill_kernel(const int32_t *rowptr, int32_t n_rows, int32_t chunk, unsigned long long *counters, int2 *rows)
 {
     int32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
-    int32_t b = rowptr[row], e = rowptr[row + 1];
-    int32_t deg = e - b;
+    int32_t deg = rowptr[row + 1] - rowptr[row];
     if (deg <= chunk) return;
-    int32_t nc = (deg + chunk - 1) / chunk;
-    int32_t k = atomicAdd(&counters[2], 1);
-    int32_t slot = atomicAdd(&counters[3], nc);
-    rows[k] = make_int4(row, slot, nc, 0);
-    // chunk 0 = the highest columns, so that chunk order == descending column order
-    int32_t hi = e;
-    for (int32_t c = 0; c < nc; c++) {
-        int32_t lo = hi - chunk < b ? b : hi - chunk;
-        items[slot + c] = make_int4(row, lo, hi, slot + c);
-        hi = lo;
-    }
+    rows[atomicAdd(&counters[2], 1ull)] = make_int2(row, deg);
 }
 
 // GNNX_SPMM_VARIANT=rows forces the one-row-per-group kernel everywhere (A/B measurements); default: the
@@ -712,12 +758,6 @@ bool use_stream_kernel(int G)
     if (forced == 1) return false;
     if (forced == 2) return G >= 8;
     return G >= 32;
-}
-
-bool use_lds_variant()
-{
-    static const bool v = [] { const char *e = experiment_env("GNNX_SPMM_VARIANT"); return e && strcmp(e, "lds") == 0; }();
-    return v;
 }
 
 // Row r opens a new block when it starts a new group of kPlanBlockRows rows or when its first non-zero falls
@@ -743,10 +783,59 @@ __global__ void plan_block_fill_kernel(const int32_t *flag, const int32_t *pos, 
     starts[pos[r]] = r;
 }
 
-template <int G, int VEC, int U, int TPB>
-void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32_t n_item_blocks)
+template <int VEC, int MODE, class XT>
+int launch_hub_kernel(hipStream_t st, const SpmmArgs &a)
 {
-#define GNNX_STREAM(M, XT) hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, M, TPB, XT>), grid, dim3(TPB), 0, st, a, n_item_blocks)
+    // look-ahead in sub-chunks of 16 neighbours: 8 where a sub-chunk is 4 DMA instructions, less where it is 8 or 16 (vmcnt counts
+    // at most 63 operations)
+    constexpr int LAS = (VEC == 4 && sizeof(XT) == 4) ? 8 : (VEC == 4 ? 6 : 3);
+    using K = HubCfg<VEC, MODE, LAS, XT>;
+    static std::atomic<uint64_t> done{0};
+    constexpr size_t lds_wave = sizeof(float) * K::LDS_FLOATS;
+    constexpr int max_waves = 160 * 1024 / lds_wave < 4 ? (int)(160 * 1024 / lds_wave) : 4;
+    const int32_t n_slabs = (int32_t)ceil_div(a.n_feat, kHubSlab);
+    const int waves = n_slabs < max_waves ? n_slabs : max_waves;
+    const int32_t n_groups = (int32_t)ceil_div(n_slabs, waves);
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {  // dynamic-LDS opt-in, once per kernel and device
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hub_kernel<VEC, MODE, LAS, XT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_wave * max_waves)));
+        if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    const dim3 grid((uint32_t)((int64_t)a.n_hub_rows * n_groups));
+    const size_t lds_wg = lds_wave * waves;
+    hipLaunchKernelGGL((spmm_hub_kernel<VEC, MODE, LAS, XT>), grid, dim3(64 * waves), lds_wg, st, a, a.hub_rows, n_slabs, n_groups);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+template <int VEC>
+int launch_hub(int mode, hipStream_t st, const SpmmArgs &a)
+{
+    if (a.x_bf16) {  // bf16 feature rows: the three plain modes (a prologue goes with f32 rows)
+        switch (mode) {
+        case 0: return launch_hub_kernel<VEC, 0, bf16_t>(st, a);
+        case 1: return launch_hub_kernel<VEC, 1, bf16_t>(st, a);
+        case 2: return launch_hub_kernel<VEC, 2, bf16_t>(st, a);
+        default: return launch_hub_kernel<VEC, 6, bf16_t>(st, a);
+        }
+    }
+    switch (mode) {
+    case 0: return launch_hub_kernel<VEC, 0, float>(st, a);
+    case 1: return launch_hub_kernel<VEC, 1, float>(st, a);
+    case 2: return launch_hub_kernel<VEC, 2, float>(st, a);
+    case 3: return launch_hub_kernel<VEC, 3, float>(st, a);
+    case 4: return launch_hub_kernel<VEC, 4, float>(st, a);
+    case 5: return launch_hub_kernel<VEC, 5, float>(st, a);
+    default: return launch_hub_kernel<VEC, 6, float>(st, a);
+    }
+}
+
+template <int G, int VEC, int U, int TPB>
+void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a)
+{
+#define GNNX_STREAM(M, XT) hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, M, TPB, XT>), grid, dim3(TPB), 0, st, a)
     if (a.x_bf16) {  // bf16 feature rows: the three plain modes (a prologue goes with f32 rows)
         switch (mode) {
         case 0: GNNX_STREAM(0, bf16_t); break;
@@ -769,9 +858,9 @@ void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32
 }
 
 template <int G, int VEC, int U>
-void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a, int32_t n_item_blocks)
+void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a)
 {
-#define GNNX_ROWS(M, XT) hipLaunchKernelGGL((spmm_kernel<G, VEC, U, M, XT>), grid, dim3(256), 0, st, a, n_item_blocks)
+#define GNNX_ROWS(M, XT) hipLaunchKernelGGL((spmm_kernel<G, VEC, U, M, XT>), grid, dim3(256), 0, st, a)
     if (a.x_bf16) {
         switch (mode) {
         case 0: GNNX_ROWS(0, bf16_t); break;
@@ -801,29 +890,16 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     SpmmArgs a = a_in;
     if (G < 2 * kPlanBlockRows) a.block_starts = nullptr;  // plan blocks hold up to kPlanBlockRows rows (< G needed)
     dim3 grid;
-    int32_t n_item_blocks = (int32_t)ceil_div(a.n_items, GROUPS);
     grid.y = (uint32_t)ceil_div(a.n_feat, feat_per_tile);
     // kernel MODE: 0 forward, 1 colscale, 2 vals (the backward: norm streamed per entry), 6 vals + colscale, 3/4/5 forward with
     // a ReLU / BN / BN+ReLU prologue
     const int mode = a.vals != nullptr ? (a.colscale ? 6 : 2) : (a.colscale ? 1 : (pro ? 2 + pro : 0));
     bool stream = false;
     if constexpr (G >= 8) stream = use_stream_kernel(G);
-#ifdef GNNX_EXPERIMENTS
-    if constexpr (G == 64 && VEC == 4) {
-        if (use_lds_variant() && a.n_feat == 256 && mode == 0 && !a.relu_out && !a.x_bf16) {  // measurement variant, forward mode only
-            grid.x = (uint32_t)(a.n_items + (a.block_starts ? a.n_blocks : ceil_div(a.n_rows, StreamCfg<64>::R)));
-            grid.y = 1;
-            hipLaunchKernelGGL((spmm_lds_kernel<16>), grid, dim3(64), 0, st, a, (int32_t)a.n_items);
-            GNNX_LAUNCH_CHECK();
-            if (plan && plan->n_split_rows > 0) {
-                dim3 cgrid((uint32_t)ceil_div(plan->n_split_rows, GROUPS), 1);
-                hipLaunchKernelGGL((spmm_combine_kernel<G, VEC>), cgrid, dim3(256), 0, st, a, plan->d_rows, plan->n_split_rows);
-                GNNX_LAUNCH_CHECK();
-            }
-            return GNNX_OK;
-        }
+    if (a.n_hub_rows > 0) {
+        const int rc = launch_hub<VEC>(mode, st, a);
+        if (rc != GNNX_OK) return rc;
     }
-#endif
     if (stream) {
         if constexpr (G >= 8) {
             constexpr int R = StreamCfg<G>::R;
@@ -831,23 +907,16 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
             // blocks of a power-law graph differ a lot in non-zeros, so multi-wave workgroups strand slots.
             static const int tpb_env = [] { const char *v = experiment_env("GNNX_SPMM_TPB"); return v ? atoi(v) : 64; }();
             const int tpb = tpb_env == 256 ? 256 : 64;
-            n_item_blocks = (int32_t)ceil_div(a.n_items, tpb / G);
-            grid.x = (uint32_t)(n_item_blocks + (a.block_starts ? ceil_div(a.n_blocks, tpb / G)
-                                                                : ceil_div(a.n_rows, (int64_t)(tpb / G) * R)));
-            if (tpb == 256) launch_stream<G, VEC, U, 256>(mode, grid, st, a, n_item_blocks);
-            else launch_stream<G, VEC, U, 64>(mode, grid, st, a, n_item_blocks);
+            grid.x = (uint32_t)(a.block_starts ? ceil_div(a.n_blocks, tpb / G) : ceil_div(a.n_rows, (int64_t)(tpb / G) * R));
+            if (tpb == 256) launch_stream<G, VEC, U, 256>(mode, grid, st, a);
+            else launch_stream<G, VEC, U, 64>(mode, grid, st, a);
         }
     } else {
-        grid.x = (uint32_t)(n_item_blocks + ceil_div(a.n_rows, GROUPS));
+        grid.x = (uint32_t)ceil_div(a.n_rows, GROUPS);
         if (grid.x == 0) return GNNX_OK;
-        launch_rows<G, VEC, U>(mode, grid, st, a, n_item_blocks);
+        launch_rows<G, VEC, U>(mode, grid, st, a);
     }
     GNNX_LAUNCH_CHECK();
-    if (plan && plan->n_split_rows > 0) {
-        dim3 cgrid((uint32_t)ceil_div(plan->n_split_rows, GROUPS), grid.y);
-        hipLaunchKernelGGL((spmm_combine_kernel<G, VEC>), cgrid, dim3(256), 0, st, a, plan->d_rows, plan->n_split_rows);
-        GNNX_LAUNCH_CHECK();
-    }
     return GNNX_OK;
 }
 
@@ -858,30 +927,39 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
 {
     GNNX_REQUIRE(d_rowptr && plan_out, GNNX_ERR_INVALID_ARG, "null pointer");
     GNNX_REQUIRE(n_rows >= 0 && chunk > 0 && max_feat > 0, GNNX_ERR_INVALID_ARG, "n_rows/chunk/max_feat");
+    (void)max_feat;  // a plan holds no per-feature storage any more (kept in the signature: callers size nothing by it)
     hipStream_t st = as_stream(stream);
     auto *plan = new gnnx_spmm_plan();
     plan->n_rows = n_rows;
     plan->chunk = chunk;
-    plan->max_feat = (max_feat + 3) & ~3;
     *plan_out = plan;
-    GNNX_HIP_CHECK(hipMalloc(&plan->d_counters, 4 * sizeof(int32_t)));
-    GNNX_HIP_CHECK(hipMemsetAsync(plan->d_counters, 0, 4 * sizeof(int32_t), st));
+    GNNX_HIP_CHECK(hipMalloc(&plan->d_counters, 4 * sizeof(unsigned long long)));
+    GNNX_HIP_CHECK(hipMemsetAsync(plan->d_counters, 0, 4 * sizeof(unsigned long long), st));
     if (n_rows == 0) return GNNX_OK;
     dim3 grid((uint32_t)ceil_div(n_rows, 256));
     hipLaunchKernelGGL(plan_count_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, chunk, plan->d_counters);
     GNNX_LAUNCH_CHECK();
-    int32_t h[4];
+    unsigned long long h[2];
     GNNX_HIP_CHECK(hipMemcpyAsync(h, plan->d_counters, sizeof(h), hipMemcpyDeviceToHost, st));
     GNNX_HIP_CHECK(hipStreamSynchronize(st));
-    plan->n_split_rows = h[0];
-    plan->n_chunks = h[1];
+    plan->n_split_rows = (int32_t)h[0];
+    plan->n_hub_nnz = (int64_t)h[1];
     if (plan->n_split_rows > 0) {
-        GNNX_HIP_CHECK(hipMalloc(&plan->d_items, sizeof(int4) * (size_t)plan->n_chunks));
-        GNNX_HIP_CHECK(hipMalloc(&plan->d_rows, sizeof(int4) * (size_t)plan->n_split_rows));
-        GNNX_HIP_CHECK(hipMalloc(&plan->d_partial, sizeof(float) * (size_t)plan->n_chunks * plan->max_feat));
-        hipLaunchKernelGGL(plan_fill_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, chunk, plan->d_counters,
-                           plan->d_items, plan->d_rows);
+        // work list of spmm_hub_kernel: the hub rows, longest first (ties by row id: the list does not depend on the order the
+        // atomics handed out positions)
+        int2 *d_list = nullptr;
+        GNNX_HIP_CHECK(hipMalloc(&d_list, sizeof(int2) * (size_t)plan->n_split_rows));
+        hipLaunchKernelGGL(plan_fill_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, chunk, plan->d_counters, d_list);
         GNNX_LAUNCH_CHECK();
+        std::vector<int2> h_rows((size_t)plan->n_split_rows);
+        GNNX_HIP_CHECK(hipMemcpyAsync(h_rows.data(), d_list, sizeof(int2) * h_rows.size(), hipMemcpyDeviceToHost, st));
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));
+        (void)hipFree(d_list);
+        std::sort(h_rows.begin(), h_rows.end(), [](const int2 &x, const int2 &y) { return x.y != y.y ? x.y > y.y : x.x < y.x; });
+        std::vector<int32_t> h_hub(h_rows.size());
+        for (size_t i = 0; i < h_rows.size(); i++) h_hub[i] = h_rows[i].x;
+        GNNX_HIP_CHECK(hipMalloc(&plan->d_hub_rows, sizeof(int32_t) * h_hub.size()));
+        GNNX_HIP_CHECK(hipMemcpyAsync(plan->d_hub_rows, h_hub.data(), sizeof(int32_t) * h_hub.size(), hipMemcpyHostToDevice, st));
         GNNX_HIP_CHECK(hipStreamSynchronize(st));
     }
     // non-zero-balanced row blocks
@@ -919,20 +997,18 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
 GNNX_API int gnnx_spmm_plan_destroy(gnnx_spmm_plan *plan)
 {
     if (!plan) return GNNX_OK;
-    if (plan->d_items) (void)hipFree(plan->d_items);
-    if (plan->d_rows) (void)hipFree(plan->d_rows);
-    if (plan->d_partial) (void)hipFree(plan->d_partial);
+    if (plan->d_hub_rows) (void)hipFree(plan->d_hub_rows);
     if (plan->d_counters) (void)hipFree(plan->d_counters);
     if (plan->d_block_starts) (void)hipFree(plan->d_block_starts);
     delete plan;
     return GNNX_OK;
 }
 
-GNNX_API int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_split_rows, int64_t *n_chunks)
+GNNX_API int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_hub_rows, int64_t *n_hub_nnz)
 {
     GNNX_REQUIRE(plan, GNNX_ERR_INVALID_ARG, "plan is null");
-    if (n_split_rows) *n_split_rows = plan->n_split_rows;
-    if (n_chunks) *n_chunks = plan->n_chunks;
+    if (n_hub_rows) *n_hub_rows = plan->n_split_rows;
+    if (n_hub_nnz) *n_hub_nnz = plan->n_hub_nnz;
     return GNNX_OK;
 }
 
@@ -950,8 +1026,6 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
     GNNX_REQUIRE(!x_bf16 || !fusion, GNNX_ERR_UNSUPPORTED, "bf16 feature rows take no fusion");
     if (plan) {
         GNNX_REQUIRE(plan->n_rows == n_rows, GNNX_ERR_SHAPE, "plan was built for %d rows, got %d", plan->n_rows, n_rows);
-        GNNX_REQUIRE(plan->n_split_rows == 0 || n_feat <= plan->max_feat, GNNX_ERR_SHAPE,
-                     "plan was built for at most %d features, got %d", plan->max_feat, n_feat);
     }
     SpmmArgs a{};
     int pro = 0;  // 0 none, 1 ReLU, 2 BatchNorm, 3 BatchNorm + ReLU
@@ -988,10 +1062,8 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
     }
     if (plan && plan->n_split_rows > 0) {
         a.split_threshold = plan->chunk;
-        a.items = plan->d_items;
-        a.n_items = plan->n_chunks;
-        a.partial = plan->d_partial;
-        a.partial_ld = plan->max_feat;
+        a.hub_rows = plan->d_hub_rows;
+        a.n_hub_rows = plan->n_split_rows;
     }
     hipStream_t st = as_stream(stream);
     auto aligned16 = [](const void *p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };

@@ -142,7 +142,7 @@ Partition::~Partition()
 
 void Partition::ensure_spmm_plans(int32_t n_feat)
 {
-    constexpr int32_t kChunk = 4096;  // rows longer than this are cut into chunks
+    constexpr int32_t kChunk = 1024;  // rows longer than this go to the sequential hub kernel
     for (Side *s : {&fwd, &bwd}) {
         if (s->spmm_plan && s->spmm_plan_feat >= n_feat) continue;
         if (s->spmm_plan) gnnx_spmm_plan_destroy(s->spmm_plan);

@@ -114,7 +114,7 @@ void Csr::ensure_plans(int32_t n_feat)
     if (plan && plan_feat >= n_feat) return;
     drop_plans();
     ensure_transpose();
-    constexpr int32_t kChunk = 4096;  // rows longer than this are cut into chunks
+    constexpr int32_t kChunk = 1024;  // rows longer than this go to the sequential hub kernel
     gx(gnnx_spmm_plan_create((const int32_t *)rowptr, n, kChunk, n_feat, &plan, current_stream()), "plan");
     gx(gnnx_spmm_plan_create((const int32_t *)rowptr_t, n, kChunk, n_feat, &plan_t, current_stream()), "plan");
     plan_feat = n_feat;

@@ -53,6 +53,9 @@ def _workspace(nbytes, device, tag):
 
 
 class SpmmPlan:
+    """gnnx_spmm_plan: hub rows (longer than `chunk`) to the sequential hub kernel, non-zero-balanced blocks for the rest; the
+    planned aggregation has the same bits as the unplanned one."""
+
     def __init__(self, rowptr, chunk, max_feat):
         self.h = C.c_void_p()
         self._rowptr = rowptr
@@ -60,7 +63,7 @@ class SpmmPlan:
                   C.byref(self.h), _stream())
         a, b = C.c_int64(0), C.c_int64(0)
         capi.call("gnnx_spmm_plan_info", self.h, C.byref(a), C.byref(b))
-        self.n_split_rows, self.n_chunks = a.value, b.value
+        self.n_split_rows, self.n_hub_nnz = a.value, b.value   # hub rows (degree > chunk) and their non-zeros
 
     def __del__(self):
         try:

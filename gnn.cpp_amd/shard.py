@@ -375,7 +375,7 @@ class ShardedGcnStack:
     values are the unsharded stack's bit for bit (same fmaf chains in the dense products, same summation order in the
     aggregations); dW / db sum the ranks' contributions in rank order (rounding-level)."""
 
-    def __init__(self, ops, dist, plan, dims, seed=0, chunk=4096, native=None):
+    def __init__(self, ops, dist, plan, dims, seed=0, chunk=1024, native=None):
         self.ops, self.dist, self.p, self.native = ops, dist, plan, native
         dev = plan.fwd.rowptr.device
         self.dims = list(dims)

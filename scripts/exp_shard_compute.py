@@ -62,9 +62,9 @@ def main():
             try:
                 torch.cuda.set_device(0)
                 if layers:
-                    r = shard.ShardedTrain(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 4096, layers)
+                    r = shard.ShardedTrain(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 1024, layers)
                 else:
-                    r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 4096,
+                    r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 1024,
                                            replicate_input_halo="--replicate-input-halo" in sys.argv)
                 r.step()
                 torch.cuda.synchronize()

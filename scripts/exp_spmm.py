@@ -59,7 +59,7 @@ def main():
         report("rmat, no plan", g, F, time_spmm(g, H, out, None))
         for chunk in [int(c) for c in os.environ.get("CHUNKS", "32,64,128,256,512").split(",")]:
             plan = ops.SpmmPlan(g.rowptr, chunk, F)
-            report(f"rmat, plan chunk {chunk} ({plan.n_split_rows} rows/{plan.n_chunks} chunks)", g, F,
+            report(f"rmat, plan chunk {chunk} ({plan.n_split_rows} hub rows / {plan.n_hub_nnz} nnz)", g, F,
                    time_spmm(g, H, out, plan))
             del plan
         if os.environ.get("HUBSPLIT"):

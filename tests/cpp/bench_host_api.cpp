@@ -1,6 +1,7 @@
 // API-level benchmark: the GCN layer through the C++ mirror of the reference API (graph::GCNConv on graph::Data),
 // forward + backward, to show what a user of the reference's call sites gets on an MI355X.
-//   bench_host_api [n_nodes=1000000] [n_edges=10000000] [features=128] [steps=5] [hot_path_only=1] [scramble_labels=0]
+//   bench_host_api [n_nodes=1000000] [n_edges=10000000] [features=128] [steps=5] [hot_path_only=1|0|2=both] [scramble_labels=0|1|2=both]
+//                  [rmat_seed=1]          one JSON line per configuration (bench.py starts this as a child and adds them to its line)
 // scramble_labels: the data set's vertex ids are multiplied by 2654435761 mod n (an isomorphic graph) before the API sees them --
 // what a user would do once at load time: R-MAT's hubs are the ids with few one-bits, and 1-KiB feature rows at such ids pile onto
 // a few memory channels; the API itself keeps the caller's vertex order.
@@ -27,16 +28,12 @@ static inline uint64_t splitmix64(uint64_t x)
 
 static double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
 
-int main(int argc, char **argv)
+// One configuration: edges of the given vertex order, one layer, first call + timed steps; prints one JSON line.
+static void run_config(long n, long e, size_t F, int steps, bool hot, bool scramble, uint64_t seed)
 {
-    const long n = argc > 1 ? atol(argv[1]) : 1000000, e = argc > 2 ? atol(argv[2]) : 10000000;
-    const size_t F = argc > 3 ? atol(argv[3]) : 128;
-    const int steps = argc > 4 ? atoi(argv[4]) : 5;
-    const bool hot = argc > 5 ? atoi(argv[5]) != 0 : true;
-    const bool scramble = argc > 6 ? atoi(argv[6]) != 0 : false;
     int scale = 1;
     while ((1l << scale) < n) scale++;
-    const uint64_t key = splitmix64(1), G = 0x9E3779B97F4A7C15ull;
+    const uint64_t key = splitmix64(seed), G = 0x9E3779B97F4A7C15ull;
     const uint32_t ta = (uint32_t)(0.57 * 4294967296.0), tb = (uint32_t)(0.76 * 4294967296.0), tc = (uint32_t)(0.95 * 4294967296.0);
     vector<int> src(e), dst(e);
     double t0 = now_s();
@@ -86,7 +83,26 @@ int main(int argc, char **argv)
     gnnx_device_sync();
     double ms = (now_s() - t0) / steps * 1e3;
     printf("{\"bench\": \"host_api GCNConv fwd+bwd\", \"n_nodes\": %ld, \"n_edges\": %ld, \"features\": %zu, \"hot_path_only\": %d, "
-           "\"ms_per_step\": %.3f, \"first_call_s\": %.3f, \"edge_gen_s\": %.3f, \"out_checksum\": %.6e}\n",
-           n, e, F, (int)hot, ms, t_first, t_gen, (double)(*out->data())[12345 % (n * F)]);
+           "\"scrambled_labels\": %d, \"rmat_seed\": %llu, \"ms_per_step\": %.3f, \"first_call_s\": %.3f, \"edge_gen_s\": %.3f, "
+           "\"out_checksum\": %.6e}\n",
+           n, e, F, (int)hot, (int)scramble, (unsigned long long)seed, ms, t_first, t_gen, (double)(*out->data())[12345 % (n * F)]);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const long n = argc > 1 ? atol(argv[1]) : 1000000, e = argc > 2 ? atol(argv[2]) : 10000000;
+    const size_t F = argc > 3 ? atol(argv[3]) : 128;
+    const int steps = argc > 4 ? atoi(argv[4]) : 5;
+    const int hot = argc > 5 ? atoi(argv[5]) : 1;            // 1 hot path, 0 full BatchNorm + ReLU layer, 2 both
+    const int scramble = argc > 6 ? atoi(argv[6]) : 0;       // 0 as generated, 1 scrambled labels, 2 both
+    const uint64_t seed = argc > 7 ? (uint64_t)atoll(argv[7]) : 1;
+    for (int sc = 0; sc < 2; sc++) {
+        if (scramble != 2 && sc != scramble) continue;
+        for (int h = 1; h >= 0; h--) {
+            if (hot != 2 && h != hot) continue;
+            run_config(n, e, F, steps, h != 0, sc != 0, seed);
+        }
+    }
     return 0;
 }

@@ -30,6 +30,18 @@ def test_library_exports_every_declared_symbol(capi):
         assert n in capi._SIGS, f"capi.py has no signature for {n}"
 
 
+def test_library_has_no_unresolved_symbols(capi):
+    """Every kernel the launch code refers to was actually emitted: `ldd -r` resolves all function and data references of the
+    built libraries.  (A HIP kernel template whose instantiation the compiler drops leaves an undefined host stub that only shows
+    at the first launch of that shape -- found with a size-16 __builtin_amdgcn_global_load_lds on a dependent pointer type.)"""
+    import os
+    here = os.path.dirname(capi.LIB_PATH)
+    for lib in ("libgnnx_hip.so", "libgnncpp_host.so"):
+        r = subprocess.run(["ldd", "-r", os.path.join(here, lib)], capture_output=True, text=True)
+        bad = [ln for ln in (r.stdout + r.stderr).splitlines() if "undefined symbol" in ln]
+        assert not bad, f"{lib}: " + "; ".join(bad[:5])
+
+
 def test_only_c_types_in_the_header():
     text = open(capi_header()).read()
     assert 'extern "C"' in text
