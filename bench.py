@@ -54,22 +54,31 @@ WORKLOADS = {
 }
 
 
-def profiled_traffic(workload, kernel_substr):
-    """Per-launch HBM bytes of a kernel from the newest committed rocprofv3 PMC summary of this workload
-    (profiles/*_hbm_traffic.json, made by scripts/summarize_profile.py from separate --pmc FETCH_SIZE /
-    WRITE_SIZE passes of this same bench command, gfx950-corrected); None if there is none."""
+def profiled_traffic(workload, kernel_patterns):
+    """Per-launch bytes leaving L2 (PMC) of ONE aggregation = the sum over its kernels (hub kernel + streaming kernel), from the
+    newest committed rocprofv3 PMC summary of this workload (profiles/*_hbm_traffic.json, made by scripts/summarize_profile.py from
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same bench command, gfx950-corrected).  kernel_patterns: regular
+    expressions, each must match exactly one kernel of the file.  Returns (bytes, provenance dict) or None."""
     import glob
+    import re
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))):   # names sort by round tag: the last match wins
         try:
             d = json.load(open(f))
         except Exception:
             continue
         if d.get("workload") != workload:
             continue
-        for k, v in d.get("kernels", {}).items():
-            if kernel_substr in k:
-                best = (v["hbm_bytes_corrected"], os.path.relpath(f, ROOT))
+        total, names = 0.0, []
+        for pat in kernel_patterns:
+            hits = [k for k in d.get("kernels", {}) if re.search(pat, k)]
+            if len(hits) != 1:
+                break
+            total += d["kernels"][hits[0]]["hbm_bytes_corrected"]
+            names.append(hits[0])
+        else:
+            best = (total, {"file": os.path.relpath(f, ROOT), "kernels": names, "git_head_of_profiled_build": d.get("git_head"),
+                            "profiled_nnz": d.get("nnz"), "file_mtime": time.strftime("%Y-%m-%d %H:%M:%S", time.gmtime(os.path.getmtime(f)))})
     return best
 
 
@@ -84,7 +93,7 @@ def _ceilings_lib():
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
         _ceil_lib = C.CDLL(path)
-        _ceil_lib.ceil_copy_f4.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        _ceil_lib.ceil_copy_f4.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         _ceil_lib.ceil_gather_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
     return _ceil_lib
 
@@ -92,7 +101,9 @@ def _ceilings_lib():
 def _timed_ms(capi, fn, reps=5, warmup=2):
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(warmup):
-        fn(stream)
+        rc = fn(stream)
+        if rc != 0:
+            raise RuntimeError(f"ceiling kernel launch failed ({rc})")
     a, b = capi.Event(), capi.Event()
     a.record(stream)
     for _ in range(reps):
@@ -102,33 +113,34 @@ def _timed_ms(capi, fn, reps=5, warmup=2):
     return a.elapsed_ms(b) / reps
 
 
-def copy_ceiling(capi, dev, gib=4):
+def copy_ceiling(capi, dev, gib=4, variant=0):
     """float4 copy of `gib` GiB (read + written bytes / time), GB/s."""
     L = _ceilings_lib()
     n = gib * 2 ** 30 // 4
     src = torch.full((n,), 1.0, dtype=torch.float32, device=dev)
     dst = torch.empty_like(src)
-    ms = _timed_ms(capi, lambda st: L.ceil_copy_f4(src.data_ptr(), dst.data_ptr(), n * 4, st))
+    ms = _timed_ms(capi, lambda st: L.ceil_copy_f4(src.data_ptr(), dst.data_ptr(), n * 4, variant, st))
     return 2 * n * 4 / (ms * 1e-3) / 1e9
 
 
-def gather_ceiling(capi, dev, table_mb=160, deg=8, gathered_gb=16):
-    """Sum of `deg` uniformly random whole 1-KiB rows of a `table_mb` MB table per streamed output row: (gathered + index + written)
+def gather_ceiling(capi, dev, table_mb=160, gathered_gb=16, variant=0):
+    """Sum of 8 uniformly random whole 1-KiB rows of a `table_mb` MB table per streamed output row: (gathered + index + written)
     bytes / time, GB/s.  With the table inside the 256 MiB Infinity Cache this is what the fabric behind L2 delivers to a row gather."""
     L = _ceilings_lib()
+    deg = 8
     rows = table_mb * 2 ** 20 // 1024
-    n_out = int(gathered_gb * 1e9 / 1024 / deg)
+    n_out = int(gathered_gb * 1e9 / 1024 / deg) // 256 * 256
     table = torch.full((rows, 256), 1.0, dtype=torch.float32, device=dev)
     idx = torch.randint(0, rows, (n_out * deg,), dtype=torch.int32, device=dev)
     out = torch.empty((n_out, 256), dtype=torch.float32, device=dev)
-    ms = _timed_ms(capi, lambda st: L.ceil_gather_rows(table.data_ptr(), idx.data_ptr(), n_out, deg, out.data_ptr(), st))
+    ms = _timed_ms(capi, lambda st: L.ceil_gather_rows(table.data_ptr(), idx.data_ptr(), n_out, variant, out.data_ptr(), st))
     return (n_out * deg * 1024 + n_out * deg * 4 + n_out * 1024) / (ms * 1e-3) / 1e9
 
 
-def measure_ceilings(capi, dev, verbose=False):
+def measure_ceilings(capi, dev):
     """The in-run ceilings of the roofline line (N = 1, outside the timed region, a few ms of kernels each)."""
     c = {"hbm_copy_GBps": copy_ceiling(capi, dev),
-         "fabric_gather_GBps": gather_ceiling(capi, dev, table_mb=160, deg=8),
+         "fabric_gather_GBps": gather_ceiling(capi, dev, table_mb=160),
          "fabric_gather": "sum of 8 uniformly random 1-KiB rows of a 160 MB table (Infinity-Cache resident) per streamed output row; "
                           "gathered + index + written bytes / time (bench_kernels/ceilings.hip)",
          "hbm_copy": "float4 copy of 4 GiB, read + written bytes / time"}
@@ -160,6 +172,9 @@ def main():
                          "vertex's result has the same bits, at another row.  as-generated: vertex v at row v (round 1).  auto (default): "
                          "scrambled when a feature row is a multiple of 512 bytes (F = 256: aggregation 19 -> 13.7 ms; F = 128: -3 %%), "
                          "as-generated otherwise (F = 100: 400-byte rows spread by themselves, the scramble costs 2 %%)")
+    ap.add_argument("--no-ceilings", action="store_true", help="skip the in-run copy / gather ceilings (roofline.peak falls back to the HBM spec)")
+    ap.add_argument("--no-cpp-api", action="store_true",
+                    help="skip the C++ call-site leg (tests/cpp/bench_host_api as a child process after the timed region: cpp_api)")
     ap.add_argument("--no-order-control", action="store_true",
                     help="skip the informational re-run of a few steps on the as-generated vertex order (vertex_order_control)")
     ap.add_argument("--no-pad-features", action="store_true",
@@ -305,25 +320,43 @@ def main():
     if graph is not None:  # per-kernel HIP events are not recorded inside a replayed graph: time the kernels once eagerly
         runner.step(timed=True)
         torch.cuda.synchronize()
-    roof = runner.roofline()
-    if dist:  # slowest rank's forward SpMM defines the job's roofline line
-        t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        roof["achieved"] = float(t.item())
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        if args.train_layers:   # whole training steps: no single-kernel roofline line (see the default run)
-            roof["achieved"] = roof["frac"] = None
+    ceilings = None
+    if world == 1 and not args.force_sharded and not args.no_ceilings and rank == 0:
+        ceilings = measure_ceilings(capi, dev)   # outside the timed region: two small kernels, a few ms each
+    if isinstance(runner, SingleGpu):
+        roof = runner.roofline(ceilings)
+    else:
+        roof = sharded_roofline(runner.aggregation_stats())
+        if roof["achieved"] is not None:  # slowest rank's forward SpMM defines the job's roofline line
+            t = torch.tensor([roof["achieved"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            roof["achieved"] = float(t.item())
+            roof["frac"] = roof["achieved"] / roof["peak"]
 
+    roof_mfma = runner.mfma_roofline() if hasattr(runner, "mfma_roofline") else None
+    kernels_ms = runner.kernel_times()
+    nnz_one, Fp_run, order_run = runner.nnz_total, getattr(runner, "Fp", F), getattr(runner, "vertex_order", None)
     # control for the vertex order (informational, outside the timed region above): the same runner on the as-generated labels
     order_control = None
     if (world == 1 and not args.force_sharded and not args.train_layers and relabel and graph is None and not args.no_order_control
             and isinstance(runner, SingleGpu)):
         order_control = runner.as_generated_control(pkg, n, e, abc, seed, args.chunk)
 
-    cpu = cpu_ref = None
+    if order_control and roof.get("avg_launch_ms") and order_control.get("spmm_fwd_ms"):
+        # the as-generated order: hub rows pile onto a few channels, HBM-side bound -> algorithmic bytes against the HBM spec
+        order_control["hbm_spec_frac_as_generated"] = (roof["algorithmic_bytes_per_launch"] / (order_control["spmm_fwd_ms"] * 1e-3) / 1e9
+                                                       / HBM_PEAK_GBS)
+    cpu = cpu_ref = cpp = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pkg, args, F, abc, seed)
         cpu_ref = cpu_reference(pkg)
+    if (rank == 0 and world == 1 and not args.force_sharded and not args.train_layers and not args.no_cpp_api and abc is not None
+            and abc == (0.57, 0.19, 0.19)):
+        # free this process's device memory first: the child builds the same graph and tensors through the C++ API
+        del runner
+        ops._ws_cache.clear()
+        torch.cuda.empty_cache()
+        cpp = cpp_api_bench(n, e, F, seed, both_orders=(4 * F) % 512 == 0)
 
     if rank == 0:
         line = {
@@ -339,9 +372,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": runner.nnz_total,
-                       "features": F, "layer": f"{F}->{F}", "feature_row_stride": getattr(runner, "Fp", F),
-                       "vertex_order": getattr(runner, "vertex_order", "dealt by degree, spread inside every rank's range"),
+            "config": {"workload": args.workload, "n_nodes": n, "n_edges_generated": e, "nnz": nnz_one,
+                       "features": F, "layer": f"{F}->{F}", "feature_row_stride": Fp_run,
+                       "vertex_order": order_run or "dealt by degree, spread inside every rank's range",
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd of every parameter, SGD; no input gradient); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 and not args.force_sharded else
@@ -352,17 +385,34 @@ def main():
                        "feature_storage": "bf16 for the aggregations (opt-in, NOT the parity path)" if args.bf16_features else "f32",
                        "gemm": "split-bf16 x6 for X.W^T and dH.W (opt-in, NOT the parity path)" if args.split_gemm else "f32 MFMA"},
             "roofline": roof,
-            "roofline_mfma": runner.mfma_roofline() if hasattr(runner, "mfma_roofline") else None,
+            "roofline_mfma": roof_mfma,
             "vertex_order_control": order_control,
+            "cpp_api": cpp,
             "cpu_baseline": cpu,
             "cpu_reference": cpu_ref,
-            "kernels_ms": runner.kernel_times(),
+            "kernels_ms": kernels_ms,
             "build_s": t_build,
             "device": torch.cuda.get_device_name(local_rank),
         }
         print(json.dumps(line), flush=True)
     if dist:
         dist.destroy_process_group()
+
+
+def sharded_roofline(st):
+    """N > 1: the slowest rank's forward aggregation, ALGORITHMIC bytes (one feature row per local non-zero) / time against the HBM
+    spec -- no PMC traffic and no in-run ceiling exist for a shard (the N = 1 line carries those)."""
+    r = {"bound": "hbm", "kernel": "forward aggregation of one rank (spmm_hub_kernel + spmm_stream_kernel), slowest rank",
+         "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+         "achieved_is": "algorithmic_bytes_per_launch / avg_launch_ms", "peak_is": "HBM spec"}
+    if st.get("spmm_fwd_ms"):
+        B = spmm_bytes(st["local_rows"], st["local_rows"], st["local_nnz"], st["features"], bias=True)
+        r.update(achieved=B / (st["spmm_fwd_ms"] * 1e-3) / 1e9, algorithmic_bytes_per_launch=B, avg_launch_ms=st["spmm_fwd_ms"])
+        r["frac"] = r["achieved"] / r["peak"]
+    else:
+        r["kernel"] = "n/a for --train-layers (see the default run)"
+    r.update({k: v for k, v in st.items() if k.startswith(("halo_", "send_")) or k in ("local_rows", "schedule")})
+    return r
 
 
 class SingleGpu:
@@ -504,30 +554,46 @@ class SingleGpu:
             out[nm] = float(np.mean([s[i][0].elapsed_ms(s[i][1]) for s in self.ev])) if self.ev else None
         return out
 
-    def roofline(self):
+    def roofline(self, ceilings=None):
+        """The contract's roofline object for the dominant kernel pair: the forward aggregation = spmm_hub_kernel (hub rows) +
+        spmm_stream_kernel (all other rows), timed together by one pair of HIP events on the launch stream.
+          achieved = bytes that leave L2 towards the fabric per aggregation (PMC: 2 FETCH_SIZE + WRITE_SIZE of both kernels, from
+                     the committed rocprofv3 passes of this bench command: `traffic`) / the HIP-event time of THIS run;
+          peak     = fabric_gather_ceiling measured in THIS run (bench_kernels/ceilings.hip): the same kind of bytes -- whole 1-KiB
+                     rows picked at random from a table that sits in the 256 MiB Infinity Cache, summed 8 to a streamed output row.
+        The neighbour rows of a power-law graph come partly from the Infinity Cache (62 % of the edges of the bench graph point at
+        168 MB of hub rows) and partly from HBM, so the bound that binds is the fabric behind L2, not the HBM pins: ALGORITHMIC
+        bytes / time (`effective_GBps`, one feature row per non-zero: SURVEY.md 8(d)) exceeds the 8 TB/s HBM peak and is therefore
+        reported beside the fraction, not as the fraction."""
         ms = self.kernel_times()["spmm_fwd"]
         B = spmm_bytes(self.n, self.n, self.g.nnz, self.F, bias=True)
         if getattr(self, "bf16_features", False):
             B -= 2 * self.F * self.g.nnz  # 2-byte features in the gather
-        achieved = B / (ms * 1e-3) / 1e9
-        tr = profiled_traffic(self.workload, "spmm_stream_kernel<64, 4, 8, 0") if self.F == 256 else None
-        return {"bound": "hbm", "kernel": "spmm_stream_kernel<64,4,8,0,64> (forward aggregation)", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
-                "traffic_source": tr[1] if tr else None,
-                "algorithmic_bytes_per_launch": B, "bytes_per_edge": B / max(1, self.g.nnz), "avg_launch_ms": ms,
-                "median_launch_ms": float(np.median([st[self.names.index("spmm_fwd")][0].elapsed_ms(st[self.names.index("spmm_fwd")][1])
-                                                     for st in self.ev])) if self.ev else None,
-                # the cache-perfect lower bound (every feature row read once) beside the gather figure
-                "cache_perfect_bytes": 4 * (self.n + 1) + 4 * self.g.nnz + 4 * self.n + 8 * self.F * self.n,
-                "frac_of_measured_copy_ceiling_6290": achieved / 6290.0,
-                "vertex_order": self.vertex_order,
-                "note": ("achieved = ALGORITHMIC bytes (one feature row per non-zero) / time; it can exceed the HBM peak because the hub "
-                         "rows of a power-law graph are served by the 256 MiB Infinity Cache.  `traffic` (PMC: 2 FETCH_SIZE + WRITE_SIZE) "
-                         "counts what leaves L2 towards the fabric -- Infinity-Cache hits included -- and stays at 0.96 x algorithmic in "
-                         "either vertex order; in the as-generated order the hub rows (ids with few one-bits, 1-KiB rows) pile onto a few "
-                         "memory channels / cache slices (twice the DRAM-credit stall cycles at the L2 read interface), the scrambled order "
-                         "spreads them (DESIGN.md section 5, profiles/r02_vertex_order_counters.json)")}
-
+        eff = B / (ms * 1e-3) / 1e9
+        tr = None
+        if not getattr(self, "bf16_features", False) and not getattr(self, "sym", False):
+            tr = profiled_traffic(self.workload, [r"^spmm_hub_kernel<\d+, 0, ", r"^spmm_(stream_)?kernel<\d+, \d+, \d+, 0, "])
+        if tr and tr[1].get("profiled_nnz") not in (None, self.g.nnz):
+            tr = None  # a profile of another graph
+        peak = ceilings["fabric_gather_GBps"] if ceilings else HBM_PEAK_GBS
+        achieved = (tr[0] if tr else B) / (ms * 1e-3) / 1e9
+        evs = [st[self.names.index("spmm_fwd")] for st in self.ev]
+        r = {"bound": "hbm", "bound_detail": "memory system behind L2 (Infinity Cache + HBM): whole-row gather",
+             "kernel": "forward aggregation = spmm_hub_kernel<VEC, 0, LAS, float> + spmm_stream_kernel<G, VEC, 8, 0, 64, float>",
+             "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+             "achieved_is": ("traffic / avg_launch_ms" if tr else "algorithmic_bytes_per_launch / avg_launch_ms (no PMC profile of this workload "
+                             "and graph is committed)"),
+             "peak_is": ("fabric_gather_ceiling measured in this run" if ceilings else "HBM spec (no in-run ceiling: N > 1 or --no-ceilings)"),
+             "traffic": tr[0] if tr else None, "traffic_source": tr[1] if tr else None,
+             "avg_launch_ms": ms, "median_launch_ms": float(np.median([a.elapsed_ms(b) for a, b in evs])) if evs else None,
+             "algorithmic_bytes_per_launch": B, "bytes_per_edge": B / max(1, self.g.nnz), "effective_GBps": eff,
+             "effective_over_hbm_spec_8000": eff / HBM_PEAK_GBS,
+             # SURVEY.md 8(d): the cache-perfect lower bound (every feature row read once) beside the gather figure
+             "cache_perfect_bytes": 4 * (self.n + 1) + 4 * self.g.nnz + 4 * self.n + 8 * self.F * self.n,
+             "ceilings": ceilings, "vertex_order": self.vertex_order}
+        if ceilings:
+            r["traffic_over_hbm_copy_ceiling"] = achieved / ceilings["hbm_copy_GBps"] if tr else None
+        return r
 
     def mfma_roofline(self):
         """The second bound of the step: the three dense products against the fp32 matrix peak (MI355X_MICROARCH.md: 157.3 TFLOP/s,
@@ -571,9 +637,40 @@ class TrainStep(SingleGpu):
             b.record(stream)
             self.ev.append([(a, b)])
 
-    def roofline(self):
+    def roofline(self, ceilings=None):
         return {"bound": "hbm", "kernel": "n/a for --train-layers (see the default run)", "achieved": None, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": None, "traffic": None}
+                "unit": "GB/s", "frac": None, "traffic": None, "ceilings": ceilings}
+
+
+def cpp_api_bench(n, e, F, seed, both_orders=True, steps=5):
+    """The same layer through the drop-in boundary itself: tests/cpp/bench_host_api drives graph::GCNConv on graph::Data (the
+    reference's call sites graph.cpp:170-191, nn.cpp:205-211: `layer(data)`, `out->backward(G)`) over libgnncpp_host.so +
+    libgnnx_hip.so -- started as a FRESH CHILD PROCESS after the timed region (never an exec of this process), its JSON lines parsed.
+    hot path (BatchNorm / ReLU switched off: the bench's step) and the reference's full layer, in the data set's as-generated vertex
+    order and with its labels scrambled once at load time (what bench.py's graph builder does for this row width)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "bench_host_api")
+    if not os.path.exists(exe):
+        return {"error": "tests/cpp/bench_host_api not built"}
+    try:
+        r = subprocess.run([exe, str(n), str(e), str(F), str(steps), "2", "2" if both_orders else "0", str(seed)], capture_output=True,
+                           text=True, timeout=900)
+        rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    except Exception as ex:  # informational leg: never fail the bench because of it
+        return {"error": str(ex)[:200]}
+    if r.returncode != 0 or not rows:
+        return {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-200:]}"}
+    out = {"program": "tests/cpp/bench_host_api (child process; graph::GCNConv::forward + tensor::backward through libgnncpp_host.so)",
+           "steps": steps}
+    for row in rows:
+        key = ("scrambled_labels" if row["scrambled_labels"] else "as_generated")
+        d = out.setdefault(key, {})
+        d["hot_path_ms" if row["hot_path_only"] else "full_layer_ms"] = row["ms_per_step"]
+        d["first_call_s_hot" if row["hot_path_only"] else "first_call_s_full"] = row["first_call_s"]
+    best = out.get("scrambled_labels") or out.get("as_generated")
+    out["hot_path_ms"], out["full_layer_ms"] = best.get("hot_path_ms"), best.get("full_layer_ms")
+    out["first_call_s"] = best.get("first_call_s_hot")
+    return out
 
 
 def cpu_baseline(pkg, args, F, abc, seed):

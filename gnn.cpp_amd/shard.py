@@ -506,12 +506,10 @@ class ShardedTrain:
         import numpy as np
         return {"train_step": float(np.mean([s[0][0].elapsed_ms(s[0][1]) for s in self.ev])) if self.ev else None}
 
-    def roofline(self):
-        from bench import HBM_PEAK_GBS
+    def aggregation_stats(self):
         p = self.plan
-        return {"bound": "hbm", "kernel": "n/a for --train-layers (see the default run)", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": 0.0, "traffic": None, "halo_rows_fwd": p.fwd.n_halo, "halo_rows_bwd": p.bwd.n_halo, "local_rows": p.n_local,
-                "schedule": "synchronous exchanges (training step)"}
+        return {"local_rows": p.n_local, "local_nnz": None, "features": None, "spmm_fwd_ms": None, "halo_rows_fwd": p.fwd.n_halo,
+                "halo_rows_bwd": p.bwd.n_halo, "schedule": "synchronous exchanges (training step)"}
 
 
 class ShardedBench:
@@ -676,14 +674,10 @@ class ShardedBench:
             out[nm] = float(np.mean([s[i][0].elapsed_ms(s[i][1]) for s in self.ev])) if self.ev else None
         return out
 
-    def roofline(self):
-        from bench import HBM_PEAK_GBS, spmm_bytes
+    def aggregation_stats(self):
+        """This rank's forward aggregation as raw facts (bench.py turns them into its roofline object; the package knows nothing of
+        the benchmark script)."""
         p = self.plan
-        ms = self.kernel_times()["spmm_fwd"]
-        B = spmm_bytes(p.n_local, p.n_local, p.nnz_local, self.F, bias=True)
-        achieved = B / (ms * 1e-3) / 1e9
-        return {"bound": "hbm", "kernel": "spmm_stream_kernel<64,4,8,0,64> (forward aggregation, slowest rank)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": B, "avg_launch_ms": ms,
-                "halo_rows_fwd": p.fwd.n_halo, "halo_rows_bwd": p.bwd.n_halo, "local_rows": p.n_local,
-                "send_rows_per_peer_fwd": p.fwd.send_counts, "schedule": self.schedule}
+        return {"local_rows": p.n_local, "local_nnz": p.nnz_local, "features": self.F, "spmm_fwd_ms": self.kernel_times()["spmm_fwd"],
+                "halo_rows_fwd": p.fwd.n_halo, "halo_rows_bwd": p.bwd.n_halo, "send_rows_per_peer_fwd": p.fwd.send_counts,
+                "schedule": self.schedule}

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Round profile set (run ON THE GPU BOX through gpurun, from the repo root):
-#   bash scripts/profile_all.sh r02
+#   GIT_HEAD=$(git rev-parse --short HEAD) gpurun -- 'GIT_HEAD='$GIT_HEAD' bash scripts/profile_all.sh r03'
 # For every workload: one `rocprofv3 --kernel-trace --stats` pass and two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE; never
 # combined with a trace domain) of the SAME bench command; for the GEMMs one SQ-counter pass of scripts/exp_gemm.py.  Raw output
 # lands under gpurun_out/prof_<tag>_*; scripts/summarize_profile.py turns it into the small files committed under profiles/.
@@ -11,10 +11,12 @@ OUT="$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 run_set() {  # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_${name}_stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-order-control "$@" > "$OUT/prof_${TAG}_${name}_stats.log" 2>&1
-  rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control "$@" > "$OUT/prof_${TAG}_${name}_fetch.log" 2>&1
-  rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control "$@" > "$OUT/prof_${TAG}_${name}_write.log" 2>&1
-  (cd "$ROOT" && WORKLOAD="${WL:-rmat10m_100m_f256}" PROFILE_CMD="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-order-control $*" \
+  rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_${name}_stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings "$@" > "$OUT/prof_${TAG}_${name}_stats.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings "$@" > "$OUT/prof_${TAG}_${name}_fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings "$@" > "$OUT/prof_${TAG}_${name}_write.log" 2>&1
+  local nnz
+  nnz=$(python3 -c "import json,sys; print([json.loads(l)['config']['nnz'] for l in open(sys.argv[1]) if l.startswith('{')][-1])" "$OUT/prof_${TAG}_${name}_stats.log")
+  (cd "$ROOT" && WORKLOAD="${WL:-rmat10m_100m_f256}" PROFILED_NNZ="$nnz" PROFILE_CMD="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings $*" \
      python3 scripts/summarize_profile.py "${TAG}_bench_${name}" "$OUT/prof_${TAG}_${name}_stats" "$OUT/prof_${TAG}_${name}_fetch" "$OUT/prof_${TAG}_${name}_write")
   echo "profiled $name"
 }
@@ -22,7 +24,7 @@ WL=rmat10m_100m_f256 run_set rmat10m
 WL=rmat1m_10m_f128 run_set rmat1m_10m_f128 --workload rmat1m_10m_f128
 WL=products_2p4m_62m_f100 run_set products_2p4m_62m_f100 --workload products_2p4m_62m_f100
 # whole 2-layer training step on the headline graph: kernel stats only
-rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_train2_stats" -- python3 "$ROOT/bench.py" --train-layers 2 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/prof_${TAG}_train2_stats.log" 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_train2_stats" -- python3 "$ROOT/bench.py" --train-layers 2 --steps 3 --warmup 1 --no-cpu-baseline --no-ceilings > "$OUT/prof_${TAG}_train2_stats.log" 2>&1
 (cd "$ROOT" && python3 scripts/summarize_profile.py "${TAG}_bench_rmat10m_train2" "$OUT/prof_${TAG}_train2_stats")
 echo "profiled train2"
 # GEMM SQ counters (MFMA busy, waits, LDS conflicts) on the three 10M x 256 x 256 products
@@ -31,3 +33,5 @@ TALL_ONLY=1 FS=256 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY S
 TALL_ONLY=1 FS=256 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_gemm_stats" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm_stats.log" 2>&1
 (cd "$ROOT" && python3 scripts/summarize_profile.py --sq "${TAG}_gemm_sq_counters" "$OUT/prof_${TAG}_gemm_sq" "$OUT/prof_${TAG}_gemm_stats")
 echo "profiled gemm sq"
+# nothing but gpurun_out/ travels back from the GPU box: leave a copy of the summaries there (the builder moves them into profiles/)
+mkdir -p "$OUT/profiles_${TAG}" && cp "$ROOT"/profiles/${TAG}_* "$OUT/profiles_${TAG}/"

@@ -92,7 +92,11 @@ def main():
             fb, wb = fetch.get(k, 0.0), write.get(k, 0.0)
             res[k] = {"fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb}
         out = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
-        json.dump({"workload": os.environ.get("WORKLOAD", "rmat10m_100m_f256"), "command": os.environ.get("PROFILE_CMD", "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"),
+        json.dump({"workload": os.environ.get("WORKLOAD", "rmat10m_100m_f256"),
+                   # provenance bench.py prints beside `traffic` so that a stale file shows: the commit the profiled build was made
+                   # from (the GPU box has no .git: the caller passes it) and the graph's non-zeros as the profiled bench reported them
+                   "git_head": os.environ.get("GIT_HEAD"), "nnz": int(os.environ["PROFILED_NNZ"]) if os.environ.get("PROFILED_NNZ") else None,
+                   "command": os.environ.get("PROFILE_CMD", "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"),
                    "note": "per launch; hbm_bytes_corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
                            "MI355X_MICROARCH.md section HBM; calibrate on colsum_stage1 = 4*N*F bytes read once)",
                    "kernels": res}, open(out, "w"), indent=1)

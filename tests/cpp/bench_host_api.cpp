@@ -28,14 +28,15 @@ static inline uint64_t splitmix64(uint64_t x)
 
 static double now_s() { return chrono::duration<double>(chrono::steady_clock::now().time_since_epoch()).count(); }
 
-// One configuration: edges of the given vertex order, one layer, first call + timed steps; prints one JSON line.
-static void run_config(long n, long e, size_t F, int steps, bool hot, bool scramble, uint64_t seed)
+// R-MAT edge list in the given vertex order (OpenMP over edges; the same SplitMix64 stream as gnn.cpp_amd/synth.py).
+static double gen_edges(long n, long e, bool scramble, uint64_t seed, vector<int> &src, vector<int> &dst)
 {
     int scale = 1;
     while ((1l << scale) < n) scale++;
     const uint64_t key = splitmix64(seed), G = 0x9E3779B97F4A7C15ull;
     const uint32_t ta = (uint32_t)(0.57 * 4294967296.0), tb = (uint32_t)(0.76 * 4294967296.0), tc = (uint32_t)(0.95 * 4294967296.0);
-    vector<int> src(e), dst(e);
+    src.resize(e);
+    dst.resize(e);
     double t0 = now_s();
 #pragma omp parallel for
     for (long i = 0; i < e; i++) {
@@ -50,17 +51,19 @@ static void run_config(long n, long e, size_t F, int steps, bool hot, bool scram
         src[i] = scramble ? graph::scrambled_label((int)s, (size_t)n) : (int)s;
         dst[i] = scramble ? graph::scrambled_label((int)d, (size_t)n) : (int)d;
     }
-    double t_gen = now_s() - t0;
+    return now_s() - t0;
+}
 
-    manual_seed(7);
+// One configuration: one layer over the given edge list; first call + timed steps; prints one JSON line.
+static void run_config(long n, long e, size_t F, int steps, bool hot, bool scramble, uint64_t seed, double t_gen, const vector<int> &src,
+                       const vector<int> &dst, tptr<float> x, tptr<float> g)
+{
     auto ei = graph::vec_to_edge_list(src, dst);
-    auto x = randn({(size_t)n, F}, -1, 1, true);
-    auto g = randn({(size_t)n, F}, -1, 1, false);
     graph::Data data(x, ei.get());
     graph::GCNConv layer(F, F);
     layer.hot_path_only = hot;
 
-    t0 = now_s();
+    double t0 = now_s();
     auto out = layer(data);  // first call: uploads, CSR build, norm, plans
     out->backward(g);
     gnnx_device_sync();
@@ -97,11 +100,18 @@ int main(int argc, char **argv)
     const int hot = argc > 5 ? atoi(argv[5]) : 1;            // 1 hot path, 0 full BatchNorm + ReLU layer, 2 both
     const int scramble = argc > 6 ? atoi(argv[6]) : 0;       // 0 as generated, 1 scrambled labels, 2 both
     const uint64_t seed = argc > 7 ? (uint64_t)atoll(argv[7]) : 1;
+    // features and upstream gradient: drawn once, shared by every configuration (their values do not depend on the vertex order; the
+    // first configuration's first_call_s includes their upload, the later ones find them resident)
+    manual_seed(7);
+    auto x = randn({(size_t)n, F}, -1, 1, true);
+    auto g = randn({(size_t)n, F}, -1, 1, false);
+    vector<int> src, dst;
     for (int sc = 0; sc < 2; sc++) {
         if (scramble != 2 && sc != scramble) continue;
+        const double t_gen = gen_edges(n, e, sc != 0, seed, src, dst);
         for (int h = 1; h >= 0; h--) {
             if (hot != 2 && h != hot) continue;
-            run_config(n, e, F, steps, h != 0, sc != 0, seed);
+            run_config(n, e, F, steps, h != 0, sc != 0, seed, t_gen, src, dst, x, g);
         }
     }
     return 0;
