@@ -95,7 +95,6 @@ _SIGS = {
     "gnnx_gemm_bn_stats_f32": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp],
     "gnnx_gemm_split_workspace": [_i64, _i64, _i64, C.POINTER(_sz)],
     "gnnx_gemm_split_bf16_f32": [C.c_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _sz, _vp],
-    "gnnx_mfma_peak_f32": [_i32, _i32, _vp, C.POINTER(_f64), _vp],
     "gnnx_colsum_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_colsum_f32": [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp],
     "gnnx_rowscale_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],

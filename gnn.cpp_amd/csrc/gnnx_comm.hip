@@ -81,10 +81,13 @@ struct LocalGroup {
         const char *send = nullptr;
         const int64_t *send_bytes = nullptr;
         float *reduce_buf = nullptr;
+        int device = -1;  // the device the rank's thread had current when it entered the collective
     };
     std::vector<Slot> slots;
 
-    // all ranks arrive -> all leave; false if a peer abandoned the group (its handle was destroyed mid-collective)
+    // all ranks arrive -> all leave; false if a peer abandoned the group before this barrier completed (its handle was destroyed
+    // mid-collective).  The reason for waking up is what counts: a peer that has passed the LAST barrier of a collective may destroy
+    // its handle (setting `broken`) before a released rank re-acquires the mutex -- that rank's barrier did complete.
     bool barrier()
     {
         std::unique_lock<std::mutex> lk(mu);
@@ -97,7 +100,7 @@ struct LocalGroup {
             return true;
         }
         cv.wait(lk, [&] { return generation != gen || broken; });
-        return !broken;
+        return generation != gen;
     }
     void abandon()
     {
@@ -106,6 +109,22 @@ struct LocalGroup {
         cv.notify_all();
     }
 };
+
+// The local all-reduce's kernel reads every peer's buffer directly: when the ranks' threads drive different GPUs that needs peer
+// access from this rank's device to each peer's (enabled on first use; GNNX_ERR_UNSUPPORTED if the topology does not allow it).
+int ensure_peer_access(int my_dev, int peer_dev)
+{
+    if (my_dev == peer_dev) return GNNX_OK;
+    int can = 0;
+    GNNX_HIP_CHECK(hipDeviceCanAccessPeer(&can, my_dev, peer_dev));
+    GNNX_REQUIRE(can, GNNX_ERR_UNSUPPORTED, "local communicator: device %d cannot access device %d (no peer access): use the RCCL transport",
+                 my_dev, peer_dev);
+    const hipError_t e = hipDeviceEnablePeerAccess(peer_dev, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return set_error(GNNX_ERR_HIP, "hipDeviceEnablePeerAccess(%d) from device %d failed: %s", peer_dev, my_dev, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return GNNX_OK;
+}
 
 __global__ void sum_buffers_kernel(const float *const *bufs, int world, int64_t n, float *out)
 {
@@ -301,12 +320,18 @@ GNNX_API int gnnx_allreduce_sum_f32(gnnx_comm *comm, float *d_buf, int64_t n, vo
         const int P = g.world;
         if (P == 1) return GNNX_OK;
         GNNX_HIP_CHECK(hipStreamSynchronize(st));
+        int my_dev = 0;
+        GNNX_HIP_CHECK(hipGetDevice(&my_dev));
         g.slots[comm->rank].reduce_buf = d_buf;
+        g.slots[comm->rank].device = my_dev;
         GNNX_REQUIRE(g.barrier(), GNNX_ERR_HIP, "local communicator: a peer left the group");
         float *tmp = nullptr;
         const float **ptrs = nullptr;
         int status = GNNX_OK;
-        if (hipMalloc((void **)&tmp, sizeof(float) * (size_t)n) != hipSuccess ||
+        for (int q = 0; q < P && status == GNNX_OK; q++) status = ensure_peer_access(my_dev, g.slots[q].device);
+        if (status != GNNX_OK) {
+            // no early return between the two barriers: the peers are waiting in the second one
+        } else if (hipMalloc((void **)&tmp, sizeof(float) * (size_t)n) != hipSuccess ||
             hipMalloc((void **)&ptrs, sizeof(float *) * (size_t)P) != hipSuccess)
             status = set_error(GNNX_ERR_HIP, "local communicator: hipMalloc failed");
         if (status == GNNX_OK) {

@@ -729,6 +729,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *slab, i
     }
 }
 
+#ifdef GNNX_EXPERIMENTS
 // Calibration: register-only MFMA loop (4 independent accumulators per wavefront, no memory traffic) -- what the
 // fp32 matrix pipe sustains on THIS chip at the clock it holds under load; the GEMM's fraction of that is the honest
 // utilisation figure next to the 157.3 TFLOP/s datasheet peak.
@@ -773,6 +774,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(int iters, float *sink)
     for (int i = 0; i < 4; i++) s += acc[i][0] + acc[i][7];
     if (s == 12345.678f) sink[0] = s;  // keep the loop alive
 }
+#endif  // GNNX_EXPERIMENTS
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -1158,6 +1160,9 @@ __global__ __launch_bounds__(256) void gemm_transpose_w_kernel(const float *X, i
 
 }  // namespace
 
+#ifdef GNNX_EXPERIMENTS
+// Measurement entry of the EXPERIMENTS build only (scripts/exp_gemm.py; not declared in include/gnnx.h): a register-only f32 MFMA
+// loop, optionally with extra instructions per MFMA (GNNX_PEAK_MODE), to calibrate what bounds such a loop on this chip.
 GNNX_API int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_sink, double *flops_out, void *stream)
 {
     GNNX_REQUIRE(iters > 0 && n_workgroups > 0 && d_sink, GNNX_ERR_INVALID_ARG, "bad arguments");
@@ -1165,7 +1170,6 @@ GNNX_API int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_si
     const dim3 pg((uint32_t)n_workgroups), pb(256);
     hipStream_t pst = as_stream(stream);
     switch (peak_mode) {
-#ifdef GNNX_EXPERIMENTS
     case 1: hipLaunchKernelGGL(mfma_peak_kernel<1>, pg, pb, 0, pst, iters, d_sink); break;
     case 2: hipLaunchKernelGGL(mfma_peak_kernel<2>, pg, pb, 0, pst, iters, d_sink); break;
     case 4: hipLaunchKernelGGL(mfma_peak_kernel<4>, pg, pb, 0, pst, iters, d_sink); break;
@@ -1174,13 +1178,13 @@ GNNX_API int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_si
     case 12: hipLaunchKernelGGL(mfma_peak_kernel<12>, pg, pb, 0, pst, iters, d_sink); break;
     case 20: hipLaunchKernelGGL(mfma_peak_kernel<20>, pg, pb, 0, pst, iters, d_sink); break;
     case 21: hipLaunchKernelGGL(mfma_peak_kernel<21>, pg, pb, 0, pst, iters, d_sink); break;
-#endif
     default: hipLaunchKernelGGL(mfma_peak_kernel<0>, pg, pb, 0, pst, iters, d_sink); break;
     }
     GNNX_LAUNCH_CHECK();
     if (flops_out) *flops_out = (double)n_workgroups * 4 /*waves*/ * 4 /*acc*/ * (double)iters * (2.0 * 32 * 32 * 2);
     return GNNX_OK;
 }
+#endif  // GNNX_EXPERIMENTS
 
 GNNX_API int gnnx_gemm_workspace(int transA, int transB, int64_t M, int64_t N, int64_t K, size_t *bytes)
 {

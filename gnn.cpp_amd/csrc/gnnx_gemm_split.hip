@@ -261,7 +261,7 @@ GNNX_API int gnnx_gemm_split_bf16_f32(int transB, int64_t M, int64_t N, int64_t 
     hipLaunchKernelGGL(split_b_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_B, ldb, transB ? 1 : 0, (int32_t)N, (int32_t)K, bp);
     GNNX_LAUNCH_CHECK();
     SplitArgs g{M, (int32_t)N, (int32_t)K, d_A, lda, bp, d_C, ldc};
-    static const int nb_env = [] { const char *e = getenv("GNNX_SPLIT_NB"); return e ? atoi(e) : 0; }();  // A/B: force the tile width
+    static const int nb_env = [] { const char *e = experiment_env("GNNX_SPLIT_NB"); return e ? atoi(e) : 0; }();  // A/B: force the tile width
     if (N % 256 == 0 && nb_env != 2) return launch_split<4>(g, st);
     return launch_split<2>(g, st);
 }

@@ -613,7 +613,10 @@ class GcnStack:
         for l in reversed(range(L)):
             h, Y = self._saved[l]
             if self.padded:
-                dH = self._zeros(("dH", P[l + 1]), (G.shape[0], P[l + 1]), G.device)   # streamed: padded width
+                # streamed: padded width.  One buffer per (padded, logical) width pair: the aggregation writes columns [:d] only, so two
+                # layers whose widths differ but round to the same 128-float bucket must not share pad columns (a narrower layer
+                # would inherit the wider one's values there, and dW / W pads would stop being zero)
+                dH = self._zeros(("dH", P[l + 1], d[l + 1]), (G.shape[0], P[l + 1]), G.device)
                 aggregate_bwd(self.g, G, out=dH[:, :d[l + 1]])
                 Wl, hl = self.Wp[l][:, :d[l]], h[:, :d[l]]            # [P_out, d_in] (ld P_in); the layer input, logical width
                 gemm(dH, h, transA=True, out=self.dWp[l])             # dW_l = dH^T . h on the padded widths

@@ -266,11 +266,6 @@ int gnnx_gemm_split_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes);
 int gnnx_gemm_split_bf16_f32(int transB, int64_t M, int64_t N, int64_t K, const float *d_A, int64_t lda, const float *d_B,
                              int64_t ldb, float *d_C, int64_t ldc, void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* Calibration aid for the roofline: a register-only v_mfma_f32_32x32x2_f32 loop (no memory traffic).  *flops_out is
- * the number of flops the launch performs; time it with events to get the fp32 matrix rate this chip sustains at the
- * clock it holds under load. */
-int gnnx_mfma_peak_f32(int32_t iters, int32_t n_workgroups, float *d_sink, double *flops_out, void *stream);
-
 /* ------------------------------------------------------------------ small ops on the path -------- */
 /* dbias: out[f] = beta*out[f] + sum_i G[i,f]  (Add::_backward -> sum_to_size, reference operation.h:114-128,
  * tensor.h:618-638).  Two-stage deterministic tree (fixed grid); workspace gnnx_colsum_workspace() bytes. */
@@ -404,8 +399,11 @@ int gnnx_scatter_add_rows_f32(const float *d_in, int64_t ldi, const int32_t *d_i
  *         channel the host program has).
  *   local (gnnx_comm_init_local): the `world` ranks are threads of ONE process; handles for all ranks are created by one call
  *         and handed to the threads.  Collectives rendezvous on host memory and move data with device copies on each rank's
- *         stream (they synchronise that stream).  Destroying a handle while peers wait in a collective fails their call
- *         instead of hanging it.
+ *         stream (they synchronise that stream).  Rank threads may drive different GPUs: the all-to-all-v uses device-to-device
+ *         copies, the all-reduce reads every peer's buffer from a kernel and enables peer access between the ranks' devices on
+ *         first use (GNNX_ERR_UNSUPPORTED where the topology has none: use the RCCL transport there).  Destroying a handle while
+ *         peers wait in a collective fails their call instead of hanging it; a collective that completed is never failed by a
+ *         peer's later destroy.
  * gnnx_halo_exchange_f32 is the all-to-all-v of the halo step: rows for peer p are send_rows[p] consecutive rows of d_send
  * (peer-major, as gnnx_gather_rows_f32 packs them with the peer-major send list), rows from peer p land as recv_rows[p]
  * consecutive rows of d_recv (the [halo] tail of the feature buffer, halo ids being grouped by owner).  On RCCL: one group of

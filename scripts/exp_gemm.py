@@ -61,11 +61,14 @@ main()
 
 
 def mfma_peak():
+    """GNNX_HIP_LIB=exp only: gnnx_mfma_peak_f32 is a measurement entry of the EXPERIMENTS build, not of include/gnnx.h."""
     sink = torch.zeros(16, dtype=torch.float32, device=dev)
     fl = C.c_double(0)
+    fn = capi.lib().gnnx_mfma_peak_f32
+    fn.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]
     for wgs in (256, 512, 1024, 2048):
-        capi.call("gnnx_mfma_peak_f32", 20000, wgs, C.c_void_p(sink.data_ptr()), C.byref(fl), None)
-        ms = timeit(lambda: capi.call("gnnx_mfma_peak_f32", 20000, wgs, C.c_void_p(sink.data_ptr()), C.byref(fl), None), reps=3)
+        fn(20000, wgs, C.c_void_p(sink.data_ptr()), C.byref(fl), None)
+        ms = timeit(lambda: fn(20000, wgs, C.c_void_p(sink.data_ptr()), C.byref(fl), None), reps=3)
         print(f"mfma peak loop, {wgs} workgroups x 4 waves: {fl.value / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 

@@ -397,9 +397,49 @@ static void test_two_layer_training_step_sharded(int world)
     }
 }
 
+// Teardown order of the in-process communicator (C-ABI level): every rank does one all-reduce and destroys its handle at once.  A
+// rank that has left the collective's last barrier may destroy its handle before a released peer has re-acquired the group's mutex;
+// that peer's collective DID complete and must not report "a peer left the group".
+static void test_local_comm_destroy_right_after_a_collective()
+{
+    const int world = 4, rounds = 200;
+    int bad = 0;
+    for (int it = 0; it < rounds; it++) {
+        vector<gnnx_comm *> comms((size_t)world, nullptr);
+        if (gnnx_comm_init_local(comms.data(), world) != 0) {
+            bad++;
+            break;
+        }
+        vector<int> rc((size_t)world, -1);
+        vector<float> got((size_t)world, 0.f);
+        vector<thread> th;
+        for (int r = 0; r < world; r++)
+            th.emplace_back([&, r] {
+                void *st = nullptr, *buf = nullptr;
+                gnnx_set_device(0);
+                gnnx_stream_create(&st);
+                gnnx_malloc(&buf, 64 * sizeof(float));
+                vector<float> h(64, (float)(r + 1));
+                gnnx_memcpy_h2d(buf, h.data(), 64 * sizeof(float), st);
+                rc[r] = gnnx_allreduce_sum_f32(comms[r], (float *)buf, 64, st);
+                gnnx_comm_destroy(comms[r]);  // at once: peers may still be on their way out of the last barrier
+                gnnx_memcpy_d2h(h.data(), buf, 64 * sizeof(float), st);
+                gnnx_stream_sync(st);
+                got[r] = h[7];
+                gnnx_free(buf);
+                gnnx_stream_destroy(st);
+            });
+        for (auto &t : th) t.join();
+        for (int r = 0; r < world; r++)
+            if (rc[r] != 0 || got[r] != 10.f) bad++;
+    }
+    CHECK(bad == 0);
+}
+
 int main()
 {
     try {
+        test_local_comm_destroy_right_after_a_collective();
         for (int world : {2, 3}) test_two_layer_training_step_sharded(world);
         test_graph_cache_is_keyed_on_content();
         const Problem p = make_problem(20000, 240000, 48, 32);

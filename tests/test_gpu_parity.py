@@ -404,7 +404,7 @@ def test_gcn_stack_backward_fused_equals_unfused(env):
         assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
 
 
-@pytest.mark.parametrize("dims", [[100, 100, 100, 100], [100, 72, 47]])
+@pytest.mark.parametrize("dims", [[100, 100, 100, 100], [100, 72, 47], [128, 120, 100, 47]])
 def test_gcn_stack_padded_streamed_layout_same_bits(env, dims):
     """Widths off the 128 grid: the stack that stores its streamed matrices (Y_l, dH_l, W_l, dW_l) on 128-float strides and keeps
     the gathered ones (H_l, G_l) at their own width gives the same logits and input gradient bit for bit as the
@@ -439,14 +439,20 @@ def test_gcn_stack_padded_streamed_layout_same_bits(env, dims):
         net.forward(wide[:, :dims[0]])
     with pytest.raises(ValueError):
         ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), n, relabel=torch.zeros(n, dtype=torch.int32, device=env["dev"]))
-    net.backward(dOut)
-    net.step(lr=0.01, weight_decay=1e-4)
-    for l in range(len(dims) - 1):
-        do, di = dims[l + 1], dims[l]
-        for t in (net.Wp[l], net.dWp[l]):
-            assert not t[do:].any() and not t[:, di:].any(), "pads of W / dW must stay zero"
-    for (hp, Yp), l in zip(net._saved, range(len(dims) - 1)):
-        assert not Yp[:, dims[l + 1]:].any() and not hp[:, dims[l]:].any()
+    # two more training steps on both stacks: pads stay zero (two layers whose widths differ inside one 128-float bucket -- 120 and
+    # 100 -- must not share a zero-padded gradient buffer), and the padded stack keeps tracking the packed one
+    for step in range(2):
+        for nt in nets:
+            nt.forward(nt.pad_input(X))
+            nt.backward(dOut)
+            nt.step(lr=0.01, weight_decay=1e-4)
+        for l in range(len(dims) - 1):
+            do, di = dims[l + 1], dims[l]
+            for t in (net.Wp[l], net.dWp[l]):
+                assert not t[do:].any() and not t[:, di:].any(), f"pads of W / dW must stay zero (step {step}, layer {l})"
+            torch.testing.assert_close(net.W[l], nets[1].W[l], rtol=1e-4, atol=1e-5 * float(nets[1].W[l].abs().max()))
+        for (hp, Yp), l in zip(net._saved, range(len(dims) - 1)):
+            assert not Yp[:, dims[l + 1]:].any() and not hp[:, dims[l]:].any()
 
 
 def test_gemm_beta_accumulate(env):
