@@ -412,20 +412,33 @@ __device__ __forceinline__ void lds_read_b32(float &dst, uint32_t addr)
 
 // Geometry of an LDS-DMA GEMM workgroup: WM x WN wavefronts of 64 x 64 -> BM x BN output tile.  4 x 4 (1024 threads, 256 x 256)
 // is the bench shape; 4 x 2 (512 threads, 256 x 128) takes 128-wide outputs (BASELINE configs[2]).  A k-major operand row of
-// 256 floats is one wave-instruction (padded to 272 words in LDS: conflict-free); one of 128 floats is half of one, two
-// consecutive k rows per instruction, which forces an unpadded 128-word stride (2-way conflicts on those reads: 4 instead of 2
-// LDS cycles; LDS stays far from saturated).
+// 256 floats is one wave-instruction; one of 128 floats is half of one, so an instruction carries two rows (k and k + 16): see the
+// operand image below -- conflict-free fragment reads at both widths.
 template <int WM_, int WN_>
 struct DmaGeo {
     static constexpr int WM = WM_, WN = WN_, NW = WM * WN, NT = 64 * NW;
     static constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
     static constexpr int A_STAGE_BYTES = BM * BK * 4;                 // K-contiguous image: [BM rows][8 slots of 16 B]
     static constexpr int A_PER_WAVE = (BM / 8) / NW;                  // 1-KiB wave-instructions per wavefront and K-tile
-    static constexpr int row_words(int width) { return width == 256 ? 272 : width; }
+    // k-major operand image (B here, both operands of the TN kernel): one DMA wave-instruction = 1 KiB = one k row of 256 floats or
+    // TWO k rows of 128, landing in a piece of 272 words (256 of data + 16 of padding: every instruction has its own LDS base, so
+    // pieces can be padded although the bytes of one instruction cannot).  A fragment read takes word (k = 4 KG + q, column c) for
+    // the four q of a wavefront at once, so consecutive q must sit 16 banks apart: with one row per piece they are consecutive
+    // pieces (272 = 16 mod 64); with two rows per piece the instruction carries rows I and I + 16 -- NOT two neighbours, which would
+    // put q and q + 1 a multiple of 64 words apart (the 2-way conflict of the first version: 0.69 of the matrix peak at N = 128) --
+    // so that rows 4 KG .. 4 KG + 3 are again four consecutive pieces.
     static constexpr int rows_per_instr(int width) { return 256 / width; }
-    static constexpr int BROW = row_words(BN);                        // k-major B: row stride in floats
-    static constexpr int B_STAGE_BYTES = BK * BROW * 4;
-    static constexpr int B_PIECE_BYTES = rows_per_instr(BN) * BROW * 4;   // LDS bytes one B wave-instruction covers (>= 1024)
+    static constexpr int KPIECE_BYTES = 272 * 4;
+    static constexpr int kstage_bytes(int width) { return (BK / rows_per_instr(width)) * KPIECE_BYTES; }
+    // byte offset of k-group KG (rows 4 KG .. 4 KG + 3; the row inside the group is q * KPIECE_BYTES in the lane's address register)
+    static constexpr int kgroup_off(int width, int KG)
+    {
+        return rows_per_instr(width) == 1 ? 4 * KG * KPIECE_BYTES : (4 * (KG % 4)) * KPIECE_BYTES + (KG / 4) * 512;
+    }
+    // k row (inside the K-tile) that lane `lane` of wave-instruction I brings
+    static constexpr int krow_of(int width, int I, int lane) { return rows_per_instr(width) == 1 ? I : I + (BK / 2) * (lane / 32); }
+    static constexpr int B_STAGE_BYTES = kstage_bytes(BN);
+    static constexpr int B_PIECE_BYTES = KPIECE_BYTES;                 // LDS bytes one B wave-instruction covers (>= 1024)
     static constexpr int B_PER_WAVE = (BK / rows_per_instr(BN)) / NW;
     static constexpr int LDS_BYTES = 2 * A_STAGE_BYTES + 2 * B_STAGE_BYTES;
     static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1 && A_PER_WAVE + B_PER_WAVE >= 4, "the epilogue needs four private 1-KiB pieces");
@@ -439,7 +452,7 @@ __device__ __forceinline__ void dma2_read_group(float (&a)[4], float (&b)[4], co
     lds_read_b32<SA + 1 * 2048>(a[1], ak[KG]);
     lds_read_b32<SA + 2 * 2048>(a[2], ak[KG]);
     lds_read_b32<SA + 3 * 2048>(a[3], ak[KG]);
-    constexpr int SB = STAGE_ID * GEO::B_STAGE_BYTES + 4 * KG * GEO::BROW * 4;  // k row 4 KG + q (q is in the address register)
+    constexpr int SB = STAGE_ID * GEO::B_STAGE_BYTES + GEO::kgroup_off(GEO::BN, KG);  // k row 4 KG + q (q is in the address register)
     lds_read_b32<SB + 0 * 64>(b[0], bk);
     lds_read_b32<SB + 1 * 64>(b[1], bk);
     lds_read_b32<SB + 2 * 64>(b[2], bk);
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
 {
     (void)ablate;
     using GEO = DmaGeo<WM_, WN_>;
-    constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK, NW = GEO::NW, BROW = GEO::BROW;
+    constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK, NW = GEO::NW;
     constexpr int APW = GEO::A_PER_WAVE, BPW = GEO::B_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][A stage], then [2][B stage]
     const int tid = threadIdx.x;
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
 #pragma unroll
     for (int u = 0; u < BPW; u++) {
         constexpr int RPI = GEO::rows_per_instr(BN), LPR = 64 / RPI;   // k rows per instruction, lanes per row
-        const int krow = (wave + NW * u) * RPI + lane / LPR;
+        const int krow = GEO::krow_of(BN, wave + NW * u, lane);
         offb[u] = (uint32_t)(krow * g.ldb + 4 * (lane % LPR)) * 4u;
         pb[u] = lds0 + B0 + (uint32_t)((wave + NW * u) * GEO::B_PIECE_BYTES);
     }
@@ -557,7 +570,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
 #pragma unroll
         for (int kg = 0; kg < 8; kg++) ak[kg] = lds0 + (uint32_t)(row * 128 + 4 * q) + (((uint32_t)kg << 4) ^ xa);
     }
-    const uint32_t bk = lds0 + B0 + (uint32_t)(q * BROW * 4 + (wn * 64 + r16) * 4);
+    const uint32_t bk = lds0 + B0 + (uint32_t)(q * GEO::KPIECE_BYTES + (wn * 64 + r16) * 4);
     // ---- epilogue through LDS.  D = mfma(b, a): a lane holds C[16 i + r16][16 j + 4 q .. + 3] of its wavefront's 64 x 64
     // block.  Block row i (16 rows x 64 columns = 4 KB) is written to four of the wavefront's OWN DMA pieces of stage 1 (free
     // after the tile's last K-tile; only this wavefront's next DMA overwrites them, and that is issued behind its reads), piece
@@ -939,8 +952,8 @@ int launch_stream(const GemmArgs &g, bool b_kc, int waves_per_slot, hipStream_t 
 template <class GEO, int STAGE_ID, int KG>
 __device__ __forceinline__ void dma_tn_read_group(float (&a)[4], float (&b)[4], uint32_t ak, uint32_t bk)
 {
-    constexpr int SA = STAGE_ID * GEO::AT_STAGE_BYTES + 4 * KG * GEO::AROW * 4;
-    constexpr int SB = STAGE_ID * GEO::B_STAGE_BYTES + 4 * KG * GEO::BROW * 4;
+    constexpr int SA = STAGE_ID * GEO::AT_STAGE_BYTES + GEO::kgroup_off(GEO::BM, KG);
+    constexpr int SB = STAGE_ID * GEO::B_STAGE_BYTES + GEO::kgroup_off(GEO::BN, KG);
     lds_read_b32<SA + 0 * 64>(a[0], ak);
     lds_read_b32<SA + 1 * 64>(a[1], ak);
     lds_read_b32<SA + 2 * 64>(a[2], ak);
@@ -970,9 +983,8 @@ __device__ __forceinline__ void dma_tn_read_group(float (&a)[4], float (&b)[4], 
 template <int WM_, int WN_>
 struct DmaGeoTN : DmaGeo<WM_, WN_> {
     using Base = DmaGeo<WM_, WN_>;
-    static constexpr int AROW = Base::row_words(Base::BM);
-    static constexpr int AT_STAGE_BYTES = Base::BK * AROW * 4;
-    static constexpr int AT_PIECE_BYTES = Base::rows_per_instr(Base::BM) * AROW * 4;
+    static constexpr int AT_STAGE_BYTES = Base::kstage_bytes(Base::BM);
+    static constexpr int AT_PIECE_BYTES = Base::KPIECE_BYTES;
     static constexpr int AT_PER_WAVE = (Base::BK / Base::rows_per_instr(Base::BM)) / Base::NW;
     static constexpr int LDS_BYTES_TN = 2 * AT_STAGE_BYTES + 2 * Base::B_STAGE_BYTES;
     static_assert(AT_PER_WAVE >= 1, "too many wavefronts for the operand tile");
@@ -1000,13 +1012,13 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_tn_kernel(GemmArgs g)
 #pragma unroll
     for (int u = 0; u < APW; u++) {
         constexpr int RPI = GEO::rows_per_instr(BM), LPR = 64 / RPI;
-        offa[u] = (uint32_t)(((wave + NW * u) * RPI + lane / LPR) * g.lda + 4 * (lane % LPR)) * 4u;
+        offa[u] = (uint32_t)(GEO::krow_of(BM, wave + NW * u, lane) * g.lda + 4 * (lane % LPR)) * 4u;
         pa[u] = lds0 + (uint32_t)((wave + NW * u) * GEO::AT_PIECE_BYTES);
     }
 #pragma unroll
     for (int u = 0; u < BPW; u++) {
         constexpr int RPI = GEO::rows_per_instr(BN), LPR = 64 / RPI;
-        offb[u] = (uint32_t)(((wave + NW * u) * RPI + lane / LPR) * g.ldb + 4 * (lane % LPR)) * 4u;
+        offb[u] = (uint32_t)(GEO::krow_of(BN, wave + NW * u, lane) * g.ldb + 4 * (lane % LPR)) * 4u;
         pb[u] = lds0 + B0 + (uint32_t)((wave + NW * u) * GEO::B_PIECE_BYTES);
     }
     const float *acol = g.A + m0, *bcol = g.B + n0;
@@ -1019,8 +1031,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_tn_kernel(GemmArgs g)
             if (u < BPW) dma_16B(offb[u < BPW ? u : 0], bbase, pb[u < BPW ? u : 0] + stage * GEO::B_STAGE_BYTES);
         }
     };
-    const uint32_t ak = lds0 + (uint32_t)(q * GEO::AROW * 4 + (wm * 64 + r16) * 4);
-    const uint32_t bk = lds0 + B0 + (uint32_t)(q * GEO::BROW * 4 + (wn * 64 + r16) * 4);
+    const uint32_t ak = lds0 + (uint32_t)(q * GEO::KPIECE_BYTES + (wm * 64 + r16) * 4);
+    const uint32_t bk = lds0 + B0 + (uint32_t)(q * GEO::KPIECE_BYTES + (wn * 64 + r16) * 4);
     gemm_f32x4acc acc[4][4];
     float a[2][4], b[2][4];
 #pragma unroll
@@ -1076,9 +1088,10 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
     if ((int64_t)BM * g.lda >= (1ll << 28) || (int64_t)BK * g.ldb >= (1ll << 28) || (int64_t)BM * g.ldc >= (1ll << 28))
         return GNNX_OK;  // per-lane BYTE offsets are 32-bit
     const int64_t m_tiles = g.M / BM, cols = ceil_div(g.N, (int64_t)BN);
-    int64_t gy = ceil_div((int64_t)kNumCU, cols);
+    constexpr size_t lds = GEO::LDS_BYTES;   // 4 x 4: 2 x (32 KB + 34 KB) = 132 KB; 4 x 2: 2 x (32 KB + 17 KB) = 98 KB; 2 x 2: 66 KB
+    constexpr int wg_per_cu = 160 * 1024 / lds >= 2 ? 2 : 1;   // resident workgroups: as many as the LDS of a CU holds
+    int64_t gy = ceil_div((int64_t)kNumCU * wg_per_cu, cols);
     if (gy > m_tiles) gy = m_tiles;
-    constexpr size_t lds = GEO::LDS_BYTES;   // 4 x 4: 2 x (32 KB + 34 KB) = 132 KB; 4 x 2: 2 x (32 KB + 16 KB) = 96 KB
     static std::atomic<uint64_t> done_plain{0}, done_fuse{0}, done_stats{0};
     static const int ablate = [] { const char *e = experiment_env("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
@@ -1118,6 +1131,11 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const Gemm
     if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return GNNX_OK;
     if (fuse_mode == 3 && g.alpha != 1.0f) return GNNX_OK;
     if (g.N % 256 == 0) return launch_dma_geo<4, 4, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    static const int geo128 = [] { const char *e = experiment_env("GNNX_GEMM_GEO128"); return e ? atoi(e) : 0; }();
+    if (geo128 == 22) {   // A/B: 128 x 128 tiles, two resident workgroups of 4 wavefronts per CU
+        if (g.N % 128 == 0) return launch_dma_geo<2, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+        return launch_dma_geo<2, 2, true>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    }
     if (g.N % 128 == 0) return launch_dma_geo<4, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
     return launch_dma_geo<4, 2, true>(g, st, rows_done, fuse, partial_rows, fuse_mode);
 }

@@ -46,9 +46,35 @@ using tptr = std::shared_ptr<tensor<A>>;
 namespace detail {
 
 // One logical buffer with a host copy and/or a device copy; whichever was written last is authoritative.
+// A backend op may ask that the NEXT op result of a given size carries spare device elements behind its data (the sharded
+// layer: the transform's output [n_local, F] gets room for the halo rows, so the all-to-all-v receives straight behind the rows the
+// GEMM wrote and the aggregation gathers from one [local | halo] buffer without a copy).  Per thread, consumed by the first
+// device result whose element count matches, dropped by the guard's destructor if nothing matched.
+struct TailReservation {
+    size_t match_numel, tail_elems;
+    static TailReservation *&pending()
+    {
+        static thread_local TailReservation *p = nullptr;
+        return p;
+    }
+    TailReservation(size_t match_numel_, size_t tail_elems_) : match_numel(match_numel_), tail_elems(tail_elems_) { pending() = this; }
+    ~TailReservation()
+    {
+        if (pending() == this) pending() = nullptr;
+    }
+    static size_t take(size_t numel)
+    {
+        TailReservation *p = pending();
+        if (!p || p->match_numel != numel) return 0;
+        pending() = nullptr;
+        return p->tail_elems;
+    }
+};
+
 template <class T>
 struct Store {
     size_t n = 0;
+    size_t tail = 0;  // spare device elements behind the n logical ones (TailReservation)
     std::valarray<T> *host = nullptr;
     void *dev = nullptr;
     bool host_ok = false, dev_ok = false;
@@ -59,7 +85,7 @@ struct Store {
     ~Store()
     {
         delete host;
-        if (dev) dev_free(dev, n * sizeof(T));
+        if (dev) dev_free(dev, (n + tail) * sizeof(T));
     }
     void adopt_host(std::valarray<T> *h)
     {
@@ -83,7 +109,7 @@ struct Store {
     }
     void ensure_dev_alloc()
     {
-        if (!dev && n) dev = dev_alloc(n * sizeof(T));
+        if (!dev && n) dev = dev_alloc((n + tail) * sizeof(T));
     }
     // device pointer, valid contents
     T *d()
@@ -296,7 +322,10 @@ public:
     {
         CHECK_VALID_DIMS(dims);
         _st = std::make_shared<detail::Store<T>>(numel_of(dims));
+        _st->tail = detail::TailReservation::take(_st->n);
     }
+    // spare device elements behind the data (detail::TailReservation); 0 for views and ordinary results
+    size_t device_tail_capacity() const { return (_st && !_tview) ? _st->tail : 0; }
     tensor(std::shared_ptr<detail::Csr> csr, bool) : _dims({(size_t)csr->n, (size_t)csr->n}), _requires_grad(false), _csr(csr) {}
 
     // ---- plain accessors

@@ -230,9 +230,13 @@ public:
                "BatchNorm");
             part->comm->allreduce_sum(var->device_inplace(), f);
         }
-        Scratch hext_buf(sizeof(float) * (size_t)(nl + part->fwd.n_halo) * (size_t)f);   // back to the pool on every exit path
-        float *hext = hext_buf.as<float>();
-        if (nl) gx(gnnx_memcpy_d2d(hext, h->device_data(), sizeof(float) * (size_t)nl * f, st), "aggregate");
+        // [local | halo] buffer: the transform already wrote its rows at the head of one (GCNConv::forward_sharded reserves the halo
+        // rows behind the product's output: the all-to-all-v receives straight into them, no copy); an `h` from elsewhere is copied
+        const size_t halo_elems = (size_t)part->fwd.n_halo * (size_t)f;
+        const bool in_place = h->device_tail_capacity() >= halo_elems;
+        Scratch hext_buf(in_place ? 0 : sizeof(float) * ((size_t)nl * f + halo_elems));   // back to the pool on every exit path
+        float *hext = in_place ? h->device_data() : hext_buf.as<float>();
+        if (!in_place && nl) gx(gnnx_memcpy_d2d(hext, h->device_data(), sizeof(float) * (size_t)nl * f, st), "aggregate");
         part->exchange(part->fwd, hext, f);
         const bool req = h->requires_grad() || (bias && bias->requires_grad()) || (use_bn && gamma->requires_grad()) ||
                          (has_beta && beta->requires_grad());
@@ -317,7 +321,11 @@ void GCNConv::shard(std::shared_ptr<Partition> part)
 tptr<float> GCNConv::forward_sharded(const tptr<float> &x)
 {
     if (x->rank() != 2 || x->shape()[0] != _part->num_local()) throw std::runtime_error(ERROR_SIZE_MISMATCH);
-    auto h = (*get_module("lin"))(x);
+    tptr<float> h;
+    {   // the product's output [n_local, F_out] gets room for the halo rows behind it (tensor.h: TailReservation)
+        cyg::detail::TailReservation halo_rows(_part->num_local() * _out_channels, (size_t)_part->fwd.n_halo * _out_channels);
+        h = (*get_module("lin"))(x);
+    }
     auto op = std::make_unique<ShardedAggregateOp>();
     op->part = _part;
     tptr<float> gamma, beta;

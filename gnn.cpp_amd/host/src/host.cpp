@@ -63,10 +63,24 @@ void *workspace(size_t bytes)
     return g_ws;
 }
 
+// The per-thread allocator cache and scratch are given back to the device when their thread ends (a rank thread of
+// dist::Comm::local_group that exits must not strand its blocks).
+struct ThreadPool {
+    std::unordered_map<size_t, std::vector<void *>> blocks;
+    ~ThreadPool()
+    {
+        if (g_stream || !blocks.empty() || g_ws) (void)gnnx_stream_sync(g_stream);
+        for (auto &kv : blocks)
+            for (void *p : kv.second) gnnx_free(p);
+        if (g_ws) gnnx_free(g_ws);
+        g_ws = nullptr;
+        g_ws_bytes = 0;
+    }
+};
 static std::unordered_map<size_t, std::vector<void *>> &pool()
 {
-    static thread_local std::unordered_map<size_t, std::vector<void *>> p;
-    return p;
+    static thread_local ThreadPool p;
+    return p.blocks;
 }
 static size_t bucket(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
@@ -97,7 +111,7 @@ void dev_free(void *ptr, size_t bytes)
 Csr::~Csr()
 {
     drop_plans();
-    for (void *p : {rowptr, colidx, rowptr_t, colidx_t, coo_src, coo_dst, norm_per_nz_t, coo_w, vals, vals_t})
+    for (void *p : {rowptr, colidx, rowptr_t, colidx_t, coo_src /* coo_dst lives in the same buffer */, norm_per_nz_t, coo_w, vals, vals_t})
         if (p) gnnx_free(p);
 }
 
@@ -329,7 +343,11 @@ namespace {
 // at BatchNorm's input reaches the transform, operation.h:80-88) instead of the mathematical gradient -- for comparing
 // through-layer gradients with the reference's own (tests/golden ref_full_*).  Off by default.
 using bn_bwd_fn = decltype(&gnnx_bn_relu_bwd_f32);
-bn_bwd_fn bn_backward() { return std::getenv("GNNCPP_REFERENCE_QUIRKS") ? &gnnx_bn_relu_bwd_quirk_f32 : &gnnx_bn_relu_bwd_f32; }
+bn_bwd_fn bn_backward()
+{
+    static const bool quirks = std::getenv("GNNCPP_REFERENCE_QUIRKS") != nullptr;  // read once, not on every backward
+    return quirks ? &gnnx_bn_relu_bwd_quirk_f32 : &gnnx_bn_relu_bwd_f32;
+}
 }  // namespace
 decltype(&gnnx_bn_relu_bwd_f32) bn_backward_fn() { return bn_backward(); }
 namespace {
@@ -571,10 +589,10 @@ tptr<float> edge_to_adj_mat(const tensor<int> &edge_index, tensor<float> *edge_a
     c->n = (int32_t)n;
     c->n_edges = (int64_t)e;
     const int32_t *d = ei.device_data();  // rows 0 (sources) and 1 (destinations), contiguous
-    detail::gx(gnnx_malloc(&c->coo_src, e * sizeof(int32_t)), "adj");
-    detail::gx(gnnx_malloc(&c->coo_dst, e * sizeof(int32_t)), "adj");
-    detail::gx(gnnx_memcpy_d2d(c->coo_src, d, e * sizeof(int32_t), detail::current_stream()), "adj");
-    detail::gx(gnnx_memcpy_d2d(c->coo_dst, d + e, e * sizeof(int32_t), detail::current_stream()), "adj");
+    // one [2, E] buffer like the edge_index tensor itself (coo_dst points into it): the graph cache compares both rows in one pass
+    detail::gx(gnnx_malloc(&c->coo_src, 2 * e * sizeof(int32_t)), "adj");
+    c->coo_dst = static_cast<int32_t *>(c->coo_src) + e;
+    detail::gx(gnnx_memcpy_d2d(c->coo_src, d, 2 * e * sizeof(int32_t), detail::current_stream()), "adj");
     if (edge_attr != nullptr) {  // A[r][c] = w (graph.cpp:38-40)
         detail::gx(gnnx_malloc(&c->coo_w, e * sizeof(float)), "adj");
         detail::gx(gnnx_memcpy_d2d(c->coo_w, edge_attr->device_data(), e * sizeof(float), detail::current_stream()), "adj");
@@ -827,12 +845,10 @@ tptr<float> GCNConv::forward(Data &&input)
         bool hit = _cache_adj && _cache_edges == ei->numel() && _cache_nodes == input.num_nodes();
         if (hit) {
             auto c = _cache_adj->csr();
-            const size_t e = ei->numel() / 2;
-            const int32_t *d = ei->device_data();
-            int same_src = 0, same_dst = 0;
-            detail::gx(gnnx_equal_i32(d, (const int32_t *)c->coo_src, (int64_t)e, &same_src, detail::current_stream()), "graph cache");
-            detail::gx(gnnx_equal_i32(d + e, (const int32_t *)c->coo_dst, (int64_t)e, &same_dst, detail::current_stream()), "graph cache");
-            hit = same_src && same_dst;
+            int same = 0;  // one pass over the [2, E] list, one host synchronisation (the answer decides a host-side branch)
+            detail::gx(gnnx_equal_i32(ei->device_data(), (const int32_t *)c->coo_src, (int64_t)ei->numel(), &same, detail::current_stream()),
+                       "graph cache");
+            hit = same != 0;
         }
         if (!hit) {
             auto adj = edge_to_adj_mat(*ei, nullptr, input.num_nodes());
@@ -849,7 +865,8 @@ tptr<float> GCNConv::forward(Data &&input)
         auto out = (*get_module("lin"))(input.x());
         if (!hot_path_only) {
             auto *bn = dynamic_cast<nn::BatchNorm *>(get_module("bnorm").get());
-            if (bn && bn->uses_batch_stats() && !std::getenv("GNNCPP_NO_PROLOGUE_FUSION")) {
+            static const bool no_prologue_fusion = std::getenv("GNNCPP_NO_PROLOGUE_FUSION") != nullptr;  // A/B switch of the tests, read once
+            if (bn && bn->uses_batch_stats() && !no_prologue_fusion) {
                 auto op = std::make_unique<BnReluAggregateOp>();
                 op->eps = bn->_eps;
                 auto res = op->forward(_cache_adj, out, _cache_norm, get_parameter("bias"), bn->get_parameter("gammas"),

@@ -185,7 +185,14 @@ def test_bench_contract_single_gpu_and_sharded_rehearsal():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["unit"] == "edges/s" and d["dtype"] == "f32"
     assert d["config"]["workload"] == "tiny" and d["vs_baseline"] is None and d["data"] == "synthetic"
     ro = d["roofline"]
-    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+    # the peak is the gather ceiling measured in the same run (bench_kernels/ceilings.hip), the copy ceiling rides along
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+    assert ro["peak"] == ro["ceilings"]["fabric_gather_GBps"] and 3000.0 < ro["peak"] < 12000.0
+    assert 2500.0 < ro["ceilings"]["hbm_copy_GBps"] < 8000.0 and ro["effective_GBps"] > 0 and ro["avg_launch_ms"] > 0
+    nc = _run_bench(["--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-ceilings", "--no-cpp-api"])
+    assert nc["roofline"]["peak"] == 8000.0 and nc["roofline"]["ceilings"] is None and nc["cpp_api"] is None
+    cp = d["cpp_api"]   # the C++ call-site leg ran as a child process on the same workload
+    assert cp and "error" not in cp and cp["hot_path_ms"] > 0 and cp["full_layer_ms"] > cp["hot_path_ms"] * 0.9, cp
     assert abs(d["value"] - d["config"]["nnz"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
