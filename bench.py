@@ -653,7 +653,7 @@ def cpp_api_bench(n, e, F, seed, both_orders=True, steps=5):
     if not os.path.exists(exe):
         return {"error": "tests/cpp/bench_host_api not built"}
     try:
-        r = subprocess.run([exe, str(n), str(e), str(F), str(steps), "2", "2" if both_orders else "0", str(seed)], capture_output=True,
+        r = subprocess.run([exe, str(n), str(e), str(F), str(steps), "2", "2" if both_orders else "0", str(seed), "1"], capture_output=True,
                            text=True, timeout=900)
         rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     except Exception as ex:  # informational leg: never fail the bench because of it
@@ -665,6 +665,9 @@ def cpp_api_bench(n, e, F, seed, both_orders=True, steps=5):
     for row in rows:
         key = ("scrambled_labels" if row["scrambled_labels"] else "as_generated")
         d = out.setdefault(key, {})
+        if row.get("fuse_bn_stats"):   # OPT-IN variant of the full layer (statistics from the transform's epilogue): reported beside, never as, the default
+            d["full_layer_ms_optin_fuse_bn_stats"] = row["ms_per_step"]
+            continue
         d["hot_path_ms" if row["hot_path_only"] else "full_layer_ms"] = row["ms_per_step"]
         d["first_call_s_hot" if row["hot_path_only"] else "first_call_s_full"] = row["first_call_s"]
     best = out.get("scrambled_labels") or out.get("as_generated")

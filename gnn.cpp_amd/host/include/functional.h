@@ -224,6 +224,15 @@ tptr<T> matmul(const tptr<T> &lhs, const tptr<T> &rhs)
         const int64_t lda = ta ? M : K, ldb = tb ? K : N;  // leading dims of the buffers as stored
         auto out = impl::new_out({ls[0], rs[1]}, req);
         size_t wsb = 0;
+        if (!ta && tb) {  // x . W^T: an opt-in request for the batch statistics of the output's columns rides in the epilogue
+            if (detail::BnStatsRequest *rq = detail::BnStatsRequest::take((size_t)M, (size_t)N)) {
+                detail::gx(gnnx_gemm_bn_stats_workspace(M, N, K, &wsb), "matmul");
+                detail::gx(gnnx_gemm_bn_stats_f32(M, N, K, A, lda, B, ldb, out->device_out(), N, rq->mean, rq->var,
+                                                  wsb ? detail::workspace(wsb) : nullptr, wsb, st), "matmul");
+                rq->done = true;
+                return out;
+            }
+        }
         detail::gx(gnnx_gemm_workspace(ta, tb, M, N, K, &wsb), "matmul");
         detail::gx(gnnx_gemm_f32(ta, tb, M, N, K, 1.0f, A, lda, B, ldb, 0.0f, out->device_out(), N, wsb ? detail::workspace(wsb) : nullptr,
                                  wsb, st), "matmul");

@@ -103,6 +103,11 @@ public:
     // false (default): the reference's full layer, transform -> BatchNorm -> ReLU -> aggregation -> bias.
     // true: only the hot path of BASELINE.json (transform -> aggregation -> bias).
     bool hot_path_only = false;
+    // OPT-IN, false by default (the default is the reference's exact two-pass statistics, nn.cpp:303,312): the BatchNorm batch
+    // statistics of the full layer come out of the transform's own epilogue (gnnx_gemm_bn_stats_f32: H is never re-read for
+    // them) -- a single-pass variance finished in double, within rounding of the two-pass one but not bit-equal to it, so the
+    // layer output moves at the 1e-6 level.  Shapes the fused kernel does not cover fall back to the exact pair of calls.
+    bool fuse_bn_stats = false;
     size_t _in_channels, _out_channels;
     float _dropout;
 

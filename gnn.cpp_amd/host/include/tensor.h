@@ -71,6 +71,33 @@ struct TailReservation {
     }
 };
 
+// OPT-IN (graph::GCNConv::fuse_bn_stats): the next product X[M,K] . W[N,K]^T with M x N outputs is asked to leave the BatchNorm
+// batch statistics of its columns in mean / var (gnnx_gemm_bn_stats_f32: one pass, single-pass variance finished in double --
+// within rounding of, not bit-equal to, the exact two-pass statistics that stay the default).  Same per-thread one-shot pattern as
+// TailReservation; `done` tells the requester whether a product took it.
+struct BnStatsRequest {
+    size_t rows, cols;
+    float *mean, *var;   // device [cols]
+    bool done = false;
+    static BnStatsRequest *&pending()
+    {
+        static thread_local BnStatsRequest *p = nullptr;
+        return p;
+    }
+    BnStatsRequest(size_t rows_, size_t cols_, float *mean_, float *var_) : rows(rows_), cols(cols_), mean(mean_), var(var_) { pending() = this; }
+    ~BnStatsRequest()
+    {
+        if (pending() == this) pending() = nullptr;
+    }
+    static BnStatsRequest *take(size_t rows, size_t cols)
+    {
+        BnStatsRequest *p = pending();
+        if (!p || p->rows != rows || p->cols != cols) return nullptr;
+        pending() = nullptr;
+        return p;
+    }
+};
+
 template <class T>
 struct Store {
     size_t n = 0;

@@ -742,6 +742,7 @@ public:
     tptr<float> norm, mean, var;
     float eps = 1e-5f;
     bool has_beta = false;
+    bool have_stats = false;   // mean / var were delivered by the transform's epilogue (GCNConv::fuse_bn_stats)
     BnReluAggregateOp() { name = "GCNBnReluAggregate"; }
     tptr<float> forward(const tptr<float> &adj, const tptr<float> &h, const tptr<float> &norm_, const tptr<float> &bias,
                         const tptr<float> &gamma, const tptr<float> &beta)
@@ -753,12 +754,14 @@ public:
         const int32_t f = (int32_t)shp[1];
         void *st = cyg::detail::current_stream();
         csr->ensure_plans(f);
-        mean = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
-        var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
-        size_t wsb = 0;
-        cyg::detail::gx(gnnx_bn_workspace(n, f, &wsb), "BatchNorm");
-        cyg::detail::gx(gnnx_bn_stats_f32(h->device_data(), f, n, f, mean->device_out(), var->device_out(), cyg::detail::workspace(wsb),
-                                          wsb, st), "BatchNorm");
+        if (!have_stats) {
+            mean = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
+            var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
+            size_t wsb = 0;
+            cyg::detail::gx(gnnx_bn_workspace(n, f, &wsb), "BatchNorm");
+            cyg::detail::gx(gnnx_bn_stats_f32(h->device_data(), f, n, f, mean->device_out(), var->device_out(), cyg::detail::workspace(wsb),
+                                              wsb, st), "BatchNorm");
+        }
         const bool req = h->requires_grad() || bias->requires_grad() || gamma->requires_grad() || (beta && beta->requires_grad());
         auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, req);
         gnnx_spmm_fusion fu{};
@@ -862,13 +865,28 @@ tptr<float> GCNConv::forward(Data &&input)
             _cache_edges = ei->numel();
             _cache_nodes = input.num_nodes();
         }
-        auto out = (*get_module("lin"))(input.x());
+        tptr<float> out, st_mean, st_var;
+        bool have_stats = false;
+        if (fuse_bn_stats && !hot_path_only) {   // opt-in: the statistics ride in the transform's epilogue
+            st_mean = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, _out_channels}, false);
+            st_var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, _out_channels}, false);
+            cyg::detail::BnStatsRequest rq(input.x()->shape()[0], _out_channels, st_mean->device_out(), st_var->device_out());
+            out = (*get_module("lin"))(input.x());
+            have_stats = rq.done;
+        } else {
+            out = (*get_module("lin"))(input.x());
+        }
         if (!hot_path_only) {
             auto *bn = dynamic_cast<nn::BatchNorm *>(get_module("bnorm").get());
             static const bool no_prologue_fusion = std::getenv("GNNCPP_NO_PROLOGUE_FUSION") != nullptr;  // A/B switch of the tests, read once
             if (bn && bn->uses_batch_stats() && !no_prologue_fusion) {
                 auto op = std::make_unique<BnReluAggregateOp>();
                 op->eps = bn->_eps;
+                if (have_stats) {
+                    op->mean = st_mean;
+                    op->var = st_var;
+                    op->have_stats = true;
+                }
                 auto res = op->forward(_cache_adj, out, _cache_norm, get_parameter("bias"), bn->get_parameter("gammas"),
                                        bn->_affine ? bn->get_parameter("betas") : nullptr);
                 if (res->requires_grad()) res->grad_fn = std::move(op);

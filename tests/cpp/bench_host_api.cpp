@@ -1,7 +1,7 @@
 // API-level benchmark: the GCN layer through the C++ mirror of the reference API (graph::GCNConv on graph::Data),
 // forward + backward, to show what a user of the reference's call sites gets on an MI355X.
 //   bench_host_api [n_nodes=1000000] [n_edges=10000000] [features=128] [steps=5] [hot_path_only=1|0|2=both] [scramble_labels=0|1|2=both]
-//                  [rmat_seed=1]          one JSON line per configuration (bench.py starts this as a child and adds them to its line)
+//                  [rmat_seed=1] [also_fuse_bn_stats=0]   one JSON line per configuration (bench.py starts this as a child and adds them to its line)
 // scramble_labels: the data set's vertex ids are multiplied by 2654435761 mod n (an isomorphic graph) before the API sees them --
 // what a user would do once at load time: R-MAT's hubs are the ids with few one-bits, and 1-KiB feature rows at such ids pile onto
 // a few memory channels; the API itself keeps the caller's vertex order.
@@ -56,12 +56,13 @@ static double gen_edges(long n, long e, bool scramble, uint64_t seed, vector<int
 
 // One configuration: one layer over the given edge list; first call + timed steps; prints one JSON line.
 static void run_config(long n, long e, size_t F, int steps, bool hot, bool scramble, uint64_t seed, double t_gen, const vector<int> &src,
-                       const vector<int> &dst, tptr<float> x, tptr<float> g)
+                       const vector<int> &dst, tptr<float> x, tptr<float> g, bool fuse_bn_stats = false)
 {
     auto ei = graph::vec_to_edge_list(src, dst);
     graph::Data data(x, ei.get());
     graph::GCNConv layer(F, F);
     layer.hot_path_only = hot;
+    layer.fuse_bn_stats = fuse_bn_stats;   // opt-in: BatchNorm statistics from the transform's epilogue (not the exact two-pass ones)
 
     double t0 = now_s();
     auto out = layer(data);  // first call: uploads, CSR build, norm, plans
@@ -86,9 +87,9 @@ static void run_config(long n, long e, size_t F, int steps, bool hot, bool scram
     gnnx_device_sync();
     double ms = (now_s() - t0) / steps * 1e3;
     printf("{\"bench\": \"host_api GCNConv fwd+bwd\", \"n_nodes\": %ld, \"n_edges\": %ld, \"features\": %zu, \"hot_path_only\": %d, "
-           "\"scrambled_labels\": %d, \"rmat_seed\": %llu, \"ms_per_step\": %.3f, \"first_call_s\": %.3f, \"edge_gen_s\": %.3f, "
+           "\"scrambled_labels\": %d, \"fuse_bn_stats\": %d, \"rmat_seed\": %llu, \"ms_per_step\": %.3f, \"first_call_s\": %.3f, \"edge_gen_s\": %.3f, "
            "\"out_checksum\": %.6e}\n",
-           n, e, F, (int)hot, (int)scramble, (unsigned long long)seed, ms, t_first, t_gen, (double)(*out->data())[12345 % (n * F)]);
+           n, e, F, (int)hot, (int)scramble, (int)fuse_bn_stats, (unsigned long long)seed, ms, t_first, t_gen, (double)(*out->data())[12345 % (n * F)]);
     fflush(stdout);
 }
 
@@ -100,6 +101,7 @@ int main(int argc, char **argv)
     const int hot = argc > 5 ? atoi(argv[5]) : 1;            // 1 hot path, 0 full BatchNorm + ReLU layer, 2 both
     const int scramble = argc > 6 ? atoi(argv[6]) : 0;       // 0 as generated, 1 scrambled labels, 2 both
     const uint64_t seed = argc > 7 ? (uint64_t)atoll(argv[7]) : 1;
+    const int optin = argc > 8 ? atoi(argv[8]) : 0;          // 1: also time the full layer with GCNConv::fuse_bn_stats (opt-in)
     // features and upstream gradient: drawn once, shared by every configuration (their values do not depend on the vertex order; the
     // first configuration's first_call_s includes their upload, the later ones find them resident)
     manual_seed(7);
@@ -112,6 +114,7 @@ int main(int argc, char **argv)
         for (int h = 1; h >= 0; h--) {
             if (hot != 2 && h != hot) continue;
             run_config(n, e, F, steps, h != 0, sc != 0, seed, t_gen, src, dst, x, g);
+            if (h == 0 && optin) run_config(n, e, F, steps, false, sc != 0, seed, t_gen, src, dst, x, g, true);
         }
     }
     return 0;

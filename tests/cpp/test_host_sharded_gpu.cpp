@@ -83,12 +83,13 @@ struct Result {
     valarray<float> out, dx, dw, dbias, dgamma, dbeta;
 };
 
-static Result run_unsharded(const Problem &p, bool hot_path_only)
+static Result run_unsharded(const Problem &p, bool hot_path_only, bool fuse_bn_stats = false)
 {
     auto ei = graph::vec_to_edge_list(p.src, p.dst);
     auto x = make_shared<tensor<float>>(vector<size_t>{p.n, p.fin}, new valarray<float>(p.X), true);
     graph::GCNConv layer(p.fin, p.fout);
     layer.hot_path_only = hot_path_only;
+    layer.fuse_bn_stats = fuse_bn_stats;
     set_params(layer, p);
     graph::Data data(x, ei.get());
     auto out = layer(data);
@@ -436,10 +437,33 @@ static void test_local_comm_destroy_right_after_a_collective()
     CHECK(bad == 0);
 }
 
+// GCNConv::fuse_bn_stats (opt-in): batch statistics from the transform's epilogue instead of the exact two-pass reduction -- the
+// full layer's output and gradients stay inside 1e-5 of the default path's (they are not bit-equal: single-pass variance).
+static void test_opt_in_bn_stats_from_the_transform_epilogue()
+{
+    const Problem p = make_problem(6000, 60000, 64, 64);   // a shape the LDS-DMA product covers (M >= 2048, K % 64 == 0)
+    const Result a = run_unsharded(p, false, false), b = run_unsharded(p, false, true);
+    auto close = [](const valarray<float> &x, const valarray<float> &y, float tol) {
+        if (x.size() != y.size()) return false;
+        float scale = 1.f, worst = 0.f;
+        for (size_t i = 0; i < x.size(); i++) scale = fmaxf(scale, fabsf(y[i]));
+        for (size_t i = 0; i < x.size(); i++) worst = fmaxf(worst, fabsf(x[i] - y[i]));
+        return worst <= tol * scale;
+    };
+    CHECK(close(b.out, a.out, 1e-5f));
+    CHECK(close(b.dx, a.dx, 1e-5f));
+    CHECK(close(b.dw, a.dw, 1e-5f));
+    CHECK(close(b.dgamma, a.dgamma, 1e-5f) && close(b.dbeta, a.dbeta, 1e-5f));
+    bool any_diff = false;   // and the switch did something: at least the last bits of the output move
+    for (size_t i = 0; i < a.out.size() && !any_diff; i++) any_diff = a.out[i] != b.out[i];
+    CHECK(any_diff);
+}
+
 int main()
 {
     try {
         test_local_comm_destroy_right_after_a_collective();
+        test_opt_in_bn_stats_from_the_transform_epilogue();
         for (int world : {2, 3}) test_two_layer_training_step_sharded(world);
         test_graph_cache_is_keyed_on_content();
         const Problem p = make_problem(20000, 240000, 48, 32);
