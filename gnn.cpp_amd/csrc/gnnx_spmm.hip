@@ -73,6 +73,16 @@ struct SpmmArgs {
     int32_t x_bf16;          // X holds bf16 (gnnx_spmm_csr_bf16_f32)
     const float *pro_mean, *pro_var, *pro_gamma, *pro_beta;
     float pro_eps;
+    // gnnx_spmm_csr_bn_sums_f32 (the backward aggregation of a fused BatchNorm + ReLU layer): besides dY = A^T . (vals (.) G), the
+    // column sums dbeta = sum_i g_i and dgamma = sum_i g_i xhat_i of BatchNorm's backward (g = dY where relu(BN(h)) > 0) are
+    // accumulated by the wavefront that stores the rows of dY: bn_h = the layer's pre-BatchNorm activations H, statistics and
+    // affine parameters in the pro_* fields above, one partial row [2][F] per streaming wavefront / hub row in bn_partial.
+    const float *bn_h;
+    int64_t bn_ldh;
+    float *bn_partial;
+    int32_t bn_relu;
+    int32_t blocks_per_wave;   // row blocks one streaming wavefront walks (1 unless bn sums: fewer, longer partial rows)
+    int32_t n_stream_waves;    // partial rows [0, n_stream_waves) belong to the streaming kernel, the hub rows follow
 };
 
 template <int VEC> struct Vec;
@@ -315,6 +325,58 @@ __global__ __launch_bounds__(256) void spmm_kernel(SpmmArgs a)
 // stream independent blocks under the EXEC mask.
 template <int G> struct StreamCfg { static constexpr int R = G / 2; };
 
+// BatchNorm-backward column sums over rows [row_lo, row_hi) whose dY this wavefront has just stored (VEC 4: a lane owns features
+// f0 .. f0+3).  Same per-element arithmetic as bn_bwd_vec_kernel<0> (gnnx_norm.hip): the ReLU mask is recomputed from h with the
+// forward's separately rounded sub / div / mul / add, xhat = (h - mean) * rstd.  The rows of dY come back from L2 (they were written
+// a moment ago; the stores are waited for first), the rows of H from HBM -- this replaces the separate sums pass over dY and H.
+__device__ __forceinline__ void bn_sums_rows(const SpmmArgs &a, int32_t row_lo, int32_t row_hi, int32_t f0, float4 &s_beta, float4 &s_gamma)
+{
+    const float4 mean4 = *reinterpret_cast<const float4 *>(a.pro_mean + f0);
+    const float4 var4 = *reinterpret_cast<const float4 *>(a.pro_var + f0);
+    float4 gm4 = make_float4(1.f, 1.f, 1.f, 1.f), bt4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.pro_gamma) gm4 = *reinterpret_cast<const float4 *>(a.pro_gamma + f0);
+    if (a.pro_beta) bt4 = *reinterpret_cast<const float4 *>(a.pro_beta + f0);
+    const float mean[4] = {mean4.x, mean4.y, mean4.z, mean4.w}, var[4] = {var4.x, var4.y, var4.z, var4.w};
+    const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w}, bt[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
+    float sd[4], rstd[4], a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        sd[c] = sqrtf(__fadd_rn(var[c], a.pro_eps));
+        rstd[c] = 1.0f / sqrtf(var[c] + a.pro_eps);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores of dY have reached L2
+    for (int32_t rb = row_lo; rb < row_hi; rb += 4) {
+        float4 d[4], h[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int32_t r = rb + u < row_hi ? rb + u : row_hi - 1;   // no predicated loads: the tail re-reads the last row
+            d[u] = *reinterpret_cast<const float4 *>(a.Y + (int64_t)r * a.ldy + f0);
+            h[u] = *reinterpret_cast<const float4 *>(a.bn_h + (int64_t)r * a.bn_ldh + f0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (rb + u < row_hi) {
+                const float ds[4] = {d[u].x, d[u].y, d[u].z, d[u].w}, hs[4] = {h[u].x, h[u].y, h[u].z, h[u].w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float g = ds[c];
+                    if (a.bn_relu) {
+                        float v = __fdiv_rn(__fsub_rn(hs[c], mean[c]), sd[c]);
+                        if (a.pro_gamma) v = __fmul_rn(v, gm[c]);
+                        if (a.pro_beta) v = __fadd_rn(v, bt[c]);
+                        if (!(v > 0.f)) g = 0.f;
+                    }
+                    const float xhat = (hs[c] - mean[c]) * rstd[c];
+                    a0[c] += g;
+                    a1[c] += g * xhat;
+                }
+            }
+        }
+    }
+    s_beta.x += a0[0]; s_beta.y += a0[1]; s_beta.z += a0[2]; s_beta.w += a0[3];
+    s_gamma.x += a1[0]; s_gamma.y += a1[1]; s_gamma.z += a1[2]; s_gamma.w += a1[3];
+}
+
 template <int G, int VEC, int B, int MODE, class XT>
 struct Stream {
     using V = typename Vec<VEC>::type;
@@ -435,7 +497,7 @@ struct Stream {
     }
 };
 
-template <int G, int VEC, int B, int MODE, int TPB, class XT>
+template <int G, int VEC, int B, int MODE, int TPB, class XT, bool SUMS = false>
 __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a)
 {
     constexpr int GROUPS = TPB / G;
@@ -448,44 +510,60 @@ __global__ __launch_bounds__(TPB) void spmm_stream_kernel(SpmmArgs a)
     const bool active = f0 + VEC <= a.n_feat;
     const XT *xf = reinterpret_cast<const XT *>(a.X) + (active ? f0 : 0);
     const ProConst<VEC> pc = pro_load<VEC, MODE>(a, f0, active);
-
-    const int32_t blk = blockIdx.x * GROUPS + grp;
-    int32_t r0, nr;
-    if (a.block_starts) {  // non-zero-balanced blocks of the plan (at most kPlanBlockRows <= R rows each)
-        if (blk >= a.n_blocks) return;
-        r0 = a.block_starts[blk];
-        nr = a.block_starts[blk + 1] - r0;
-        if constexpr (G == 64) {
-            r0 = __builtin_amdgcn_readfirstlane(r0);
-            nr = __builtin_amdgcn_readfirstlane(nr);
-        }
-    } else {
-        const int64_t r0l = (int64_t)blk * R;
-        if (r0l >= a.n_rows) return;
-        r0 = (int32_t)r0l;
-        nr = a.n_rows - r0 < R ? a.n_rows - r0 : R;
-    }
     const int gbase = (tid & 63) - li;
     typename Vec<VEC>::type bias_v;
     zero(bias_v);
     if (a.bias && active) bias_v = ld_vec(reinterpret_cast<const typename Vec<VEC>::type *>(a.bias + f0));
-    const float rs_l = a.rowscale ? a.rowscale[r0 + (li < nr ? li : nr - 1)] : 1.f;
-    Stream<G, VEC, B, MODE, XT> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)], rs_l, bias_v, pc};
 
-    uint64_t hub = 0;  // bit l: local row l is a hub (left to spmm_hub_kernel)
-    if (a.split_threshold > 0) {
-        const int32_t nxt = __shfl(st.rp_l, (tid & 63) + 1, 64);  // lane li+1 (li < nr < G: inside the group)
-        const uint64_t m = __ballot(li < nr && nxt - st.rp_l > a.split_threshold);
-        hub = G == 64 ? m : ((m >> gbase) & ((1ull << (G & 63)) - 1));
+    // a wavefront (a G-lane group) walks blocks_per_wave consecutive blocks: 1, or a few when it also carries the BatchNorm column
+    // sums of the rows it stores (one partial row per wavefront instead of one per block)
+    const int32_t wave_id = blockIdx.x * GROUPS + grp;
+    const int32_t nbw = SUMS ? a.blocks_per_wave : 1;
+    float4 s_beta = make_float4(0.f, 0.f, 0.f, 0.f), s_gamma = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int32_t bi = 0; bi < nbw; bi++) {
+        const int32_t blk = wave_id * nbw + bi;
+        int32_t r0, nr;
+        if (a.block_starts) {  // non-zero-balanced blocks of the plan (at most kPlanBlockRows <= R rows each)
+            if (blk >= a.n_blocks) break;
+            r0 = a.block_starts[blk];
+            nr = a.block_starts[blk + 1] - r0;
+            if constexpr (G == 64) {
+                r0 = __builtin_amdgcn_readfirstlane(r0);
+                nr = __builtin_amdgcn_readfirstlane(nr);
+            }
+        } else {
+            const int64_t r0l = (int64_t)blk * R;
+            if (r0l >= a.n_rows) break;
+            r0 = (int32_t)r0l;
+            nr = a.n_rows - r0 < R ? a.n_rows - r0 : R;
+        }
+        const float rs_l = a.rowscale ? a.rowscale[r0 + (li < nr ? li : nr - 1)] : 1.f;
+        Stream<G, VEC, B, MODE, XT> st{a, xf, li, gbase, f0, active, r0, a.rowptr[r0 + (li < nr ? li : nr)], rs_l, bias_v, pc};
+
+        uint64_t hub = 0;  // bit l: local row l is a hub (left to spmm_hub_kernel)
+        if (a.split_threshold > 0) {
+            const int32_t nxt = __shfl(st.rp_l, (tid & 63) + 1, 64);  // lane li+1 (li < nr < G: inside the group)
+            const uint64_t m = __ballot(li < nr && nxt - st.rp_l > a.split_threshold);
+            hub = G == 64 ? m : ((m >> gbase) & ((1ull << (G & 63)) - 1));
+        }
+        int sa = 0;
+        while (sa < nr) {
+            const uint64_t rest = hub >> sa;
+            if (rest & 1) { sa++; continue; }
+            int run = rest ? __builtin_ctzll(rest) : 64;
+            int sb = sa + run < nr ? sa + run : nr;
+            st.segment(sa, sb);
+            if constexpr (SUMS && VEC == 4)
+                if (active) bn_sums_rows(a, r0 + sa, r0 + sb, f0, s_beta, s_gamma);
+            sa = sb;
+        }
     }
-    int sa = 0;
-    while (sa < nr) {
-        const uint64_t rest = hub >> sa;
-        if (rest & 1) { sa++; continue; }
-        int run = rest ? __builtin_ctzll(rest) : 64;
-        int sb = sa + run < nr ? sa + run : nr;
-        st.segment(sa, sb);
-        sa = sb;
+    if constexpr (SUMS && VEC == 4) {
+        if (active) {
+            float *prow = a.bn_partial + (int64_t)wave_id * 2 * a.n_feat;
+            *reinterpret_cast<float4 *>(prow + f0) = s_beta;
+            *reinterpret_cast<float4 *>(prow + a.n_feat + f0) = s_gamma;
+        }
     }
 }
 
@@ -556,7 +634,7 @@ struct HubCfg {
     static_assert(SUBS * DI * IPS >= LAS * IPS, "an index chunk must be older than the counted wait when it is first read");
 };
 
-template <int VEC, int MODE, int LAS, class XT>
+template <int VEC, int MODE, int LAS, class XT, bool SUMS = false>
 __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t *hub_rows, int32_t n_slabs, int32_t n_groups)
 {
     using K = HubCfg<VEC, MODE, LAS, XT>;
@@ -721,6 +799,21 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
         if (a.beta) v = add_rn(*dst, v);
         if (a.relu_out) v = relu1(v);
         *dst = v;
+        if constexpr (SUMS) {   // this row's term of BatchNorm's backward sums (bn_sums_rows' arithmetic), a partial row of its own
+            const float h = a.bn_h[(int64_t)row * a.bn_ldh + f];
+            const float mean = a.pro_mean[f], var = a.pro_var[f];
+            float g = v;
+            if (a.bn_relu) {
+                float z = __fdiv_rn(__fsub_rn(h, mean), sqrtf(__fadd_rn(var, a.pro_eps)));
+                if (a.pro_gamma) z = __fmul_rn(z, a.pro_gamma[f]);
+                if (a.pro_beta) z = __fadd_rn(z, a.pro_beta[f]);
+                if (!(z > 0.f)) g = 0.f;
+            }
+            const float xhat = (h - mean) * (1.0f / sqrtf(var + a.pro_eps));
+            float *prow = a.bn_partial + ((int64_t)a.n_stream_waves + (int64_t)(blockIdx.x / n_groups)) * 2 * a.n_feat;
+            prow[f] = g;
+            prow[a.n_feat + f] = g * xhat;
+        }
     }
 }
 
@@ -783,12 +876,16 @@ __global__ void plan_block_fill_kernel(const int32_t *flag, const int32_t *pos, 
     starts[pos[r]] = r;
 }
 
-template <int VEC, int MODE, class XT>
+template <int VEC, int MODE, class XT, bool SUMS = false>
 int launch_hub_kernel(hipStream_t st, const SpmmArgs &a)
 {
     // look-ahead in sub-chunks of 16 neighbours: 8 where a sub-chunk is 4 DMA instructions, less where it is 8 or 16 (vmcnt counts
     // at most 63 operations)
-    constexpr int LAS = (VEC == 4 && sizeof(XT) == 4) ? 8 : (VEC == 4 ? 6 : 3);
+    // With a BatchNorm / ReLU prologue every gathered element costs ~15 vector-ALU instructions (an IEEE division among them) instead
+    // of one add: a single wavefront per SIMD then alternates between issuing DMAs and computing, so those modes take a shorter ring
+    // (LAS 3: 17 KB per wavefront) and run two workgroups per CU (6.17 -> 5.86 ms on the hub rows of the bench graph, against 3.44 ms
+    // without a prologue: these modes are bound by the vector ALU -- the division -- in both kernels, not by memory).
+    constexpr int LAS = (VEC == 4 && sizeof(XT) == 4) ? (has_pro(MODE) ? 3 : 8) : (VEC == 4 ? 6 : 3);
     using K = HubCfg<VEC, MODE, LAS, XT>;
     static std::atomic<uint64_t> done{0};
     constexpr size_t lds_wave = sizeof(float) * K::LDS_FLOATS;
@@ -799,13 +896,13 @@ int launch_hub_kernel(hipStream_t st, const SpmmArgs &a)
     int dev = 0;
     GNNX_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {  // dynamic-LDS opt-in, once per kernel and device
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hub_kernel<VEC, MODE, LAS, XT>),
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_wave * max_waves)));
         if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
     }
     const dim3 grid((uint32_t)((int64_t)a.n_hub_rows * n_groups));
     const size_t lds_wg = lds_wave * waves;
-    hipLaunchKernelGGL((spmm_hub_kernel<VEC, MODE, LAS, XT>), grid, dim3(64 * waves), lds_wg, st, a, a.hub_rows, n_slabs, n_groups);
+    hipLaunchKernelGGL((spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS>), grid, dim3(64 * waves), lds_wg, st, a, a.hub_rows, n_slabs, n_groups);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }
@@ -813,6 +910,8 @@ int launch_hub_kernel(hipStream_t st, const SpmmArgs &a)
 template <int VEC>
 int launch_hub(int mode, hipStream_t st, const SpmmArgs &a)
 {
+    if constexpr (VEC == 4)
+        if (a.bn_partial) return launch_hub_kernel<VEC, 2, float, true>(st, a);   // backward aggregation + BatchNorm sums (mode 2, f32)
     if (a.x_bf16) {  // bf16 feature rows: the three plain modes (a prologue goes with f32 rows)
         switch (mode) {
         case 0: return launch_hub_kernel<VEC, 0, bf16_t>(st, a);
@@ -844,6 +943,12 @@ void launch_stream(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a)
         default: GNNX_STREAM(6, bf16_t); break;
         }
         return;
+    }
+    if constexpr (VEC == 4 && G >= 32) {
+        if (a.bn_partial) {   // backward aggregation + BatchNorm sums (mode 2, f32 rows)
+            hipLaunchKernelGGL((spmm_stream_kernel<G, VEC, U, 2, TPB, float, true>), grid, dim3(TPB), 0, st, a);
+            return;
+        }
     }
     switch (mode) {
     case 0: GNNX_STREAM(0, float); break;
@@ -907,7 +1012,9 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
             // blocks of a power-law graph differ a lot in non-zeros, so multi-wave workgroups strand slots.
             static const int tpb_env = [] { const char *v = experiment_env("GNNX_SPMM_TPB"); return v ? atoi(v) : 64; }();
             const int tpb = tpb_env == 256 ? 256 : 64;
-            grid.x = (uint32_t)(a.block_starts ? ceil_div(a.n_blocks, tpb / G) : ceil_div(a.n_rows, (int64_t)(tpb / G) * R));
+            const int64_t n_blk = a.block_starts ? a.n_blocks : ceil_div(a.n_rows, R);
+            const int64_t n_waves = ceil_div(n_blk, a.blocks_per_wave > 0 ? a.blocks_per_wave : 1);
+            grid.x = (uint32_t)ceil_div(n_waves, tpb / G);
             if (tpb == 256) launch_stream<G, VEC, U, 256>(mode, grid, st, a);
             else launch_stream<G, VEC, U, 64>(mode, grid, st, a);
         }
@@ -1013,9 +1120,31 @@ GNNX_API int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_hub_rows
 }
 
 namespace {
+// BatchNorm-backward sums riding in the backward aggregation (gnnx_spmm_csr_bn_sums_f32)
+struct BnSums {
+    const float *h;
+    int64_t ldh;
+    const float *mean, *var, *gamma, *beta;
+    float eps;
+    int relu;
+    float *partial;
+    int32_t blocks_per_wave, n_stream_waves;
+};
+constexpr int kBnSumsBlocksPerWave = 4;
+
+// partial rows the streaming kernel writes for a graph / width (= the G-lane groups it launches); 0: shape not covered
+int64_t bn_sums_stream_waves(int32_t n_rows, int32_t n_feat, const gnnx_spmm_plan *plan)
+{
+    if (n_feat % 4 || n_feat <= 64) return 0;           // needs the VEC 4 streaming kernel (G >= 32)
+    const int G = n_feat / 4 > 32 ? 64 : 32, groups = 64 / G, R = G / 2;
+    const int64_t n_blk = plan && plan->d_block_starts ? plan->n_blocks : ceil_div(n_rows, R);
+    return ceil_div(ceil_div(n_blk, kBnSumsBlocksPerWave), groups) * groups;
+}
+
 int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr, const int32_t *d_colidx, const float *d_vals,
               const float *d_colscale, const float *d_rowscale, const float *d_bias, const float *d_X, int64_t ldx, float beta,
-              float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan, void *stream, bool x_bf16 = false)
+              float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan, void *stream, bool x_bf16 = false,
+              const BnSums *bs = nullptr)
 {
     GNNX_REQUIRE(n_rows >= 0 && n_cols >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
     if (n_rows == 0 || n_feat == 0) return GNNX_OK;
@@ -1041,6 +1170,20 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         a.pro_gamma = fusion->bn_gamma;
         a.pro_beta = fusion->bn_beta;
         a.pro_eps = fusion->bn_eps;
+    }
+    a.blocks_per_wave = 1;
+    if (bs) {
+        a.bn_h = bs->h;
+        a.bn_ldh = bs->ldh;
+        a.bn_partial = bs->partial;
+        a.bn_relu = bs->relu;
+        a.blocks_per_wave = bs->blocks_per_wave;
+        a.n_stream_waves = bs->n_stream_waves;
+        a.pro_mean = bs->mean;
+        a.pro_var = bs->var;
+        a.pro_gamma = bs->gamma;
+        a.pro_beta = bs->beta;
+        a.pro_eps = bs->eps;
     }
     a.x_bf16 = x_bf16;
     a.n_rows = n_rows;
@@ -1103,6 +1246,56 @@ GNNX_API int gnnx_spmm_csr_fused_f32(int32_t n_rows, int32_t n_cols, int32_t n_f
 {
     return spmm_impl(n_rows, n_cols, n_feat, d_rowptr, d_colidx, d_vals, d_colscale, d_rowscale, d_bias, d_X, ldx, beta, d_Y, ldy,
                      fusion, plan, stream);
+}
+
+GNNX_API int gnnx_spmm_csr_bn_sums_workspace(int32_t n_rows, int32_t n_feat, const gnnx_spmm_plan *plan, size_t *bytes)
+{
+    GNNX_REQUIRE(bytes && n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    const int64_t sw = bn_sums_stream_waves(n_rows, n_feat, plan);
+    const int64_t n_partial = sw + (plan ? plan->n_split_rows : 0);
+    size_t cs = 0;
+    int rc = gnnx_colsum_workspace(n_partial > 0 ? n_partial : 1, 2 * n_feat, &cs);
+    if (rc) return rc;
+    *bytes = sizeof(float) * ((size_t)n_partial * 2 * (size_t)n_feat + 2 * (size_t)n_feat) + cs + 256;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_spmm_csr_bn_sums_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr, const int32_t *d_colidx,
+                                       const float *d_vals, const float *d_G, int64_t ldg, float *d_dY, int64_t ldy, const float *d_H,
+                                       int64_t ldh, const float *d_mean, const float *d_var, float eps, const float *d_gamma,
+                                       const float *d_beta, int relu, float *d_dgamma, float *d_dbeta, void *d_workspace,
+                                       size_t workspace_bytes, const gnnx_spmm_plan *plan, void *stream)
+{
+    GNNX_REQUIRE(n_rows > 0 && n_feat > 0, GNNX_ERR_INVALID_ARG, "empty problem");
+    GNNX_REQUIRE(d_vals && d_G && d_dY && d_H && d_mean && d_var && d_dgamma && d_dbeta, GNNX_ERR_INVALID_ARG, "null pointer");
+    GNNX_REQUIRE(ldh >= n_feat, GNNX_ERR_SHAPE, "leading dimension smaller than n_feat");
+    auto aligned16 = [](const void *p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int64_t sw = bn_sums_stream_waves(n_rows, n_feat, plan);
+    const bool ok = sw > 0 && ldg % 4 == 0 && ldy % 4 == 0 && ldh % 4 == 0 && aligned16(d_G) && aligned16(d_dY) && aligned16(d_H) &&
+                    aligned16(d_mean) && aligned16(d_var) && aligned16(d_gamma) && aligned16(d_beta);
+    GNNX_REQUIRE(ok, GNNX_ERR_UNSUPPORTED, "shape not covered by the fused sums (n_feat %% 4 == 0, n_feat > 64, 16-byte aligned rows): use "
+                                           "gnnx_spmm_csr_f32 + gnnx_bn_relu_bwd_sums_f32");
+    size_t need = 0;
+    int rc = gnnx_spmm_csr_bn_sums_workspace(n_rows, n_feat, plan, &need);
+    if (rc) return rc;
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+    const int64_t n_partial = sw + (plan ? plan->n_split_rows : 0);
+    float *partial = static_cast<float *>(d_workspace);
+    float *sums = partial + (size_t)n_partial * 2 * n_feat;
+    char *cs_ws = reinterpret_cast<char *>(sums + 2 * n_feat);
+    cs_ws += (256 - (reinterpret_cast<uintptr_t>(cs_ws) & 255)) & 255;
+    const size_t cs_bytes = workspace_bytes - (size_t)(cs_ws - static_cast<char *>(d_workspace));
+    BnSums bs{d_H, ldh, d_mean, d_var, d_gamma, d_beta, eps, relu, partial, kBnSumsBlocksPerWave, (int32_t)sw};
+    rc = spmm_impl(n_rows, n_cols, n_feat, d_rowptr, d_colidx, d_vals, nullptr, nullptr, nullptr, d_G, ldg, 0.0f, d_dY, ldy, nullptr, plan,
+                   stream, false, &bs);
+    if (rc) return rc;
+    // partial rows -> [2F] in a fixed order (two-stage deterministic tree), then to the caller's two [F] vectors
+    rc = gnnx_colsum_f32(partial, 2 * (int64_t)n_feat, n_partial, 2 * n_feat, 0.0f, sums, cs_ws, cs_bytes, stream);
+    if (rc) return rc;
+    hipStream_t st = as_stream(stream);
+    GNNX_HIP_CHECK(hipMemcpyAsync(d_dbeta, sums, sizeof(float) * (size_t)n_feat, hipMemcpyDeviceToDevice, st));
+    GNNX_HIP_CHECK(hipMemcpyAsync(d_dgamma, sums + n_feat, sizeof(float) * (size_t)n_feat, hipMemcpyDeviceToDevice, st));
+    return GNNX_OK;
 }
 
 GNNX_API int gnnx_spmm_csr_bf16_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,

@@ -799,18 +799,37 @@ public:
                                                  (float *)csr->norm_per_nz_t, 1, st), "aggregate");
         }
         auto dy = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);  // d relu(BN(H))
-        cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
-                                          (const float *)csr->norm_per_nz_t, nullptr, nullptr, nullptr, g->device_data(), f, 0.0f,
-                                          dy->device_out(), f, csr->plan_t, st), "aggregate");
         size_t wsb = 0;
         cyg::detail::gx(gnnx_bn_workspace(n, f, &wsb), "BatchNorm");
         auto dh = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
         auto dgamma = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
         auto dbeta = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, gamma->shape(), false);
-        cyg::detail::gx(nn::bn_backward_fn()(h->device_data(), f, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
-                                             var->device_data(), eps, gamma->device_data(), has_beta ? beta->device_data() : nullptr, 1,
-                                             dh->device_out(), f, dgamma->device_out(), dbeta->device_out(),
-                                             cyg::detail::workspace(wsb), wsb, st), "BatchNorm");
+        const float *beta_d = has_beta ? beta->device_data() : nullptr;
+        // BatchNorm's backward needs dbeta = sum g and dgamma = sum g xhat before it can write dX: the aggregation's own store
+        // epilogue accumulates them (gnnx_spmm_csr_bn_sums_f32), so dY and H are not re-read by a sums pass of their own; widths
+        // the fused form does not cover (and the reference-quirk mode) take the two separate kernels
+        size_t sums_ws = 0;
+        const bool fused_sums = nn::bn_backward_fn() == &gnnx_bn_relu_bwd_f32 &&
+                                gnnx_spmm_csr_bn_sums_workspace(csr->n, f, csr->plan_t, &sums_ws) == GNNX_OK && f % 4 == 0 && f > 64;
+        if (fused_sums) {
+            cyg::detail::gx(gnnx_spmm_csr_bn_sums_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
+                                                      (const float *)csr->norm_per_nz_t, g->device_data(), f, dy->device_out(), f,
+                                                      h->device_data(), f, mean->device_data(), var->device_data(), eps,
+                                                      gamma->device_data(), beta_d, 1, dgamma->device_out(), dbeta->device_out(),
+                                                      cyg::detail::workspace(sums_ws), sums_ws, csr->plan_t, st), "aggregate");
+            cyg::detail::gx(gnnx_bn_relu_bwd_apply_f32(h->device_data(), f, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
+                                                       var->device_data(), eps, gamma->device_data(), beta_d, 1, dgamma->device_data(),
+                                                       dbeta->device_data(), n, dh->device_out(), f, cyg::detail::workspace(wsb), wsb, st),
+                            "BatchNorm");
+        } else {
+            cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
+                                              (const float *)csr->norm_per_nz_t, nullptr, nullptr, nullptr, g->device_data(), f, 0.0f,
+                                              dy->device_out(), f, csr->plan_t, st), "aggregate");
+            cyg::detail::gx(nn::bn_backward_fn()(h->device_data(), f, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
+                                                 var->device_data(), eps, gamma->device_data(), beta_d, 1, dh->device_out(), f,
+                                                 dgamma->device_out(), dbeta->device_out(), cyg::detail::workspace(wsb), wsb, st),
+                            "BatchNorm");
+        }
         if (h->requires_grad()) h->backward(dh);
         if (gamma->requires_grad()) gamma->backward(dgamma);
         if (has_beta && beta->requires_grad()) beta->backward(dbeta);

@@ -455,6 +455,28 @@ def aggregate_bwd(g, G, out=None, beta=0.0, use_plan=True):
     return spmm(g.rowptr_t, g.colidx_t, G, out=out, vals=g.norm_per_nz_t, beta=beta, plan=g.plan_t if use_plan else None)
 
 
+def aggregate_bwd_bn_sums(g, G, H, mean, var, gamma=None, beta=None, eps=1e-5, relu=True, out=None, use_plan=True):
+    """gnnx_spmm_csr_bn_sums_f32: dY = A^T . (norm (.) G) as aggregate_bwd computes it (same bits) plus BatchNorm's backward column
+    sums dgamma / dbeta over g = dY masked by relu(BN(H)) -- accumulated by the wavefronts that store dY, so the separate sums
+    pass over dY and H disappears.  Returns (dY, dgamma, dbeta); follow with gnnx_bn_relu_bwd_apply_f32."""
+    if getattr(g, "norm_per_nz_t", None) is None:
+        g.norm_per_nz_t = gather_rows(g.norm.reshape(-1, 1), g.colidx_t).reshape(-1)
+    n, F = G.shape
+    if out is None:
+        out = torch.empty((n, F), dtype=torch.float32, device=G.device)
+    dgamma = torch.empty(F, dtype=torch.float32, device=G.device)
+    dbeta = torch.empty(F, dtype=torch.float32, device=G.device)
+    plan = g.plan_t if use_plan else None
+    ph = plan.h if plan is not None else None
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_spmm_csr_bn_sums_workspace", n, F, ph, C.byref(wsb))
+    ws = _workspace(wsb.value, G.device, "bn_sums")
+    capi.call("gnnx_spmm_csr_bn_sums_f32", n, n, F, _ptr(g.rowptr_t), _ptr(g.colidx_t), _ptr(g.norm_per_nz_t), _ptr(G), _ld(G), _ptr(out),
+              _ld(out), _ptr(H), _ld(H), _ptr(mean), _ptr(var), float(eps), _ptr(gamma), _ptr(beta), int(relu), _ptr(dgamma), _ptr(dbeta),
+              _ptr(ws), wsb.value, ph, _stream())
+    return out, dgamma, dbeta
+
+
 def aggregate_fwd_sym(g, H, bias=None, out=None, self_term=False, use_plan=True):
     """Mode SYM, the textbook layer the north_star writes: out = D^-1/2 A D^-1/2 . H (+ bias), s = (1 + deg)^-1/2 as in the
     reference's degree block (graph.cpp:178,183); with self_term the D^-1/2 (A + I) D^-1/2 form.  Unlike Mode REF (the

@@ -191,6 +191,21 @@ int gnnx_spmm_csr_fused_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, cons
                             float *d_Y, int64_t ldy, const gnnx_spmm_fusion *fusion, const gnnx_spmm_plan *plan,
                             void *stream);
 
+/* Backward aggregation of a layer whose forward fused BatchNorm + ReLU into the gather (gnnx_spmm_csr_fused_f32): dY = A^T . (vals (.) G)
+ * on CSR(A^T) as gnnx_spmm_csr_f32 computes it (same bits), PLUS the two column sums BatchNorm's backward needs before it can
+ * produce dX -- dbeta = sum_i g_i and dgamma = sum_i g_i xhat_i with g = dY where relu(BN(h)) > 0 (the mask recomputed from H
+ * with the forward's arithmetic; relu = 0: g = dY), xhat = (h - mean) * (var + eps)^-1/2 -- accumulated by the wavefronts that
+ * store the rows of dY (the row of dY comes back from L2, the row of H is the one extra read) and reduced in a fixed order: the
+ * separate sums pass over dY and H (gnnx_bn_relu_bwd_sums_f32: 8 F bytes per node) disappears.  Follow with
+ * gnnx_bn_relu_bwd_apply_f32.  Same summands as gnnx_bn_relu_bwd_sums_f32 in another (fixed) order: rounding-level agreement.
+ * Shapes: n_feat % 4 == 0, n_feat > 64, 16-byte aligned rows; GNNX_ERR_UNSUPPORTED otherwise (use the two separate calls). */
+int gnnx_spmm_csr_bn_sums_workspace(int32_t n_rows, int32_t n_feat, const gnnx_spmm_plan *plan, size_t *bytes);
+int gnnx_spmm_csr_bn_sums_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr, const int32_t *d_colidx,
+                              const float *d_vals, const float *d_G, int64_t ldg, float *d_dY, int64_t ldy, const float *d_H, int64_t ldh,
+                              const float *d_mean, const float *d_var, float eps, const float *d_gamma, const float *d_beta, int relu,
+                              float *d_dgamma, float *d_dbeta, void *d_workspace, size_t workspace_bytes, const gnnx_spmm_plan *plan,
+                              void *stream);
+
 /* Opt-in bf16 FEATURE STORAGE: the same SpMM gathering rows of X stored as bf16 -- 2 bytes per
  * feature instead of 4, i.e. about half the algorithmic bytes of the aggregation -- widened exactly to f32 in registers and
  * accumulated in f32 in the same order.  NOT the parity path: rounding X to bf16 (gnnx_f32_to_bf16, round to nearest even)

@@ -261,6 +261,44 @@ def test_plan_hub_rows_keep_the_reference_order(env, n, e, F, chunk):
     assert torch.equal(ops.aggregate_fwd(g, dev(env, H), dev(env, bias)), out)
 
 
+@pytest.mark.parametrize("n,e,F,chunk,relu,affine", [(30000, 600000, 256, 256, True, True), (30000, 600000, 128, 64, True, True),
+                                                     (20000, 400000, 100, 64, True, False), (20000, 300000, 256, 0, False, True)])
+def test_backward_aggregation_with_batchnorm_sums(env, n, e, F, chunk, relu, affine):
+    """gnnx_spmm_csr_bn_sums_f32: the backward aggregation of a fused BatchNorm + ReLU layer with BatchNorm's column sums accumulated in
+    the store epilogue (nn.cpp:301-330's backward, operation.h:144-167): dY keeps the bits of the plain backward aggregation; dgamma
+    and dbeta agree with float64 and with the separate sums pass (gnnx_bn_relu_bwd_f32) to rounding; run-to-run identical; narrow
+    widths are refused loudly."""
+    ops, torch, capi = env["ops"], env["torch"], env["capi"]
+    src, dst, rp, ci, g = make_graph(env, n, e, seed=170 + F)
+    if chunk:
+        g.make_plans(chunk, F)
+    H = dev(env, synth.uniform_pm1(141, (n, F)))
+    G = dev(env, synth.uniform_pm1(142, (n, F)))
+    gamma = dev(env, 1.0 + 0.3 * synth.uniform_pm1(143, (F,))) if affine else None
+    beta = dev(env, 0.2 * synth.uniform_pm1(144, (F,))) if affine else None
+    mean, var = ops.bn_stats(H)
+    dY0 = ops.aggregate_bwd(g, G)
+    dY, dgamma, dbeta = ops.aggregate_bwd_bn_sums(g, G, H, mean, var, gamma, beta, 1e-5, relu)
+    assert torch.equal(dY, dY0), "dY must keep the plain backward aggregation's bits"
+    # float64 sums with the device's own mask decision (sign of the forward value, recomputed in float32 by the separate kernel)
+    Y = ops.bn_relu_fwd(H, mean, var, gamma, beta, 1e-5, relu=True)
+    mask = (Y > 0) if relu else torch.ones_like(Y, dtype=torch.bool)
+    g64 = torch.where(mask, dY0.double(), torch.zeros_like(dY0, dtype=torch.float64))
+    xhat = (H.double() - mean.double().reshape(1, -1)) / torch.sqrt(var.double().reshape(1, -1) + 1e-5)
+    ref_b, ref_g = g64.sum(0), (g64 * xhat).sum(0)
+    ab_b, ab_g = g64.abs().sum(0), (g64 * xhat).abs().sum(0)
+    assert float(((dbeta.double() - ref_b).abs() / torch.clamp(ab_b, min=1.0)).max()) <= 1e-5
+    assert float(((dgamma.double() - ref_g).abs() / torch.clamp(ab_g, min=1.0)).max()) <= 1e-5
+    _, dg_sep, db_sep = ops.bn_relu_bwd(H, None, dY0, mean, var, gamma, 1e-5, relu, beta=beta)
+    assert float(((dbeta - db_sep).abs() / torch.clamp(ab_b.float(), min=1.0)).max()) <= 1e-5
+    assert float(((dgamma - dg_sep).abs() / torch.clamp(ab_g.float(), min=1.0)).max()) <= 1e-5
+    dY2, dgamma2, dbeta2 = ops.aggregate_bwd_bn_sums(g, G, H, mean, var, gamma, beta, 1e-5, relu)
+    assert torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta) and torch.equal(dY2, dY), "deterministic"
+    with pytest.raises(capi.GnnxError):
+        ops.aggregate_bwd_bn_sums(g, G[:, :32].contiguous(), H[:, :32].contiguous(), mean[..., :32].contiguous(),
+                                  var[..., :32].contiguous(), None, None, 1e-5, relu)
+
+
 @pytest.mark.parametrize("F", [16, 7, 33])
 def test_spmm_split_rows_plan_narrow_features(env, F):
     """The plan (hub kernel + the one-row-per-group kernel used at F <= 64), vector and scalar lanes: the oracle's bits."""
