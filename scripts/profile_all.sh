@@ -33,5 +33,11 @@ TALL_ONLY=1 FS=256 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY S
 TALL_ONLY=1 FS=256 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_gemm_stats" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm_stats.log" 2>&1
 (cd "$ROOT" && python3 scripts/summarize_profile.py --sq "${TAG}_gemm_sq_counters" "$OUT/prof_${TAG}_gemm_sq" "$OUT/prof_${TAG}_gemm_stats")
 echo "profiled gemm sq"
+# the same for the 128-wide products (10 M x 128 x 128: the 256 x 128 / 128 x 128 LDS-DMA geometry and its k-major operand image)
+TALL_ONLY=1 FS=128 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT -f csv \
+  -d "$OUT/prof_${TAG}_gemm128_sq" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm128_sq.log" 2>&1
+TALL_ONLY=1 FS=128 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_gemm128_stats" -- python3 "$ROOT/scripts/exp_gemm.py" > "$OUT/prof_${TAG}_gemm128_stats.log" 2>&1
+(cd "$ROOT" && python3 scripts/summarize_profile.py --sq "${TAG}_gemm128_sq_counters" "$OUT/prof_${TAG}_gemm128_sq" "$OUT/prof_${TAG}_gemm128_stats")
+echo "profiled gemm128 sq"
 # nothing but gpurun_out/ travels back from the GPU box: leave a copy of the summaries there (the builder moves them into profiles/)
 mkdir -p "$OUT/profiles_${TAG}" && cp "$ROOT"/profiles/${TAG}_* "$OUT/profiles_${TAG}/"
