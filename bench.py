@@ -672,7 +672,9 @@ def cpp_api_bench(n, e, F, seed, both_orders=True, steps=5):
         d["first_call_s_hot" if row["hot_path_only"] else "first_call_s_full"] = row["first_call_s"]
     best = out.get("scrambled_labels") or out.get("as_generated")
     out["hot_path_ms"], out["full_layer_ms"] = best.get("hot_path_ms"), best.get("full_layer_ms")
-    out["first_call_s"] = best.get("first_call_s_hot")
+    # the process's very first layer(data) + backward: uploads of X / G / the edge list from host valarrays, both CSRs, norm, plans
+    # (later configurations find the features resident)
+    out["first_call_s"] = rows[0]["first_call_s"]
     return out
 
 
