@@ -246,10 +246,15 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
-        if args.dist_backend == "gloo":
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        try:
+            if args.dist_backend == "gloo":
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+                dist.barrier()   # the first collective creates the RCCL communicator: fail here, loudly, not inside the timed loop
+        except Exception as ex:  # no retry, no re-exec: report the transport's own message and exit non-zero
+            print(f"bench.py: rank {rank}/{world}: {args.dist_backend} process group could not be initialised: {ex}", file=sys.stderr, flush=True)
+            sys.exit(2)
 
     pkg = load_package()
     if dist is not None and args.dist_backend == "gloo":   # rehearsal transport (shard.HostStagedDist): never the measured path

@@ -23,3 +23,23 @@ def test_bench_gpus_n_started_as_plain_python_spawns_its_ranks():
     assert "must be launched with" not in out
     assert out.count("bench.py needs a HIP device") >= 1, out[-2000:]
     assert "nproc-per-node" in out or "local_rank" in out or "torch.distributed" in out, out[-2000:]
+
+
+def test_roofline_traffic_comes_from_the_newest_profile_of_the_same_graph():
+    """bench.py's `traffic` = bytes leaving L2 per aggregation, summed over the aggregation's two kernels (hub + streaming) of the newest
+    committed rocprofv3 PMC summary of the workload, with the file's provenance (commit of the profiled build, nnz, mtime) beside it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod_cpu", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pats = [r"^spmm_hub_kernel<\d+, 0, ", r"^spmm_(stream_)?kernel<\d+, \d+, \d+, 0, "]
+    for wl, lo, hi in (("rmat10m_100m_f256", 100e9, 112.2e9), ("rmat1m_10m_f128", 3e9, 5.7e9), ("products_2p4m_62m_f100", 26e9, 36e9)):
+        tr = bench.profiled_traffic(wl, pats)
+        assert tr is not None, wl
+        total, src = tr
+        assert lo < total < hi, (wl, total)
+        assert src["file"].startswith("profiles/r03_") and len(src["kernels"]) == 2 and src["profiled_nnz"] and src["git_head_of_profiled_build"]
+        assert any("spmm_hub_kernel" in k for k in src["kernels"]) and any("spmm_stream_kernel" in k for k in src["kernels"])
+    assert bench.profiled_traffic("no_such_workload", pats) is None
+    # the algorithmic byte count of SURVEY.md 8(d) for the headline graph
+    assert bench.spmm_bytes(10_000_000, 10_000_000, 99_100_605, 256, bias=True) == 112_195_422_968
