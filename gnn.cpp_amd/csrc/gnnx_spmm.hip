@@ -38,6 +38,7 @@ struct gnnx_spmm_plan {
     int32_t chunk = 0;
     int32_t n_split_rows = 0;   // rows with degree > chunk (the hub rows)
     int64_t n_hub_nnz = 0;      // their non-zeros
+    int32_t max_hub_degree = 0;
     int32_t *d_hub_rows = nullptr;  // [n_split_rows] the hub rows, longest first: work list of spmm_hub_kernel
     unsigned long long *d_counters = nullptr;
     // non-zero-balanced row blocks for the streaming kernel: block k owns rows [d_block_starts[k], [k+1])
@@ -65,6 +66,7 @@ struct SpmmArgs {
     int32_t split_threshold; // rows with degree > this are left to the hub kernel (0 = none)
     const int32_t *hub_rows; // the plan's hub rows, longest first
     int32_t n_hub_rows;
+    int32_t hub_beside;      // run the hub kernel on the side stream, beside the row kernel (its time is one row's add chain)
     // row blocks of the streaming kernel (plan): nullptr => fixed blocks of StreamCfg<G>::R rows
     const int32_t *block_starts;
     int32_t n_blocks;
@@ -609,11 +611,14 @@ template <int N> __device__ __forceinline__ void hub_wait_vm() { asm volatile("s
 // DMA shapes (bytes per lane / lanes per 64-feature slice / neighbours per wave-instruction):
 //   f32 rows, 16-byte aligned (VEC 4): 16 / 16 / 4      f32 rows, any alignment (VEC 1): 4 / 64 / 1
 //   bf16 rows, 8-byte aligned (VEC 4):  4 / 32 / 2      bf16 rows, any alignment (VEC 1): 2 / 64 / 1
-template <int VEC, int MODE, int LAS, class XT>
+// (SLAB: features per work item.  Narrower slabs -- 16 features, 64-byte slices, 384 neighbours in flight -- were tried for the
+// longest rows and are slower: a row's time is its chain of dependent adds and the per-neighbour issue work, ~12 ns per neighbour
+// whatever is in flight, so more wavefronts per row only repeat that work.)
+template <int VEC, int MODE, int LAS, class XT, int SLAB = kHubSlab>
 struct HubCfg {
     static constexpr int EB = (int)sizeof(XT);          // bytes per stored feature
     static constexpr int DS = VEC == 4 ? (EB == 4 ? 16 : 4) : EB;  // bytes per lane of one DMA instruction
-    static constexpr int SB = kHubSlab * EB;            // bytes of a neighbour's slice (= its stride in the ring)
+    static constexpr int SB = SLAB * EB;                // bytes of a neighbour's slice (= its stride in the ring)
     static constexpr int EPI = 64 * DS / SB;            // neighbours per DMA wave-instruction
     static constexpr int LPE = 64 / EPI;                // lanes per neighbour
     static constexpr int FPL = DS / EB;                 // features per lane of a DMA instruction
@@ -634,10 +639,10 @@ struct HubCfg {
     static_assert(SUBS * DI * IPS >= LAS * IPS, "an index chunk must be older than the counted wait when it is first read");
 };
 
-template <int VEC, int MODE, int LAS, class XT, bool SUMS = false>
+template <int VEC, int MODE, int LAS, class XT, bool SUMS = false, int SLAB = kHubSlab>
 __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t *hub_rows, int32_t n_slabs, int32_t n_groups)
 {
-    using K = HubCfg<VEC, MODE, LAS, XT>;
+    using K = HubCfg<VEC, MODE, LAS, XT, SLAB>;
     constexpr int EPI = K::EPI, IPS = K::IPS, NS = K::NS, SUBS = K::SUBS, DI = K::DI, NC = K::NC, NI = K::NI;
     extern __shared__ __attribute__((aligned(16))) float lds_all[];
     // a workgroup = the slabs of one row (up to 4 wavefronts, each with a ring of its own): nothing is shared and there is no
@@ -648,22 +653,23 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
     const int32_t row = __builtin_amdgcn_readfirstlane(hub_rows[blockIdx.x / n_groups]);
     const int32_t slab = (int32_t)(blockIdx.x % n_groups) * (int32_t)(blockDim.x >> 6) + wv;
     if (slab >= n_slabs) return;
-    const int32_t f_slab = slab * kHubSlab;
+    const int32_t f_slab = slab * SLAB;
     const int32_t lo = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
     const int32_t hi = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
     const int32_t total = hi - lo;
     const int32_t nsub = (total + kHubSub - 1) / kHubSub;
-    const int32_t f = f_slab + lane;
-    const bool active = f < a.n_feat;
+    const int32_t f = f_slab + (lane & (SLAB - 1));     // a narrow slab leaves lanes >= SLAB idle in the adds (they mirror lane & 15)
+    const bool active = f < a.n_feat && lane < SLAB;
     // DMA source of this lane: neighbour sub_e of the instruction, FPL features at feature foff.  Lanes past the row's width
     // re-read the slab's first piece (never a byte outside the row); their LDS words are never stored.
     const int sub_e = lane / K::LPE;
     int32_t foff = f_slab + (lane % K::LPE) * K::FPL;
     if (foff + K::FPL > a.n_feat) foff = f_slab;
-    const XT *xsrc = reinterpret_cast<const XT *>(a.X) + foff;
+    const char *xsrc = reinterpret_cast<const char *>(reinterpret_cast<const XT *>(a.X) + foff);
+    const uint32_t row_bytes = (uint32_t)(a.ldx * (int64_t)sizeof(XT));   // a neighbour row's address = one 32 x 32 -> 64-bit mad
     const ProConst<1> pc = pro_load<1, MODE>(a, active ? f : 0, active);
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t *)lds;
-    const uint32_t ring_lane = lds0 + (uint32_t)lane * (uint32_t)K::EB;            // this lane's feature of slice 0, slot 0
+    const uint32_t ring_lane = lds0 + (uint32_t)(lane & (SLAB - 1)) * (uint32_t)K::EB;   // this lane's feature of slice 0, slot 0
     const uint32_t col_lane = lds0 + (uint32_t)(K::IR + sub_e) * 4u;               // index slot 0, this lane's neighbour of instruction 0
     const uint32_t val_lane = lds0 + (uint32_t)(K::VR + (lane & 15)) * 4u;         // one value per lane 0..15 (read back by v_readlane)
     const uint32_t sc_lane = lds0 + (uint32_t)(K::SR + (lane & 15)) * 4u;
@@ -680,14 +686,16 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c)::"memory");
         __builtin_amdgcn_global_load_lds(a.colscale + c, (lds_void_t *)(lds + K::SR + islot * kHubChunk), 4, 0, 0);
     };
-    auto issue = [&](int slot, int islot, int k0) {  // sub-chunk = neighbours k0 .. k0+15 of the index chunk in ring slot islot
-        float *dst = lds + slot * K::SUB_FLOATS;
+    // a sub-chunk = neighbours k0 .. k0+15 of the index chunk in ring slot islot: the DMA lanes read their neighbour's column from
+    // the index ring (idx_read: LDS reads only, the caller waits), then dma_issue puts the slices in flight
+    auto idx_read = [&](int islot, int k0, int32_t(&c)[16]) {
         const uint32_t ca = col_lane + (uint32_t)(islot * kHubChunk + k0) * 4u;
-        int32_t c[16];  // IPS of them are used
 #define GNNX_HUB_RC(i) if constexpr ((i) < IPS) hub_lds_read<(i) * EPI * 4>(c[i], ca)
         GNNX_HUB_RC(0); GNNX_HUB_RC(1); GNNX_HUB_RC(2); GNNX_HUB_RC(3); GNNX_HUB_RC(4); GNNX_HUB_RC(5); GNNX_HUB_RC(6); GNNX_HUB_RC(7);
         GNNX_HUB_RC(8); GNNX_HUB_RC(9); GNNX_HUB_RC(10); GNNX_HUB_RC(11); GNNX_HUB_RC(12); GNNX_HUB_RC(13); GNNX_HUB_RC(14); GNNX_HUB_RC(15);
 #undef GNNX_HUB_RC
+    };
+    auto idx_wait = [&](int32_t(&c)[16]) {   // the reads above (and every older LDS operation) have returned
         static_assert(IPS == 4 || IPS == 8 || IPS == 16, "DMA instructions per sub-chunk");
         if constexpr (IPS == 4)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])::"memory");
@@ -698,16 +706,25 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]), "+v"(c[8]),
                            "+v"(c[9]), "+v"(c[10]), "+v"(c[11]), "+v"(c[12]), "+v"(c[13]), "+v"(c[14]), "+v"(c[15])::"memory");
+    };
+    auto dma_issue = [&](int slot, const int32_t(&c)[16]) {
+        float *dst = lds + slot * K::SUB_FLOATS;
 #pragma unroll
         for (int i = 0; i < IPS; i++) {
-            const XT *srcp = xsrc + (int64_t)c[i] * a.ldx;
+            const char *srcp = xsrc + (uint64_t)(uint32_t)c[i] * row_bytes;
             lds_void_t *dstp = (lds_void_t *)(dst + i * K::IFLOATS);
             // (a source pointer of DEPENDENT type makes clang drop the whole instantiation without a diagnostic when the size is
-            // 16: the kernel's symbol stays undefined -- hence the casts; tests/test_cabi_cpu.py runs `ldd -r` on the library)
+            // 16: the kernel's symbol stays undefined -- hence the concrete types; tests/test_cabi_cpu.py runs `ldd -r` on the library)
             if constexpr (K::DS == 16) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(srcp), dstp, 16, 0, 0);
             else if constexpr (K::DS == 4) __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(srcp), dstp, 4, 0, 0);
             else __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint16_t *>(srcp), dstp, 2, 0, 0);
         }
+    };
+    auto issue = [&](int slot, int islot, int k0) {   // prologue form: read, wait, issue
+        int32_t c[16];
+        idx_read(islot, k0, c);
+        idx_wait(c);
+        dma_issue(slot, c);
     };
     float acc = 0.f;
     auto add1 = [&](float x, float scv, float vv, int src) {
@@ -716,7 +733,12 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
         if constexpr (has_val(MODE)) x = mul_rn(x, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), src)));
         acc = add_rn(acc, x);
     };
-    auto consume = [&](int slot, int islot, int32_t cnt, int k0) {
+    // one step: sub-chunk t is added while sub-chunk t + LAS is put in flight.  The LDS reads of both -- the next issue's column
+    // indices and this sub-chunk's 16 values -- go out together and share one wait (a second LDS round trip per step was a quarter
+    // of a long row's time); the DMAs are issued in front of the adds.
+    auto step = [&](int slot, int islot, int32_t cnt, int k0, bool more, int slot_next, int islot_next, int k0_next) {
+        int32_t c[16];
+        if (more) idx_read(islot_next, k0_next, c);
         const uint32_t ad = ring_lane + (uint32_t)slot * (uint32_t)(K::SUB_FLOATS * 4);
         float v[kHubSub], vv = 1.f, scv = 1.f;
         if constexpr (has_val(MODE)) hub_lds_read<0>(vv, val_lane + (uint32_t)(islot * kHubChunk + k0) * 4u);
@@ -737,6 +759,10 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
         hub_lds_read_x<13 * K::SB, XT>(v[13], ad);
         hub_lds_read_x<14 * K::SB, XT>(v[14], ad);
         hub_lds_read_x<15 * K::SB, XT>(v[15], ad);
+        if (more) {
+            idx_wait(c);   // lgkmcnt(0): the values below have returned as well (LDS returns in order)
+            dma_issue(slot_next, c);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
                        "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(vv), "+v"(scv)::"memory");
@@ -773,14 +799,13 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
         for (int u = 0; u < SUBS; u++) {
             const int32_t t = cc * SUBS + u;
             if (t < nsub) {
-                if (t + LAS < nsub) {
-                    issue(slot_i, wrap(islot_c + (u + LAS) / SUBS), ((u + LAS) % SUBS) * kHubSub);
-                    slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
-                    hub_wait_vm<LAS * IPS>();  // sub-chunk t has landed; the LAS younger ones stay in flight
-                } else {
-                    hub_wait_vm<0>();
-                }
-                consume(slot_c, islot_c, total - t * kHubSub, u * kHubSub);
+                const bool more = t + LAS < nsub;
+                // sub-chunk t has landed: at most the LAS - 1 younger ones are still in flight (the tail drains everything)
+                if (more) hub_wait_vm<(LAS - 1) * IPS>();
+                else hub_wait_vm<0>();
+                step(slot_c, islot_c, total - t * kHubSub, u * kHubSub, more, slot_i, wrap(islot_c + (u + LAS) / SUBS),
+                     ((u + LAS) % SUBS) * kHubSub);
+                if (more) slot_i = slot_i + 1 == NS ? 0 : slot_i + 1;
                 slot_c = slot_c + 1 == NS ? 0 : slot_c + 1;
             }
         }
@@ -876,35 +901,42 @@ __global__ void plan_block_fill_kernel(const int32_t *flag, const int32_t *pos, 
     starts[pos[r]] = r;
 }
 
-template <int VEC, int MODE, class XT, bool SUMS = false>
-int launch_hub_kernel(hipStream_t st, const SpmmArgs &a)
+template <int VEC, int MODE, class XT, bool SUMS, int SLAB>
+int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int32_t n_rows_hub)
 {
     // look-ahead in sub-chunks of 16 neighbours: 8 where a sub-chunk is 4 DMA instructions, less where it is 8 or 16 (vmcnt counts
-    // at most 63 operations)
+    // at most 63 operations).
     // With a BatchNorm / ReLU prologue every gathered element costs ~15 vector-ALU instructions (an IEEE division among them) instead
     // of one add: a single wavefront per SIMD then alternates between issuing DMAs and computing, so those modes take a shorter ring
     // (LAS 3: 17 KB per wavefront) and run two workgroups per CU (6.17 -> 5.86 ms on the hub rows of the bench graph, against 3.44 ms
     // without a prologue: these modes are bound by the vector ALU -- the division -- in both kernels, not by memory).
     constexpr int LAS = (VEC == 4 && sizeof(XT) == 4) ? (has_pro(MODE) ? 3 : 8) : (VEC == 4 ? 6 : 3);
-    using K = HubCfg<VEC, MODE, LAS, XT>;
+    using K = HubCfg<VEC, MODE, LAS, XT, SLAB>;
+    if (n_rows_hub <= 0) return GNNX_OK;
     static std::atomic<uint64_t> done{0};
     constexpr size_t lds_wave = sizeof(float) * K::LDS_FLOATS;
     constexpr int max_waves = 160 * 1024 / lds_wave < 4 ? (int)(160 * 1024 / lds_wave) : 4;
-    const int32_t n_slabs = (int32_t)ceil_div(a.n_feat, kHubSlab);
+    const int32_t n_slabs = (int32_t)ceil_div(a.n_feat, SLAB);
     const int waves = n_slabs < max_waves ? n_slabs : max_waves;
     const int32_t n_groups = (int32_t)ceil_div(n_slabs, waves);
     int dev = 0;
     GNNX_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {  // dynamic-LDS opt-in, once per kernel and device
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS>),
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS, SLAB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_wave * max_waves)));
         if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
     }
-    const dim3 grid((uint32_t)((int64_t)a.n_hub_rows * n_groups));
+    const dim3 grid((uint32_t)((int64_t)n_rows_hub * n_groups));
     const size_t lds_wg = lds_wave * waves;
-    hipLaunchKernelGGL((spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS>), grid, dim3(64 * waves), lds_wg, st, a, a.hub_rows, n_slabs, n_groups);
+    hipLaunchKernelGGL((spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS, SLAB>), grid, dim3(64 * waves), lds_wg, st, a, rows, n_slabs, n_groups);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
+}
+
+template <int VEC, int MODE, class XT, bool SUMS = false>
+int launch_hub_kernel(hipStream_t st, const SpmmArgs &a)
+{
+    return launch_hub_rows<VEC, MODE, XT, SUMS, kHubSlab>(st, a, a.hub_rows, a.n_hub_rows);
 }
 
 template <int VEC>
@@ -987,6 +1019,31 @@ void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a)
 #undef GNNX_ROWS
 }
 
+// Side stream of the aggregation (hub kernel beside the row kernel): one per host thread and device, created on first use, with
+// the two events of the fork / join.  Per thread because a rank = one host thread = one stream (gnnx.h): two threads never share
+// the events.  Never destroyed before the process ends (the runtime reclaims it).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+SideStream *side_stream()
+{
+    constexpr int kMaxDev = 64;
+    static thread_local SideStream table[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    SideStream &s = table[dev];
+    if (!s.stream) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+            s = SideStream{};
+            return nullptr;
+        }
+    }
+    return &s;
+}
+
 template <int G, int VEC, int U>
 int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipStream_t st)
 {
@@ -1001,9 +1058,24 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     const int mode = a.vals != nullptr ? (a.colscale ? 6 : 2) : (a.colscale ? 1 : (pro ? 2 + pro : 0));
     bool stream = false;
     if constexpr (G >= 8) stream = use_stream_kernel(G);
-    if (a.n_hub_rows > 0) {
+    // The hub kernel (LDS rings, few registers, 4 wavefronts per CU) and the row kernel (registers, no LDS) touch disjoint rows and
+    // fit on a CU together.  When the hub kernel is latency-bound (spmm_impl: hub_beside) it goes to a side stream -- forked from
+    // and joined back into the caller's stream with events -- and hides under the row kernel (RMAT 1M / 10M, F = 128: a 0.49 ms hub
+    // kernel beside a 0.45 ms streaming kernel); when it is bandwidth-bound the two would only share the same bytes per second.
+    SideStream *side = nullptr;
+    static const int side_env = [] { const char *e = experiment_env("GNNX_SPMM_SIDE"); return e ? atoi(e) : -1; }();   // A/B: 0 never, 1 always
+    const bool beside = side_env < 0 ? a.hub_beside != 0 : side_env != 0;
+    if (a.n_hub_rows > 0 && !beside) {
         const int rc = launch_hub<VEC>(mode, st, a);
         if (rc != GNNX_OK) return rc;
+    } else if (a.n_hub_rows > 0) {
+        side = side_stream();
+        GNNX_REQUIRE(side, GNNX_ERR_HIP, "could not create the aggregation's side stream");
+        GNNX_HIP_CHECK(hipEventRecord(side->fork, st));
+        GNNX_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+        const int rc = launch_hub<VEC>(mode, side->stream, a);
+        if (rc != GNNX_OK) return rc;
+        GNNX_HIP_CHECK(hipEventRecord(side->join, side->stream));
     }
     if (stream) {
         if constexpr (G >= 8) {
@@ -1024,6 +1096,7 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
         launch_rows<G, VEC, U>(mode, grid, st, a);
     }
     GNNX_LAUNCH_CHECK();
+    if (side) GNNX_HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));   // whatever follows on the caller's stream sees every row
     return GNNX_OK;
 }
 
@@ -1065,6 +1138,7 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
         std::sort(h_rows.begin(), h_rows.end(), [](const int2 &x, const int2 &y) { return x.y != y.y ? x.y > y.y : x.x < y.x; });
         std::vector<int32_t> h_hub(h_rows.size());
         for (size_t i = 0; i < h_rows.size(); i++) h_hub[i] = h_rows[i].x;
+        plan->max_hub_degree = h_rows.empty() ? 0 : h_rows[0].y;
         GNNX_HIP_CHECK(hipMalloc(&plan->d_hub_rows, sizeof(int32_t) * h_hub.size()));
         GNNX_HIP_CHECK(hipMemcpyAsync(plan->d_hub_rows, h_hub.data(), sizeof(int32_t) * h_hub.size(), hipMemcpyHostToDevice, st));
         GNNX_HIP_CHECK(hipStreamSynchronize(st));
@@ -1207,6 +1281,10 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         a.split_threshold = plan->chunk;
         a.hub_rows = plan->d_hub_rows;
         a.n_hub_rows = plan->n_split_rows;
+        // Hub kernel beside the row kernel (side stream) or in front of it (same stream)?  Beside, when its time is the dependent-add
+        // chain of its longest row (~12 ns per neighbour) rather than its bytes (hub non-zeros x row bytes at ~7 TB/s):
+        // RMAT 1M / 10M, F = 128: 0.92 -> 0.79 ms; RMAT 10M / 100M, F = 256 (28 GB of hub rows): in front, 13.59 vs 13.76 ms beside.
+        a.hub_beside = (int64_t)plan->max_hub_degree * 20000 > plan->n_hub_nnz * (int64_t)n_feat;
     }
     hipStream_t st = as_stream(stream);
     auto aligned16 = [](const void *p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };

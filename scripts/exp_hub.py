@@ -35,15 +35,16 @@ def timed(fn, reps=10):
 
 
 def main():
-    n, e, F = 10_000_000, 100_000_000, int(os.environ.get("F", "256"))
+    n, e, F = int(os.environ.get("N", 10_000_000)), int(os.environ.get("E", 100_000_000)), int(os.environ.get("F", "256"))
+    seed = int(os.environ.get("SEED", "2"))
     relabel = None if os.environ.get("ORDER") == "as-generated" else "scramble"
-    src, dst = ops.rmat_edges(2, n, e, device=dev)
+    src, dst = ops.rmat_edges(seed, n, e, device=dev)
     g = ops.CsrGraph.from_coo(src, dst, n, relabel=relabel)
     del src, dst
     H = ops.uniform_pm1(1, (n, F), device=dev)
     bias = torch.zeros(F, dtype=torch.float32, device=dev)
     out = torch.empty_like(H)
-    tag = f"lib={os.environ.get('GNNX_HIP_LIB', 'product')} hub={os.environ.get('GNNX_SPMM_HUB', '-')} las={os.environ.get('GNNX_SPMM_HUB_LAS', '-')}"
+    tag = f"lib={os.environ.get('GNNX_HIP_LIB', 'product')} n={n} F={F} side={os.environ.get('GNNX_SPMM_SIDE', '1')}"
     for chunk in [int(c) for c in os.environ.get("CHUNKS", "0,1024,2048,4096,8192").split(",")]:
         if chunk:
             g.make_plans(chunk, F)
