@@ -74,10 +74,14 @@ class _RankDist:
         self.w.bar.wait()
 
 
-@pytest.mark.parametrize("world,schedule,partition", [(2, "overlap", "deal"), (4, "overlap", "deal"), (8, "overlap", "deal"),
-                                                      (4, "sequential", "deal"), (8, "sequential", "contiguous"),
-                                                      (4, "replicate-input-halo", "deal"), (8, "replicate-input-halo", "deal")])
-def test_sharded_step_equals_single_gpu(world, schedule, partition):
+@pytest.mark.parametrize("world,schedule,partition,chunk", [(2, "overlap", "deal", 0), (4, "overlap", "deal", 64), (8, "overlap", "deal", 0),
+                                                            (4, "sequential", "deal", 0), (8, "sequential", "contiguous", 64),
+                                                            (4, "replicate-input-halo", "deal", 0),
+                                                            (8, "replicate-input-halo", "deal", 256)])
+def test_sharded_step_equals_single_gpu(world, schedule, partition, chunk):
+    """chunk > 0: every shard runs with a load-balancing plan (hub rows of the shard's [local | halo] CSR on the sequential hub
+    kernel), as bench.py does -- same bits.  The single-GPU reference the shards are compared with is itself compared with the CPU
+    oracle here, bit for bit, so "equals one GPU" is "equals the oracle" at this size."""
     import torch
     if not torch.cuda.is_available():
         pytest.fail("needs a HIP device")
@@ -99,6 +103,12 @@ def test_sharded_step_equals_single_gpu(world, schedule, partition):
     dX_ref, dW_ref = ops.linear_bwd(dH_ref, X, W)
     dbias_ref = ops.colsum(G)
     torch.cuda.synchronize()
+    import oracle   # checker only
+    rp, ci = oracle.coo_to_csr(src.cpu().numpy(), dst.cpu().numpy(), n)
+    rT, cT = oracle.csr_transpose(rp, ci, n)
+    norm_h = g.norm.cpu().numpy()
+    assert np.array_equal(out_ref.cpu().numpy(), oracle.aggregate_fwd(rp, ci, H.cpu().numpy(), norm_h, bias.cpu().numpy()))
+    assert np.array_equal(dH_ref.cpu().numpy(), oracle.aggregate_bwd(rT, cT, G.cpu().numpy(), norm_h))
 
     lw = LoopbackWorld(world)
     runners, errors = [None] * world, []
@@ -107,7 +117,7 @@ def test_sharded_step_equals_single_gpu(world, schedule, partition):
         try:
             torch.cuda.set_device(0)
             rep = schedule == "replicate-input-halo"   # opt-in first-layer form: X halo fetched once, one exchange per step
-            r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 0, global_inputs=True,
+            r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, chunk, global_inputs=True,
                                    schedule="overlap" if rep else schedule, partition=partition, replicate_input_halo=rep)
             r.step()
             r.step(timed=True)  # a second step reuses every buffer (send buffers, halo tails) while nothing is in flight
