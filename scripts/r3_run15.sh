@@ -1,7 +1,7 @@
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-GIT_HEAD=91d68fe bash scripts/profile_all.sh r03 2>&1 | tail -12
+GIT_HEAD=e45684d bash scripts/profile_all.sh r03 2>&1 | tail -12
 cd $GRAFT_REPO_ROOT
 mkdir -p profiles && cp gpurun_out/profiles_r03/* profiles/
 ( time timeout -k 10 900 python bench.py > gpurun_out/r3_bench_default.json 2> gpurun_out/r3_bench_default.err ) 2>&1 | tail -4
