@@ -33,6 +33,28 @@ inline const char *experiment_env(const char *) { return nullptr; }
 
 }  // namespace gnnx
 
+namespace gnnx {
+// RN_f32(d / sd) -- the reference's `(x - mean) / (var + eps)->pow(0.5)` element (nn.cpp:301-316 -> functional.h Div: one IEEE
+// division) -- from ONE f64 multiply by the precomputed RN_f64(1 / sd) instead of the ~10-instruction f32 division sequence: the
+// prologue is bound by the vector ALU, and the division was most of it.  Correctly rounded, not approximately:
+//   * with 24-bit operands the quotient d / sd is never half-way between two floats (that would need 2^25 | B for a 24-bit B), and
+//     if it is not a float itself it lies at least 2^-49 (relative) away from every float and every half-way point:
+//     |A / B - N 2^-25| = |A 2^25 - N B| / (B 2^25) >= 1 / (B 2^25) > 2^-49 for integers A, B < 2^24;
+//   * (double)d * rsd carries two f64 roundings: relative error <= 2^-52 -- an eighth of that distance -- so rounding it to f32
+//     (v_cvt_f32_f64, round to nearest even) lands on the float the exact quotient rounds to; the overflow threshold is a half-way
+//     point of the same form;
+//   * the argument needs a NORMAL quotient: a subnormal (or flushed) result takes the IEEE division itself (never seen on
+//     normalised activations; a wave-uniform-in-practice branch).  NaN / inf / zero operands give what the division gives.
+// tests/test_gpu_parity.py::test_division_by_column_constant_is_ieee_exact sweeps it against numpy's division.
+__device__ __forceinline__ float div_by_const(float d, float sd, double rsd)
+{
+    float q = (float)((double)d * rsd);
+    if (__builtin_expect(!(fabsf(q) >= 1.17549435e-38f) && d != 0.f, 0)) q = __fdiv_rn(d, sd);
+    return q;
+}
+
+}  // namespace gnnx
+
 #define GNNX_HIP_CHECK(expr)                                                                              \
     do {                                                                                                  \
         hipError_t _e = (expr);                                                                           \

@@ -201,12 +201,14 @@ __global__ __launch_bounds__(256) void bn_bwd_vec_kernel(BnBwdVecArgs p)
     const int32_t f = 4 * cq;
     float mean[4] = {0.f, 0.f, 0.f, 0.f}, rstd[4] = {1.f, 1.f, 1.f, 1.f}, sd[4] = {1.f, 1.f, 1.f, 1.f}, gm[4] = {1.f, 1.f, 1.f, 1.f},
           bt[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f}, dg[4] = {0.f, 0.f, 0.f, 0.f};
+    double rsd[4] = {1.0, 1.0, 1.0, 1.0};   // RN_f64(1 / sd): the forward's division as one f64 multiply (gnnx_common.h: div_by_const)
     const bool stats = p.mean != nullptr;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         if (stats) {
             mean[c] = p.mean[f + c];
             sd[c] = sqrtf(__fadd_rn(p.var[f + c], p.eps));      // (var + eps)->pow(0.5), the forward's divisor
+            rsd[c] = 1.0 / (double)sd[c];
             rstd[c] = 1.0f / sqrtf(p.var[f + c] + p.eps);
             if (p.gamma) gm[c] = p.gamma[f + c];
             if (p.beta) bt[c] = p.beta[f + c];
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void bn_bwd_vec_kernel(BnBwdVecArgs p)
                         else {
                             float v = xs[c];
                             if (stats) {
-                                v = __fdiv_rn(__fsub_rn(v, mean[c]), sd[c]);
+                                v = div_by_const(__fsub_rn(v, mean[c]), sd[c], rsd[c]);
                                 if (p.gamma) v = __fmul_rn(v, gm[c]);
                                 if (p.beta) v = __fadd_rn(v, bt[c]);
                             }
@@ -304,11 +306,13 @@ __global__ __launch_bounds__(256) void bn_fwd_vec_kernel(const float *X, int64_t
     if (rr >= rpp) return;
     const int32_t f = 4 * cq;
     float mu[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {1.f, 1.f, 1.f, 1.f}, gm[4] = {1.f, 1.f, 1.f, 1.f}, bt[4] = {0.f, 0.f, 0.f, 0.f};
+    double rsd[4] = {1.0, 1.0, 1.0, 1.0};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         if (mean) {
             mu[c] = mean[f + c];
             sd[c] = sqrtf(__fadd_rn(var[f + c], eps));
+            rsd[c] = 1.0 / (double)sd[c];
             if (gamma) gm[c] = gamma[f + c];
             if (beta) bt[c] = beta[f + c];
         }
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void bn_fwd_vec_kernel(const float *X, int64_t
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 if (mean) {
-                    v[c] = __fdiv_rn(__fsub_rn(v[c], mu[c]), sd[c]);
+                    v[c] = div_by_const(__fsub_rn(v[c], mu[c]), sd[c], rsd[c]);   // == __fdiv_rn: one f64 multiply (gnnx_common.h)
                     if (gamma) v[c] = __fmul_rn(v[c], gm[c]);
                     if (beta) v[c] = __fadd_rn(v[c], bt[c]);
                 }

@@ -139,13 +139,14 @@ constexpr bool has_val(int MODE) { return MODE == 2 || MODE == 6; }   // per-ent
 constexpr bool has_pro(int MODE) { return MODE >= 3 && MODE <= 5; }   // prologue on the gathered row
 constexpr bool pro_bn(int MODE) { return MODE == 4 || MODE == 5; }
 constexpr bool pro_relu(int MODE) { return MODE == 3 || MODE == 5; }
-template <int VEC> struct ProConst { typename Vec<VEC>::type mean, sd, gamma, beta; };
+// rsd[i] = RN_f64(1 / sd_i): the divisor of the normalisation is a per-column constant (div_by_const below)
+template <int VEC> struct ProConst { typename Vec<VEC>::type mean, sd, gamma, beta; double rsd[VEC]; };
 
 template <int MODE>
-__device__ __forceinline__ float pro1(float v, float mean, float sd, float gamma, float beta)
+__device__ __forceinline__ float pro1(float v, float mean, float sd, double rsd, float gamma, float beta)
 {
     if constexpr (pro_bn(MODE)) {
-        v = __fdiv_rn(__fsub_rn(v, mean), sd);
+        v = div_by_const(__fsub_rn(v, mean), sd, rsd);
         v = __fmul_rn(v, gamma);
         v = __fadd_rn(v, beta);
     }
@@ -153,12 +154,12 @@ __device__ __forceinline__ float pro1(float v, float mean, float sd, float gamma
     return v;
 }
 template <int MODE>
-__device__ __forceinline__ float pro_apply(float v, const ProConst<1> &c) { return pro1<MODE>(v, c.mean, c.sd, c.gamma, c.beta); }
+__device__ __forceinline__ float pro_apply(float v, const ProConst<1> &c) { return pro1<MODE>(v, c.mean, c.sd, c.rsd[0], c.gamma, c.beta); }
 template <int MODE>
 __device__ __forceinline__ float4 pro_apply(float4 v, const ProConst<4> &c)
 {
-    return make_float4(pro1<MODE>(v.x, c.mean.x, c.sd.x, c.gamma.x, c.beta.x), pro1<MODE>(v.y, c.mean.y, c.sd.y, c.gamma.y, c.beta.y),
-                       pro1<MODE>(v.z, c.mean.z, c.sd.z, c.gamma.z, c.beta.z), pro1<MODE>(v.w, c.mean.w, c.sd.w, c.gamma.w, c.beta.w));
+    return make_float4(pro1<MODE>(v.x, c.mean.x, c.sd.x, c.rsd[0], c.gamma.x, c.beta.x), pro1<MODE>(v.y, c.mean.y, c.sd.y, c.rsd[1], c.gamma.y, c.beta.y),
+                       pro1<MODE>(v.z, c.mean.z, c.sd.z, c.rsd[2], c.gamma.z, c.beta.z), pro1<MODE>(v.w, c.mean.w, c.sd.w, c.rsd[3], c.gamma.w, c.beta.w));
 }
 __device__ __forceinline__ float sd_of(float var, float eps) { return sqrtf(__fadd_rn(var, eps)); }  // (var + eps)->pow(0.5)
 __device__ __forceinline__ float4 sd_of(float4 var, float eps)
@@ -177,10 +178,20 @@ __device__ __forceinline__ ProConst<VEC> pro_load(const ARGS &a, int32_t f0, boo
     splat(c.sd, 1.f);
     splat(c.gamma, 1.f);
     splat(c.beta, 0.f);
+#pragma unroll
+    for (int i = 0; i < VEC; i++) c.rsd[i] = 1.0;
     if constexpr (pro_bn(MODE)) {
         if (active) {
             c.mean = ld_vec(reinterpret_cast<const V *>(a.pro_mean + f0));
             c.sd = sd_of(ld_vec(reinterpret_cast<const V *>(a.pro_var + f0)), a.pro_eps);
+            if constexpr (VEC == 4) {
+                c.rsd[0] = 1.0 / (double)c.sd.x;
+                c.rsd[1] = 1.0 / (double)c.sd.y;
+                c.rsd[2] = 1.0 / (double)c.sd.z;
+                c.rsd[3] = 1.0 / (double)c.sd.w;
+            } else {
+                c.rsd[0] = 1.0 / (double)c.sd;
+            }
             if (a.pro_gamma) c.gamma = ld_vec(reinterpret_cast<const V *>(a.pro_gamma + f0));
             if (a.pro_beta) c.beta = ld_vec(reinterpret_cast<const V *>(a.pro_beta + f0));
         }
@@ -341,9 +352,11 @@ __device__ __forceinline__ void bn_sums_rows(const SpmmArgs &a, int32_t row_lo, 
     const float mean[4] = {mean4.x, mean4.y, mean4.z, mean4.w}, var[4] = {var4.x, var4.y, var4.z, var4.w};
     const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w}, bt[4] = {bt4.x, bt4.y, bt4.z, bt4.w};
     float sd[4], rstd[4], a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+    double rsd[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         sd[c] = sqrtf(__fadd_rn(var[c], a.pro_eps));
+        rsd[c] = 1.0 / (double)sd[c];
         rstd[c] = 1.0f / sqrtf(var[c] + a.pro_eps);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wavefront's stores of dY have reached L2
@@ -363,7 +376,7 @@ __device__ __forceinline__ void bn_sums_rows(const SpmmArgs &a, int32_t row_lo, 
                 for (int c = 0; c < 4; c++) {
                     float g = ds[c];
                     if (a.bn_relu) {
-                        float v = __fdiv_rn(__fsub_rn(hs[c], mean[c]), sd[c]);
+                        float v = div_by_const(__fsub_rn(hs[c], mean[c]), sd[c], rsd[c]);   // the forward's quotient, same bits
                         if (a.pro_gamma) v = __fmul_rn(v, gm[c]);
                         if (a.pro_beta) v = __fadd_rn(v, bt[c]);
                         if (!(v > 0.f)) g = 0.f;
@@ -906,10 +919,11 @@ int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int3
 {
     // look-ahead in sub-chunks of 16 neighbours: 8 where a sub-chunk is 4 DMA instructions, less where it is 8 or 16 (vmcnt counts
     // at most 63 operations).
-    // With a BatchNorm / ReLU prologue every gathered element costs ~15 vector-ALU instructions (an IEEE division among them) instead
-    // of one add: a single wavefront per SIMD then alternates between issuing DMAs and computing, so those modes take a shorter ring
-    // (LAS 3: 17 KB per wavefront) and run two workgroups per CU (6.17 -> 5.86 ms on the hub rows of the bench graph, against 3.44 ms
-    // without a prologue: these modes are bound by the vector ALU -- the division -- in both kernels, not by memory).
+    // With a BatchNorm / ReLU prologue every gathered element costs ~12 vector-ALU instructions (three of them f64) instead of one
+    // add: a single wavefront per SIMD then alternates between issuing DMAs and computing, so those modes take a shorter ring
+    // (LAS 3: 17 KB per wavefront) and run two workgroups per CU: 5.7 ms on the hub rows of the bench graph against 6.2 ms with the
+    // long ring and 3.4 ms without a prologue -- the hub kernel's prologue modes stay bound by the vector ALU (the streaming
+    // kernel, 16 wavefronts per CU, hides it: 10.1 ms with and without).
     constexpr int LAS = (VEC == 4 && sizeof(XT) == 4) ? (has_pro(MODE) ? 3 : 8) : (VEC == 4 ? 6 : 3);
     using K = HubCfg<VEC, MODE, LAS, XT, SLAB>;
     if (n_rows_hub <= 0) return GNNX_OK;

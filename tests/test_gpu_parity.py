@@ -299,6 +299,38 @@ def test_backward_aggregation_with_batchnorm_sums(env, n, e, F, chunk, relu, aff
                                   var[..., :32].contiguous(), None, None, 1e-5, relu)
 
 
+@pytest.mark.parametrize("F", [256, 100, 16, 7])
+def test_division_by_column_constant_is_ieee_exact(env, F):
+    """The BatchNorm prologue of the fused aggregation divides by a per-column constant with ONE f64 multiply by the precomputed
+    reciprocal (gnnx_spmm.hip: div_by_const; proof of correct rounding there).  Swept against numpy's IEEE float32 division on a ring
+    graph (every row has exactly one neighbour, so the output IS the normalised element): operands over the whole exponent range,
+    quotients that are subnormal, zero, huge and infinite, divisors from 1e-19 to 1e18 -- every element equal, NaN for NaN."""
+    ops, torch = env["ops"], env["torch"]
+    n = 262144
+    rng = np.random.default_rng(1234 + F)
+    mant = rng.uniform(1.0, 2.0, size=(n, F)).astype(np.float32)
+    expo = rng.integers(-140, 120, size=(n, F))
+    X = (np.where(rng.random((n, F)) < 0.5, -1.0, 1.0) * np.ldexp(mant.astype(np.float64), expo)).astype(np.float32)
+    X[::97, 0] = 0.0
+    X[5::101, F - 1] = np.inf
+    var = np.ldexp(rng.uniform(1.0, 2.0, size=F), rng.integers(-126, 120, size=F)).astype(np.float32)
+    mean = (rng.uniform(-1, 1, size=F) * np.ldexp(1.0, rng.integers(-30, 30, size=F))).astype(np.float32)
+    mean[::3] = 0.0   # then x - mean is x itself: the sweep of quotients is the sweep of x
+    eps = np.float32(1e-5)
+    rowptr = torch.arange(n + 1, dtype=torch.int32, device=env["dev"])
+    colidx = ((torch.arange(n, dtype=torch.int64, device=env["dev"]) + 1) % n).to(torch.int32)
+    got = host(ops.spmm(rowptr, colidx, dev(env, X), bn=(dev(env, mean), dev(env, var), None, None, float(eps))))
+    with np.errstate(all="ignore"):
+        sd = np.sqrt((var + eps).astype(np.float32)).astype(np.float32)
+        d = (X - mean[None, :]).astype(np.float32)
+        want = (d / sd[None, :]).astype(np.float32)
+        want = (want * np.float32(1.0)).astype(np.float32) + np.float32(0.0)
+    want = np.roll(want, -1, axis=0)   # row i holds the element of row i + 1
+    same_val = (got == want) | (np.isnan(got) & np.isnan(want))
+    assert same_val.all(), f"{(~same_val).sum()} of {same_val.size} quotients differ from IEEE division"
+    assert (np.abs(want[np.isfinite(want)]) < 1.2e-38).sum() > 100 and np.isinf(want).sum() > 10   # the sweep reached the edges
+
+
 @pytest.mark.parametrize("F", [16, 7, 33])
 def test_spmm_split_rows_plan_narrow_features(env, F):
     """The plan (hub kernel + the one-row-per-group kernel used at F <= 64), vector and scalar lanes: the oracle's bits."""
