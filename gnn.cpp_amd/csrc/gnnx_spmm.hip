@@ -922,7 +922,7 @@ int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int3
     // With a BatchNorm / ReLU prologue every gathered element costs ~12 vector-ALU instructions (three of them f64) instead of one
     // add: a single wavefront per SIMD then alternates between issuing DMAs and computing, so those modes take a shorter ring
     // (LAS 3: 17 KB per wavefront) and run two workgroups per CU: 5.7 ms on the hub rows of the bench graph against 6.2 ms with the
-    // long ring and 3.4 ms without a prologue -- the hub kernel's prologue modes stay bound by the vector ALU (the streaming
+    // long ring, 6.5 ms with LAS 2, and 3.4 ms without a prologue -- the hub kernel's prologue modes stay bound by the vector ALU (the streaming
     // kernel, 16 wavefronts per CU, hides it: 10.1 ms with and without).
     constexpr int LAS = (VEC == 4 && sizeof(XT) == 4) ? (has_pro(MODE) ? 3 : 8) : (VEC == 4 ? 6 : 3);
     using K = HubCfg<VEC, MODE, LAS, XT, SLAB>;
