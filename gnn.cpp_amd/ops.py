@@ -154,6 +154,21 @@ class CsrGraph:
                   _ptr(self.norm), _stream())
         return self.s, self.norm
 
+    def norm_from_pow_table(self, pow_table):
+        """OPT-IN "libm-exact" degree block: s_i = pow_table[1 + deg_i] with the table supplied by the CALLER -- pow_table[k] =
+        powf((float)k, -0.5f) evaluated by the host's libm, which is literally what the reference computes (functional.h:253,
+        std::pow on the host) -- instead of the device's correctly rounded rsqrt (1 ulp apart for a few degrees >= 1058), then
+        norm = (A . s) (.) s through gnnx_degree_norm_f32 with the caller's s (its d_s_cols argument).  Returns (s, norm) in this
+        graph's row order; nothing of the graph object changes.  With it the whole chain norm -> aggregation is bit-exact against
+        the reference's arithmetic at any size (tests/test_gpu_parity.py::test_headline_config_whole_graph_vs_oracle)."""
+        deg1 = (self.rowptr[1:] - self.rowptr[:-1] + 1).long()
+        if int(deg1.max()) >= pow_table.numel():
+            raise ValueError(f"pow_table has {pow_table.numel()} entries, the largest 1 + degree is {int(deg1.max())}")
+        s = pow_table.to(torch.float32)[deg1].contiguous()
+        norm = torch.empty(self.n, dtype=torch.float32, device=s.device)
+        capi.call("gnnx_degree_norm_f32", _ptr(self.rowptr), _ptr(self.colidx), self.n, None, _ptr(s), _ptr(norm), _stream())
+        return s, norm
+
     def make_plans(self, chunk, max_feat):
         """Load-balancing plans for power-law rows (forward CSR and transposed CSR)."""
         self.plan = SpmmPlan(self.rowptr, chunk, max_feat)

@@ -131,6 +131,10 @@ int gnnx_csr_from_coo_weighted(const int32_t *d_src, const int32_t *d_dst, const
  * d_s and d_norm: n_rows fp32 each (the reference's [N,1] tensors).  Either may be NULL.
  * For a row block of a sharded graph pass d_s_cols (the s values indexed by COLUMN id, i.e. [local|halo])
  * and d_s is written for the block's own rows only; with d_s_cols == NULL columns index d_s itself.
+ * s written here is the CORRECTLY ROUNDED (1 + deg)^-1/2; the reference's libm powf is 1 ulp off for 9 685 of the 2^24 degrees,
+ * the smallest 1058.  A caller that wants the reference's very bits at any size passes its own s (d_s == NULL, d_s_cols = s_i looked
+ * up in a table of its host libm's powf(k, -0.5f): functional.h:253 is that call) -- ops.CsrGraph.norm_from_pow_table does; norm
+ * and both aggregations of the 10 M / 100 M graph are then bit-exact end to end (test_headline_config_whole_graph_vs_oracle).
  */
 int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_colidx, int32_t n_rows, float *d_s,
                          const float *d_s_cols, float *d_norm, void *stream);

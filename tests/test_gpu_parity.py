@@ -1006,7 +1006,9 @@ def test_headline_config_whole_graph_vs_oracle(env):
       * fed the same norm, every one of the 10 M rows of both PLANNED aggregations is BIT-EXACT -- and the unplanned kernels and the
         as-generated order give those bits too;
       * end to end with the ORACLE'S OWN norm (glibc powf order; the device's rsqrt is correctly rounded, 1 ulp apart for a few
-        degrees >= 1058): inside the 1e-5 bar (condition-aware for the backward, whose terms carry the per-source norm)."""
+        degrees >= 1058): inside the 1e-5 bar (condition-aware for the backward, whose terms carry the per-source norm);
+      * with the opt-in libm-exact degree block (s looked up in the host libm's powf table, CsrGraph.norm_from_pow_table): s, norm,
+        and both aggregations BIT-EXACT against the oracle with its own norm -- nothing tolerance-level is left on the path."""
     ops, torch = env["ops"], env["torch"]
     n, e, F, abc, seed = 10_000_000, 100_000_000, 256, (0.57, 0.19, 0.19), 2
     srcd, dstd = ops.rmat_edges(seed, n, e, *abc)
@@ -1046,7 +1048,14 @@ def test_headline_config_whole_graph_vs_oracle(env):
     ref2 = oracle.aggregate_fwd(rp, ci, Hh, norm, bias)                 # the oracle's own norm: end to end
     got = host(O_v)
     assert (np.abs(got.astype(np.float64) - ref2) / np.maximum(1.0, np.abs(ref2))).max() <= 1e-5, "forward vs oracle (own norm)"
-    del got, ref2, O_v, H, Hh
+    # opt-in libm-exact degree block: s from the HOST libm's powf table (the reference's own call, functional.h:253) -> s, norm and
+    # the whole aggregation are the oracle's, bit for bit, end to end at this size
+    pow_table = dev(env, oracle.powf_table(int(np.diff(rp).max()) + 3))
+    s_l, norm_l = g.norm_from_pow_table(pow_table)
+    assert same(host(g.to_vertex_order(s_l)), s) and same(host(g.to_vertex_order(norm_l)), norm), "libm-exact s / norm"
+    O_l = ops.spmm(g.rowptr, g.colidx, g.to_new_order(H), rowscale=norm_l, bias=dev(env, bias), plan=g.plan)
+    assert same(host(g.to_vertex_order(O_l)), ref2), "libm-exact mode: forward aggregation bit-exact end to end"
+    del got, ref2, O_v, O_l, H, Hh
     torch.cuda.empty_cache()
     # ---- backward
     G = ops.uniform_pm1(430, (n, F))
@@ -1065,7 +1074,10 @@ def test_headline_config_whole_graph_vs_oracle(env):
     indeg = np.diff(rT).astype(np.float64)
     scale = np.maximum(np.maximum(1.0, np.abs(ref2)), (float(np.abs(norm).max()) * indeg)[:, None])
     assert (np.abs(got.astype(np.float64) - ref2) / scale).max() <= 1e-5, "backward vs oracle (own norm)"
-    del got, ref2, D_v, G, Gh, g, g0
+    vals_l = ops.gather_rows(norm_l.reshape(-1, 1), g.colidx_t).reshape(-1)   # libm-exact norm as the backward's per-entry scale
+    D_l = ops.spmm(g.rowptr_t, g.colidx_t, g.to_new_order(G), vals=vals_l, plan=g.plan_t)
+    assert same(host(g.to_vertex_order(D_l)), ref2), "libm-exact mode: backward aggregation bit-exact end to end"
+    del got, ref2, D_v, D_l, G, Gh, g, g0
     ops._ws_cache.clear()
     torch.cuda.empty_cache()
 
