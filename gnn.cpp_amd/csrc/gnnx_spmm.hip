@@ -740,8 +740,33 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
         dma_issue(slot, c);
     };
     float acc = 0.f;
+    // The prologue of a whole sub-chunk in straight-line code: 16 independent chains (sub, f64 multiply, convert, mul, add, max) that
+    // the scheduler interleaves.  Applied element by element inside the add loop, each chain sat between exec-mask branches (the
+    // subnormal guard of div_by_const, the j < cnt test) and ran at its full latency: the hub kernel's prologue modes were bound by
+    // that, not by memory.  The guard is taken once per sub-chunk; slots past the row's end hold stale LDS words -- harmless, never added.
+    auto pro_batch = [&](float(&v)[kHubSub]) {
+        if constexpr (pro_bn(MODE)) {
+            float d[kHubSub];
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++) {
+                d[j] = __fsub_rn(v[j], pc.mean);
+                v[j] = (float)((double)d[j] * pc.rsd[0]);
+                bad |= !(fabsf(v[j]) >= 1.17549435e-38f) && d[j] != 0.f;
+            }
+            if (__builtin_expect(bad, 0)) {   // a subnormal quotient somewhere: the IEEE division for the sub-chunk (div_by_const)
+#pragma unroll
+                for (int j = 0; j < kHubSub; j++) v[j] = __fdiv_rn(d[j], pc.sd);
+            }
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++) v[j] = __fadd_rn(__fmul_rn(v[j], pc.gamma), pc.beta);
+        }
+        if constexpr (pro_relu(MODE)) {
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++) v[j] = relu1(v[j]);
+        }
+    };
     auto add1 = [&](float x, float scv, float vv, int src) {
-        if constexpr (has_pro(MODE)) x = pro_apply<MODE>(x, pc);
         if constexpr (has_sc(MODE)) x = mul_rn(x, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(scv), src)));
         if constexpr (has_val(MODE)) x = mul_rn(x, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), src)));
         acc = add_rn(acc, x);
@@ -783,6 +808,7 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
 #pragma unroll
             for (int j = 0; j < kHubSub; j++) v[j] = __uint_as_float(__float_as_uint(v[j]) << 16);
         }
+        if constexpr (has_pro(MODE)) pro_batch(v);
         if (cnt >= kHubSub) {
 #pragma unroll
             for (int j = 0; j < kHubSub; j++) add1(v[j], scv, vv, j);
@@ -919,12 +945,10 @@ int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int3
 {
     // look-ahead in sub-chunks of 16 neighbours: 8 where a sub-chunk is 4 DMA instructions, less where it is 8 or 16 (vmcnt counts
     // at most 63 operations).
-    // With a BatchNorm / ReLU prologue every gathered element costs ~12 vector-ALU instructions (three of them f64) instead of one
-    // add: a single wavefront per SIMD then alternates between issuing DMAs and computing, so those modes take a shorter ring
-    // (LAS 3: 17 KB per wavefront) and run two workgroups per CU: 5.7 ms on the hub rows of the bench graph against 6.2 ms with the
-    // long ring, 6.5 ms with LAS 2, and 3.4 ms without a prologue -- the hub kernel's prologue modes stay bound by the vector ALU (the streaming
-    // kernel, 16 wavefronts per CU, hides it: 10.1 ms with and without).
-    constexpr int LAS = (VEC == 4 && sizeof(XT) == 4) ? (has_pro(MODE) ? 3 : 8) : (VEC == 4 ? 6 : 3);
+    // (Prologue modes: with the sub-chunk's prologue in straight-line code the ring length no longer matters -- 4.90 ms on the hub
+    // rows of the bench graph with LAS 3 or 8, against 5.7 / 6.2 ms when the prologue ran element by element between branches, and
+    // 3.4 ms without a prologue.)
+    constexpr int LAS = (VEC == 4 && sizeof(XT) == 4) ? 8 : (VEC == 4 ? 6 : 3);
     using K = HubCfg<VEC, MODE, LAS, XT, SLAB>;
     if (n_rows_hub <= 0) return GNNX_OK;
     static std::atomic<uint64_t> done{0};
