@@ -1101,6 +1101,17 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     // and joined back into the caller's stream with events -- and hides under the row kernel (RMAT 1M / 10M, F = 128: a 0.49 ms hub
     // kernel beside a 0.45 ms streaming kernel); when it is bandwidth-bound the two would only share the same bytes per second.
     SideStream *side = nullptr;
+    struct JoinGuard {
+        SideStream *s = nullptr;
+        hipStream_t to = nullptr;
+        void arm(SideStream *s_, hipStream_t to_) { s = s_; to = to_; }
+        ~JoinGuard()
+        {
+            if (!s) return;
+            if (hipEventRecord(s->join, s->stream) == hipSuccess) (void)hipStreamWaitEvent(to, s->join, 0);
+            else (void)hipStreamSynchronize(s->stream);
+        }
+    } joiner;
     static const int side_env = [] { const char *e = experiment_env("GNNX_SPMM_SIDE"); return e ? atoi(e) : -1; }();   // A/B: 0 never, 1 always
     const bool beside = side_env < 0 ? a.hub_beside != 0 : side_env != 0;
     if (a.n_hub_rows > 0 && !beside) {
@@ -1112,8 +1123,10 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
         GNNX_HIP_CHECK(hipEventRecord(side->fork, st));
         GNNX_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
         const int rc = launch_hub<VEC>(mode, side->stream, a);
+        // from here on every exit path joins the side stream back into the caller's (JoinGuard): an error return must not leave
+        // work of this call running beside whatever the caller enqueues next
+        joiner.arm(side, st);
         if (rc != GNNX_OK) return rc;
-        GNNX_HIP_CHECK(hipEventRecord(side->join, side->stream));
     }
     if (stream) {
         if constexpr (G >= 8) {
@@ -1134,8 +1147,7 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
         launch_rows<G, VEC, U>(mode, grid, st, a);
     }
     GNNX_LAUNCH_CHECK();
-    if (side) GNNX_HIP_CHECK(hipStreamWaitEvent(st, side->join, 0));   // whatever follows on the caller's stream sees every row
-    return GNNX_OK;
+    return GNNX_OK;   // (the JoinGuard orders whatever follows on the caller's stream behind the hub kernel)
 }
 
 }  // namespace
