@@ -23,6 +23,18 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Scope guards for device temporaries: released on EVERY exit path of the enclosing scope (the GNNX_HIP_CHECK / GNNX_REQUIRE early
+// returns included).  DeviceFree: a hipMallocAsync allocation, freed in stream order; DeviceFreeSync: a hipMalloc allocation.
+struct DeviceFree {
+    void *p;
+    hipStream_t st;
+    ~DeviceFree() { if (p) (void)hipFreeAsync(p, st); }
+};
+struct DeviceFreeSync {
+    void *p = nullptr;
+    ~DeviceFreeSync() { if (p) (void)hipFree(p); }
+};
+
 // Measurement switches (kernel variants, forced tile shapes, ablation flags, the LDS-staged SpMM) exist only in an EXPERIMENTS
 // build (`make EXPERIMENTS=1`, scripts/exp_*.py); the shipped library has one code path per shape and reads no environment.
 #ifdef GNNX_EXPERIMENTS

@@ -1,6 +1,9 @@
 // Small HBM-bound ops on the GCN path: dbias column sum, unfused row-scale / bias / axpy, and the halo
 // pack / unpack (row gather, row scatter-add).  All are streaming kernels: 16 B per lane where alignment
 // allows, grid capped at 2048 workgroups with a grid-stride loop.
+#include <cmath>
+#include <vector>
+
 #include "gnnx_common.h"
 
 // Parity depends on separately rounded fp32 mul / add (the reference has no FMA): never contract.
@@ -168,6 +171,33 @@ __global__ __launch_bounds__(256) void pow_kernel(const float *x, int64_t n, flo
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         y[i] = e == -0.5f ? (float)(1.0 / sqrt((double)x[i])) : powf(x[i], e);
+}
+
+// info[0] = max over i of x[i] as an integer, info[1] = 1 when some x[i] is not a non-negative integer <= kPowTableMax
+constexpr int32_t kPowTableMax = 1 << 24;
+__global__ __launch_bounds__(256) void pow_scan_kernel(const float *x, int64_t n, int32_t *info)
+{
+    int32_t mx = 0, bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        if (!(v >= 0.f && v <= (float)kPowTableMax && v == truncf(v))) bad = 1;
+        else mx = (int32_t)v > mx ? (int32_t)v : mx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int32_t o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+        bad |= __shfl_xor(bad, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (mx > 0) atomicMax(&info[0], mx);
+        if (bad) atomicOr(&info[1], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void pow_table_kernel(const float *x, int64_t n, const float *table, float *y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = table[(int32_t)x[i]];
 }
 
 __global__ __launch_bounds__(256) void csr_rowsum_kernel(const int32_t *rowptr, const float *vals, int32_t n, float *out)
@@ -548,9 +578,37 @@ GNNX_API int gnnx_pow_f32(const float *d_x, int64_t n, float exponent, float *d_
     GNNX_REQUIRE(n >= 0, GNNX_ERR_INVALID_ARG, "negative size");
     if (n == 0) return GNNX_OK;
     GNNX_REQUIRE(d_x && d_y, GNNX_ERR_INVALID_ARG, "null pointer");
+    hipStream_t st = as_stream(stream);
     int64_t blocks = ceil_div(n, 256);
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-    hipLaunchKernelGGL(pow_kernel, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream), d_x, n, exponent, d_y);
+    // The reference evaluates std::pow on the HOST (functional.h:253), i.e. the host libm's powf, and the one call on the hot path is
+    // deg->pow(-0.5) on the degrees 1 + rowsum(A): non-negative integers.  For such an argument vector (every element an integer in
+    // [0, 2^24]) the result is looked up in a table of that very libm call, table[k] = powf((float)k, e) -- the reference's bits, where a
+    // device pow would be 1 ulp off for some k.  One reduction, one host synchronisation and max + 1 libm calls: a graph-build call,
+    // not a per-step one.  Any other argument vector is evaluated on the device (tolerance-level against the host libm).
+    int32_t *d_info = nullptr;
+    GNNX_HIP_CHECK(hipMallocAsync((void **)&d_info, 2 * sizeof(int32_t), st));
+    DeviceFree free_info{d_info, st};
+    GNNX_HIP_CHECK(hipMemsetAsync(d_info, 0, 2 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(pow_scan_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, d_info);
+    GNNX_LAUNCH_CHECK();
+    int32_t info[2] = {0, 1};
+    GNNX_HIP_CHECK(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    if (!info[1]) {
+        std::vector<float> table((size_t)info[0] + 1);
+        volatile float e = exponent;   // a run-time exponent: the call stays the libm's powf whatever the optimiser knows about it
+        for (int64_t k = 0; k <= info[0]; k++) table[(size_t)k] = powf((float)k, e);
+        float *d_table = nullptr;
+        GNNX_HIP_CHECK(hipMallocAsync((void **)&d_table, sizeof(float) * table.size(), st));
+        DeviceFree free_table{d_table, st};
+        GNNX_HIP_CHECK(hipMemcpyAsync(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(pow_table_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, d_table, d_y);
+        GNNX_LAUNCH_CHECK();
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // `table` is pageable host memory: read by the copy until here
+        return GNNX_OK;
+    }
+    hipLaunchKernelGGL(pow_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, exponent, d_y);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }

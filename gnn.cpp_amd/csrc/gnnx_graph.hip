@@ -9,7 +9,9 @@
 // rocPRIM radix sort of the keys (only the bits that can be set) -> head flags + exclusive scan ->
 // compact unique keys into colidx -> rowptr by per-row binary search on the sorted unique keys.
 // Integer work, HBM-bound, deterministic.  rocPRIM is used for the sort/scan primitives only.
+#include <cmath>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -80,15 +82,28 @@ __global__ void rowptr_kernel(const uint64_t *ukeys, int32_t nnz, int32_t n_node
     rowptr[r] = lo;
 }
 
-// s_i = (1 + deg_i)^(-1/2).  The reference calls libm powf(deg, -0.5f) (functional.h:253); this is the
-// correctly rounded value, which differs from glibc's powf by 1 ulp for 0.06 % of degrees, none below
-// 1058 (tests/test_oracle_vs_reference.py::test_pow_minus_half_vs_double_rsqrt).
-__global__ void deg_rsqrt_kernel(const int32_t *rowptr, int32_t n_rows, float *s)
+// s_i = (1 + deg_i)^(-1/2).  The reference calls the HOST libm's powf(deg, -0.5f) (functional.h:253, std::pow on a float) -- glibc's
+// powf is 1 ulp away from the correctly rounded value for 9 685 of the 2^24 degrees, the smallest 1058
+// (tests/test_oracle_vs_reference.py::test_pow_minus_half_vs_double_rsqrt) -- so s is LOOKED UP in a table of that very call,
+// evaluated on the host for 1 .. 1 + max degree by gnnx_degree_norm_f32 (a once-per-graph build call): s, norm and through them the
+// whole layer carry the reference's bits at every size, by default.
+__global__ void max_degree_kernel(const int32_t *rowptr, int32_t n_rows, int32_t *out)
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t d = i < n_rows ? rowptr[i + 1] - rowptr[i] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int32_t o = __shfl_xor(d, off, 64);
+        d = o > d ? o : d;
+    }
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(out, d);
+}
+
+__global__ void deg_pow_table_kernel(const int32_t *rowptr, int32_t n_rows, const float *table, float *s)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
-    float deg = __fadd_rn((float)(rowptr[i + 1] - rowptr[i]), 1.0f);
-    s[i] = (float)(1.0 / sqrt((double)deg));
+    s[i] = table[rowptr[i + 1] - rowptr[i] + 1];   // table[k] = powf((float)k, -0.5f)
 }
 
 // norm_i = fl(fl(sum_{j desc} s_j) * s_i), strictly sequential in the reference's matmul order (descending column)
@@ -471,8 +486,29 @@ GNNX_API int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_coli
     const int T = 256;
     dim3 grid((uint32_t)ceil_div(n_rows, T));
     if (d_s) {
-        hipLaunchKernelGGL(deg_rsqrt_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_s);
+        // table[k] = the host libm's powf((float)k, -0.5f) for k = 1 .. 1 + max degree: what the reference evaluates per vertex
+        // (functional.h:253).  One reduction + one host synchronisation + (1 + max degree) libm calls, once per graph.
+        int32_t *d_max = nullptr;
+        GNNX_HIP_CHECK(hipMallocAsync((void **)&d_max, sizeof(int32_t), st));
+        DeviceFree free_max{d_max, st};
+        GNNX_HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(max_degree_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_max);
         GNNX_LAUNCH_CHECK();
+        int32_t h_max = 0;
+        GNNX_HIP_CHECK(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));
+        GNNX_REQUIRE(h_max >= 0, GNNX_ERR_INVALID_ARG, "rowptr is not monotone");
+        std::vector<float> table((size_t)h_max + 2);
+        table[0] = 0.f;
+        volatile float expo = -0.5f;   // a run-time exponent: the call stays a libm powf call whatever the optimiser knows about -0.5
+        for (int64_t k = 1; k <= (int64_t)h_max + 1; k++) table[(size_t)k] = powf((float)k, expo);
+        float *d_table = nullptr;
+        GNNX_HIP_CHECK(hipMallocAsync((void **)&d_table, sizeof(float) * table.size(), st));
+        DeviceFree free_table{d_table, st};
+        GNNX_HIP_CHECK(hipMemcpyAsync(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(deg_pow_table_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_table, d_s);
+        GNNX_LAUNCH_CHECK();
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // `table` (pageable host memory) is read by the copy until here
     }
     if (d_norm) {
         if (!d_colidx) {  // only a graph without entries may come without colidx (once-per-graph call: the sync is fine)

@@ -1059,22 +1059,48 @@ void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a)
 
 // Side stream of the aggregation (hub kernel beside the row kernel): one per host thread and device, created on first use, with
 // the two events of the fork / join.  Per thread because a rank = one host thread = one stream (gnnx.h): two threads never share
-// the events.  Never destroyed before the process ends (the runtime reclaims it).
+// the events.  Released when the thread ends (a rank thread of an in-process group that exits leaves nothing behind).
 struct SideStream {
     hipStream_t stream = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-SideStream *side_stream()
+constexpr int kSideMaxDev = 64;
+struct SideStreamTable {
+    SideStream t[kSideMaxDev];
+    ~SideStreamTable()
+    {
+        for (SideStream &s : t) {
+            if (!s.stream) continue;
+            (void)hipStreamSynchronize(s.stream);
+            if (s.fork) (void)hipEventDestroy(s.fork);
+            if (s.join) (void)hipEventDestroy(s.join);
+            (void)hipStreamDestroy(s.stream);
+            s = SideStream{};
+        }
+    }
+};
+// the side stream lives on the device that owns the CALLER's stream (the current device for the null stream)
+SideStream *side_stream(hipStream_t caller)
 {
-    constexpr int kMaxDev = 64;
-    static thread_local SideStream table[kMaxDev];
+    static thread_local SideStreamTable table;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-    SideStream &s = table[dev];
+    if (caller == nullptr || hipStreamGetDevice(caller, &dev) != hipSuccess) {
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    }
+    if (dev < 0 || dev >= kSideMaxDev) return nullptr;
+    SideStream &s = table.t[dev];
     if (!s.stream) {
-        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+        if (cur != dev && hipSetDevice(dev) != hipSuccess) return nullptr;
+        const bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+        if (cur != dev) (void)hipSetDevice(cur);
+        if (!ok) {
+            if (s.fork) (void)hipEventDestroy(s.fork);
+            if (s.join) (void)hipEventDestroy(s.join);
+            if (s.stream) (void)hipStreamDestroy(s.stream);
             s = SideStream{};
             return nullptr;
         }
@@ -1118,7 +1144,7 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
         const int rc = launch_hub<VEC>(mode, st, a);
         if (rc != GNNX_OK) return rc;
     } else if (a.n_hub_rows > 0) {
-        side = side_stream();
+        side = side_stream(st);
         GNNX_REQUIRE(side, GNNX_ERR_HIP, "could not create the aggregation's side stream");
         GNNX_HIP_CHECK(hipEventRecord(side->fork, st));
         GNNX_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
@@ -1152,17 +1178,9 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
 
 }  // namespace
 
-GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int32_t chunk, int32_t max_feat,
-                                   gnnx_spmm_plan **plan_out, void *stream)
+namespace {
+int plan_build(gnnx_spmm_plan *plan, const int32_t *d_rowptr, int32_t n_rows, int32_t chunk, hipStream_t st)
 {
-    GNNX_REQUIRE(d_rowptr && plan_out, GNNX_ERR_INVALID_ARG, "null pointer");
-    GNNX_REQUIRE(n_rows >= 0 && chunk > 0 && max_feat > 0, GNNX_ERR_INVALID_ARG, "n_rows/chunk/max_feat");
-    (void)max_feat;  // a plan holds no per-feature storage any more (kept in the signature: callers size nothing by it)
-    hipStream_t st = as_stream(stream);
-    auto *plan = new gnnx_spmm_plan();
-    plan->n_rows = n_rows;
-    plan->chunk = chunk;
-    *plan_out = plan;
     GNNX_HIP_CHECK(hipMalloc(&plan->d_counters, 4 * sizeof(unsigned long long)));
     GNNX_HIP_CHECK(hipMemsetAsync(plan->d_counters, 0, 4 * sizeof(unsigned long long), st));
     if (n_rows == 0) return GNNX_OK;
@@ -1177,14 +1195,14 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
     if (plan->n_split_rows > 0) {
         // work list of spmm_hub_kernel: the hub rows, longest first (ties by row id: the list does not depend on the order the
         // atomics handed out positions)
-        int2 *d_list = nullptr;
-        GNNX_HIP_CHECK(hipMalloc(&d_list, sizeof(int2) * (size_t)plan->n_split_rows));
+        DeviceFreeSync list;   // every temporary below is released on every exit path
+        GNNX_HIP_CHECK(hipMalloc(&list.p, sizeof(int2) * (size_t)plan->n_split_rows));
+        int2 *d_list = static_cast<int2 *>(list.p);
         hipLaunchKernelGGL(plan_fill_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, chunk, plan->d_counters, d_list);
         GNNX_LAUNCH_CHECK();
         std::vector<int2> h_rows((size_t)plan->n_split_rows);
         GNNX_HIP_CHECK(hipMemcpyAsync(h_rows.data(), d_list, sizeof(int2) * h_rows.size(), hipMemcpyDeviceToHost, st));
         GNNX_HIP_CHECK(hipStreamSynchronize(st));
-        (void)hipFree(d_list);
         std::sort(h_rows.begin(), h_rows.end(), [](const int2 &x, const int2 &y) { return x.y != y.y ? x.y > y.y : x.x < y.x; });
         std::vector<int32_t> h_hub(h_rows.size());
         for (size_t i = 0; i < h_rows.size(); i++) h_hub[i] = h_rows[i].x;
@@ -1197,17 +1215,17 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
     {
         static const int env_bn = [] { const char *v = experiment_env("GNNX_SPMM_BLOCK_NNZ"); return v ? atoi(v) : 0; }();
         plan->block_nnz = env_bn > 0 ? env_bn : (chunk < 256 ? chunk : 256);
-        int32_t *flag = nullptr, *pos = nullptr;
-        void *tmp = nullptr;
+        DeviceFreeSync flag_g, pos_g, tmp_g;
         size_t tmp_bytes = 0;
         GNNX_HIP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, (int32_t *)nullptr, (int32_t *)nullptr, 0, (size_t)n_rows,
                                                rocprim::plus<int32_t>()));
-        GNNX_HIP_CHECK(hipMalloc(&flag, sizeof(int32_t) * (size_t)n_rows));
-        GNNX_HIP_CHECK(hipMalloc(&pos, sizeof(int32_t) * (size_t)n_rows));
-        GNNX_HIP_CHECK(hipMalloc(&tmp, tmp_bytes > 0 ? tmp_bytes : 4));
+        GNNX_HIP_CHECK(hipMalloc(&flag_g.p, sizeof(int32_t) * (size_t)n_rows));
+        GNNX_HIP_CHECK(hipMalloc(&pos_g.p, sizeof(int32_t) * (size_t)n_rows));
+        GNNX_HIP_CHECK(hipMalloc(&tmp_g.p, tmp_bytes > 0 ? tmp_bytes : 4));
+        int32_t *flag = static_cast<int32_t *>(flag_g.p), *pos = static_cast<int32_t *>(pos_g.p);
         hipLaunchKernelGGL(plan_block_flags_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, plan->block_nnz, flag);
         GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, flag, pos, 0, (size_t)n_rows, rocprim::plus<int32_t>(), st));
+        GNNX_HIP_CHECK(rocprim::exclusive_scan(tmp_g.p, tmp_bytes, flag, pos, 0, (size_t)n_rows, rocprim::plus<int32_t>(), st));
         int32_t last[2];
         GNNX_HIP_CHECK(hipMemcpyAsync(&last[0], pos + (n_rows - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
         GNNX_HIP_CHECK(hipMemcpyAsync(&last[1], flag + (n_rows - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1217,11 +1235,29 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
         hipLaunchKernelGGL(plan_block_fill_kernel, grid, dim3(256), 0, st, flag, pos, n_rows, plan->n_blocks,
                            plan->d_block_starts);
         GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(hipStreamSynchronize(st));
-        (void)hipFree(flag);
-        (void)hipFree(pos);
-        (void)hipFree(tmp);
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // the temporaries are freed (hipFree) when this scope ends: the kernels are done
     }
+    return GNNX_OK;
+}
+}  // namespace
+
+GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int32_t chunk, int32_t max_feat,
+                                   gnnx_spmm_plan **plan_out, void *stream)
+{
+    GNNX_REQUIRE(d_rowptr && plan_out, GNNX_ERR_INVALID_ARG, "null pointer");
+    *plan_out = nullptr;
+    GNNX_REQUIRE(n_rows >= 0 && chunk > 0 && max_feat > 0, GNNX_ERR_INVALID_ARG, "n_rows/chunk/max_feat");
+    (void)max_feat;  // a plan holds no per-feature storage any more (kept in the signature: callers size nothing by it)
+    auto *plan = new gnnx_spmm_plan();
+    plan->n_rows = n_rows;
+    plan->chunk = chunk;
+    const int rc = plan_build(plan, d_rowptr, n_rows, chunk, as_stream(stream));
+    if (rc != GNNX_OK) {   // nothing half-built reaches the caller
+        (void)hipStreamSynchronize(as_stream(stream));
+        (void)gnnx_spmm_plan_destroy(plan);
+        return rc;
+    }
+    *plan_out = plan;
     return GNNX_OK;
 }
 
@@ -1263,6 +1299,20 @@ int64_t bn_sums_stream_waves(int32_t n_rows, int32_t n_feat, const gnnx_spmm_pla
     const int G = n_feat / 4 > 32 ? 64 : 32, groups = 64 / G, R = G / 2;
     const int64_t n_blk = plan && plan->d_block_starts ? plan->n_blocks : ceil_div(n_rows, R);
     return ceil_div(ceil_div(n_blk, kBnSumsBlocksPerWave), groups) * groups;
+}
+
+// Hub kernel beside the row kernel (side stream) or in front of it (same stream)?  Beside, when its time is the dependent-add chain
+// of its LONGEST row rather than its bytes: the two measured constants of the hub kernel, in one place.
+//   chain: kHubNsPerNeighbour per non-zero of the longest row (one accumulator per feature, the reference's order);
+//   bytes: hub non-zeros x row bytes at kHubBytesPerNs.
+// RMAT 1M / 10M, F = 128: beside (0.92 -> 0.79 ms); RMAT 10M / 100M, F = 256 (28 GB of hub rows): in front (13.59 vs 13.76 ms beside).
+constexpr double kHubNsPerNeighbour = 12.0;   // profiles/r03: 0.75 ms for the 62 k-entry longest row of RMAT 1M / 10M
+constexpr double kHubBytesPerNs = 7000.0;     // ~7 TB/s on the hub rows of the headline graph
+bool hub_is_chain_bound(int32_t max_hub_degree, int64_t n_hub_nnz, int32_t n_feat, int bytes_per_feature)
+{
+    const double chain_ns = (double)max_hub_degree * kHubNsPerNeighbour;
+    const double bytes_ns = (double)n_hub_nnz * (double)n_feat * bytes_per_feature / kHubBytesPerNs;
+    return chain_ns > bytes_ns;
 }
 
 int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr, const int32_t *d_colidx, const float *d_vals,
@@ -1334,13 +1384,20 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         // Hub kernel beside the row kernel (side stream) or in front of it (same stream)?  Beside, when its time is the dependent-add
         // chain of its longest row (~12 ns per neighbour) rather than its bytes (hub non-zeros x row bytes at ~7 TB/s):
         // RMAT 1M / 10M, F = 128: 0.92 -> 0.79 ms; RMAT 10M / 100M, F = 256 (28 GB of hub rows): in front, 13.59 vs 13.76 ms beside.
-        a.hub_beside = (int64_t)plan->max_hub_degree * 20000 > plan->n_hub_nnz * (int64_t)n_feat;
+        a.hub_beside = hub_is_chain_bound(plan->max_hub_degree, plan->n_hub_nnz, n_feat, x_bf16 ? 2 : 4);
     }
     hipStream_t st = as_stream(stream);
     auto aligned16 = [](const void *p) { return !p || (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     const bool vec4 = (n_feat % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (x_bf16 ? (reinterpret_cast<uintptr_t>(d_X) & 7u) == 0 : aligned16(d_X)) && aligned16(d_Y) &&
                       aligned16(d_bias) && aligned16(a.pro_mean) && aligned16(a.pro_var) && aligned16(a.pro_gamma) &&
                       aligned16(a.pro_beta);
+    if (x_bf16 && !vec4) {
+        // bf16 rows that are not 8-byte pieces (n_feat % 4 != 0 or an unaligned X): LDS-DMA moves one DWORD per lane whatever the
+        // load size, so a 2-byte-per-lane ring layout does not exist -- the hub rows stay with the row / streaming kernel (same bits)
+        a.split_threshold = 0;
+        a.hub_rows = nullptr;
+        a.n_hub_rows = 0;
+    }
     if (vec4) {
         int lanes = n_feat / 4;
         if (lanes > 32) return launch_mode<64, 4, 8>(a, plan, pro, st);

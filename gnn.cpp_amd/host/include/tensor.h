@@ -136,7 +136,7 @@ struct Store {
     }
     void ensure_dev_alloc()
     {
-        if (!dev && n) dev = dev_alloc((n + tail) * sizeof(T));
+        if (!dev && n + tail) dev = dev_alloc((n + tail) * sizeof(T));   // n == 0 with a reserved tail (a rank without local rows) still allocates
     }
     // device pointer, valid contents
     T *d()

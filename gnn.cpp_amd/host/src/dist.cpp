@@ -144,7 +144,7 @@ void Partition::ensure_spmm_plans(int32_t n_feat)
 {
     constexpr int32_t kChunk = 1024;  // rows longer than this go to the sequential hub kernel
     for (Side *s : {&fwd, &bwd}) {
-        if (s->spmm_plan && s->spmm_plan_feat >= n_feat) continue;
+        if (s->spmm_plan) continue;   // a plan does not depend on the feature width
         if (s->spmm_plan) gnnx_spmm_plan_destroy(s->spmm_plan);
         s->spmm_plan = nullptr;
         gx(gnnx_spmm_plan_create((const int32_t *)s->rowptr, (int32_t)_n_local, kChunk, n_feat, &s->spmm_plan, current_stream()), "plan");

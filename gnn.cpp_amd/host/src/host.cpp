@@ -125,7 +125,7 @@ void Csr::drop_plans()
 
 void Csr::ensure_plans(int32_t n_feat)
 {
-    if (plan && plan_feat >= n_feat) return;
+    if (plan) return;   // a plan does not depend on the feature width (gnnx_spmm_plan_create ignores max_feat)
     drop_plans();
     ensure_transpose();
     constexpr int32_t kChunk = 1024;  // rows longer than this go to the sequential hub kernel

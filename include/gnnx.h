@@ -131,10 +131,10 @@ int gnnx_csr_from_coo_weighted(const int32_t *d_src, const int32_t *d_dst, const
  * d_s and d_norm: n_rows fp32 each (the reference's [N,1] tensors).  Either may be NULL.
  * For a row block of a sharded graph pass d_s_cols (the s values indexed by COLUMN id, i.e. [local|halo])
  * and d_s is written for the block's own rows only; with d_s_cols == NULL columns index d_s itself.
- * s written here is the CORRECTLY ROUNDED (1 + deg)^-1/2; the reference's libm powf is 1 ulp off for 9 685 of the 2^24 degrees,
- * the smallest 1058.  A caller that wants the reference's very bits at any size passes its own s (d_s == NULL, d_s_cols = s_i looked
- * up in a table of its host libm's powf(k, -0.5f): functional.h:253 is that call) -- ops.CsrGraph.norm_from_pow_table does; norm
- * and both aggregations of the 10 M / 100 M graph are then bit-exact end to end (test_headline_config_whole_graph_vs_oracle).
+ * s written here is LOOKED UP in a table of the host libm's powf(k, -0.5f), k = 1 .. 1 + max degree -- functional.h:253 is that call,
+ * and glibc's powf is 1 ulp away from the correctly rounded value for 9 685 of the 2^24 degrees (the smallest 1058) -- so s, norm and
+ * both aggregations carry the reference's bits at every size (test_headline_config_whole_graph_vs_oracle).  Writing d_s costs one
+ * host synchronisation (the maximum degree); a caller may still pass its own s through d_s_cols with d_s == NULL.
  */
 int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_colidx, int32_t n_rows, float *d_s,
                          const float *d_s_cols, float *d_norm, void *stream);
@@ -316,8 +316,10 @@ int gnnx_rowsum_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_col
 
 /* Elementwise helpers behind the tensor API mirror (gnn.cpp_amd/host/):
  *   fill      : x[i] = value                                   (tensor(dims, value) ctor, reference tensor.h:106)
- *   pow       : y[i] = pow(x[i], e); e == -0.5 is the correctly rounded 1/sqrt (the GCN degree scaling,
- *               reference graph.cpp:183 -> functional.h:253), other exponents use powf
+ *   pow       : y[i] = pow(x[i], e).  The reference's pow is the HOST libm's powf (functional.h:253) and its one use on the path is
+ *               deg->pow(-0.5) on the degrees (graph.cpp:183): when every x[i] is an integer in [0, 2^24] the result is looked up in a
+ *               table of that libm call (table[k] = powf(k, e), built on the host: one synchronisation, a graph-build call) -- the
+ *               reference's bits; any other argument vector is evaluated on the device (e == -0.5: correctly rounded 1/sqrt)
  *   csr_rowsum: out[i] = sum_j A_ij = rowptr[i+1]-rowptr[i] (vals == NULL) -- adj_mat->sum(-1,true), reference
  *               graph.cpp:178 -> functional.h:267-296, without the dense N x N matrix
  *   transpose : Y[c,r] = X[r,c]  (materialises a 2-D transpose only when a caller insists on the data;
