@@ -78,6 +78,7 @@ def profiled_traffic(workload, kernel_patterns):
             names.append(hits[0])
         else:
             best = (total, {"file": os.path.relpath(f, ROOT), "kernels": names, "git_head_of_profiled_build": d.get("git_head"),
+                            "spmm_source_sha256_of_profiled_build": d.get("spmm_source_sha256"),
                             "profiled_nnz": d.get("nnz"), "file_mtime": time.strftime("%Y-%m-%d %H:%M:%S", time.gmtime(os.path.getmtime(f)))})
     return best
 
@@ -216,9 +217,10 @@ def main():
                          "memory over a CPU process group, so that the whole multi-process job can run on a box with one GPU")
     ap.add_argument("--all-ranks-on-device0", action="store_true",
                     help="rehearsal: every rank uses GPU 0 (needs --dist-backend gloo; RCCL refuses two ranks on one device)")
-    ap.add_argument("--cpu-sample-nodes", type=int, default=2_500_000,
-                    help="nodes of the bounded CPU-baseline sample (same generator and average degree): about 12 s on all host "
-                         "threads + about 10 s for the single-thread leg on a tenth of it")
+    ap.add_argument("--cpu-sample-nodes", type=int, default=0,
+                    help="0 (default): the CPU baseline runs the bench's OWN workload -- graph, features and gradient copied from the "
+                         "device -- on all host threads (about 35 s at 10 M / 100 M / 256 on 128 threads); > 0: a sample of that many "
+                         "nodes from the same generator (same average degree).  The single-thread leg always runs on 1/40 of the nodes")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -359,7 +361,7 @@ def main():
                                                        / HBM_PEAK_GBS)
     cpu = cpu_ref = cpp = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(pkg, args, F, abc, seed)
+        cpu = cpu_baseline(pkg, args, F, abc, seed, runner=runner)
         cpu_ref = cpu_reference(pkg)
     if (rank == 0 and world == 1 and not args.force_sharded and not args.train_layers and not args.no_cpp_api and abc is not None
             and abc == (0.57, 0.19, 0.19)):
@@ -568,14 +570,17 @@ class SingleGpu:
     def roofline(self, ceilings=None):
         """The contract's roofline object for the dominant kernel pair: the forward aggregation = spmm_hub_kernel (hub rows) +
         spmm_stream_kernel (all other rows), timed together by one pair of HIP events on the launch stream.
-          achieved = bytes that leave L2 towards the fabric per aggregation (PMC: 2 FETCH_SIZE + WRITE_SIZE of both kernels, from
-                     the committed rocprofv3 passes of this bench command: `traffic`) / the HIP-event time of THIS run;
-          peak     = fabric_gather_ceiling measured in THIS run (bench_kernels/ceilings.hip): the same kind of bytes -- whole 1-KiB
-                     rows picked at random from a table that sits in the 256 MiB Infinity Cache, summed 8 to a streamed output row.
-        The neighbour rows of a power-law graph come partly from the Infinity Cache (62 % of the edges of the bench graph point at
-        168 MB of hub rows) and partly from HBM, so the bound that binds is the fabric behind L2, not the HBM pins: ALGORITHMIC
-        bytes / time (`effective_GBps`, one feature row per non-zero: SURVEY.md 8(d)) exceeds the 8 TB/s HBM peak and is therefore
-        reported beside the fraction, not as the fraction."""
+          peak     = 8000 GB/s, the HBM3E spec (MI355X_MICROARCH.md) -- a fixed hardware figure, never a self-measured one;
+          achieved = bytes that leave L2 per aggregation (PMC: 2 FETCH_SIZE + WRITE_SIZE of both kernels = `traffic`, taken FROM THE
+                     COMMITTED rocprofv3 passes of this bench command -- `traffic_from_committed_profile` names the file, and the file
+                     is refused when gnnx_spmm.hip has changed since it was made) / the HIP-event time of THIS run; without such a
+                     profile: the algorithmic bytes (SURVEY.md 8(d): one feature row per non-zero) / that time;
+          frac     = achieved / peak; `frac_algorithmic_vs_hbm_spec` = algorithmic bytes / time / 8000 beside it.
+        Both readings are in the record because they differ for a power-law graph: 62 % of the edges of the bench graph point at
+        168 MB of hub rows that live in the 256 MiB Infinity Cache, FETCH_SIZE counts Infinity-Cache hits, and the algorithmic count
+        charges L2 hits as HBM reads -- so the algorithmic reading exceeds 1 and the traffic reading is a fraction of what the
+        FABRIC behind L2 moved, not of the HBM pins alone.  `frac_traffic_vs_fabric_gather_ceiling` holds the same traffic against the
+        whole-row gather ceiling measured in this run (bench_kernels/ceilings.hip), for context only."""
         ms = self.kernel_times()["spmm_fwd"]
         B = spmm_bytes(self.n, self.n, self.g.nnz, self.F, bias=True)
         if getattr(self, "bf16_features", False):
@@ -584,25 +589,32 @@ class SingleGpu:
         tr = None
         if not getattr(self, "bf16_features", False) and not getattr(self, "sym", False):
             tr = profiled_traffic(self.workload, [r"^spmm_hub_kernel<\d+, 0, ", r"^spmm_(stream_)?kernel<\d+, \d+, \d+, 0, "])
+        stale = None
         if tr and tr[1].get("profiled_nnz") not in (None, self.g.nnz):
-            tr = None  # a profile of another graph
-        peak = ceilings["fabric_gather_GBps"] if ceilings else HBM_PEAK_GBS
+            tr, stale = None, "the committed profile is of another graph"
+        if tr:
+            import hashlib
+            cur = hashlib.sha256(open(os.path.join(ROOT, "gnn.cpp_amd", "csrc", "gnnx_spmm.hip"), "rb").read()).hexdigest()
+            was = tr[1].get("spmm_source_sha256_of_profiled_build")
+            if was is not None and was != cur:
+                tr, stale = None, "gnnx_spmm.hip has changed since the committed profile was made"
         achieved = (tr[0] if tr else B) / (ms * 1e-3) / 1e9
         evs = [st[self.names.index("spmm_fwd")] for st in self.ev]
         r = {"bound": "hbm", "bound_detail": "memory system behind L2 (Infinity Cache + HBM): whole-row gather",
              "kernel": "forward aggregation = spmm_hub_kernel<VEC, 0, LAS, float> + spmm_stream_kernel<G, VEC, 8, 0, 64, float>",
-             "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-             "achieved_is": ("traffic / avg_launch_ms" if tr else "algorithmic_bytes_per_launch / avg_launch_ms (no PMC profile of this workload "
-                             "and graph is committed)"),
-             "peak_is": ("fabric_gather_ceiling measured in this run" if ceilings else "HBM spec (no in-run ceiling: N > 1 or --no-ceilings)"),
-             "traffic": tr[0] if tr else None, "traffic_source": tr[1] if tr else None,
+             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "achieved_is": ("traffic / avg_launch_ms" if tr else "algorithmic_bytes_per_launch / avg_launch_ms (no usable PMC profile of this "
+                             "workload, graph and kernel source is committed" + (": " + stale if stale else "") + ")"),
+             "peak_is": "HBM3E spec, 8000 GB/s (MI355X_MICROARCH.md)",
+             "traffic": tr[0] if tr else None, "traffic_from_committed_profile": tr[1] if tr else None,
              "avg_launch_ms": ms, "median_launch_ms": float(np.median([a.elapsed_ms(b) for a, b in evs])) if evs else None,
              "algorithmic_bytes_per_launch": B, "bytes_per_edge": B / max(1, self.g.nnz), "effective_GBps": eff,
-             "effective_over_hbm_spec_8000": eff / HBM_PEAK_GBS,
+             "frac_algorithmic_vs_hbm_spec": eff / HBM_PEAK_GBS,
              # the cache-perfect lower bound (every feature row read once) beside the gather figure
              "cache_perfect_bytes": 4 * (self.n + 1) + 4 * self.g.nnz + 4 * self.n + 8 * self.F * self.n,
              "ceilings": ceilings, "vertex_order": self.vertex_order}
         if ceilings:
+            r["frac_traffic_vs_fabric_gather_ceiling"] = achieved / ceilings["fabric_gather_GBps"] if tr else None
             r["traffic_over_hbm_copy_ceiling"] = achieved / ceilings["hbm_copy_GBps"] if tr else None
         return r
 
@@ -689,14 +701,26 @@ def cpp_api_bench(n, e, F, seed, both_orders=True, steps=5):
     return out
 
 
-def cpu_baseline(pkg, args, F, abc, seed):
-    """The CPU oracle (port of the reference arithmetic) on bounded samples of the same workload: same generator, same
-    average degree and feature width, fewer nodes.  Two legs: OpenMP over rows on every host thread
-    (the reported `value`), and one thread -- the reference itself is single-threaded -- on a 10x smaller sample."""
+def cpu_baseline(pkg, args, F, abc, seed, runner=None):
+    """The CPU oracle (port of the reference arithmetic) timed on this box's host cores.  Two legs:
+      * OpenMP over rows on every host thread (the reported `value`) on the bench's OWN workload -- the very graph (CSR of A and
+        A^T, norm), features and upstream gradient of the GPU run, copied from the device (--cpu-sample-nodes 0, the default; about
+        35 s at 10 M / 100 M / 256 on 128 threads), or on a smaller sample of the same generator when --cpu-sample-nodes says so;
+      * one thread -- the reference itself is single-threaded -- on a sample 40x smaller."""
     import oracle  # checker / reported baseline only
     wl_n, wl_e = WORKLOADS[args.workload][:2]
 
-    def leg(n, threads):
+    def timed_layer(rp, ci, rT, cT, norm, X, W, bias, G, threads):
+        oracle.set_threads(threads)
+        t0 = time.perf_counter()
+        H = oracle.linear_fwd(X, W)
+        oracle.aggregate_fwd(rp, ci, H, norm, bias)
+        oracle.colsum(G)
+        dH = oracle.aggregate_bwd(rT, cT, G, norm)
+        oracle.linear_bwd(dH, X, W)
+        return time.perf_counter() - t0
+
+    def sample_leg(n, threads):
         e = int(round(wl_e * (n / wl_n)))
         if abc is None:
             src, dst = pkg.synth.uniform_edges(seed, n, e)
@@ -710,24 +734,29 @@ def cpu_baseline(pkg, args, F, abc, seed):
         rp, ci = oracle.coo_to_csr(src, dst, n)
         rT, cT = oracle.csr_transpose(rp, ci, n)
         s, norm = oracle.degree_norm(rp, ci, n)
-        oracle.set_threads(threads)
-        t0 = time.perf_counter()
-        H = oracle.linear_fwd(X, W)
-        oracle.aggregate_fwd(rp, ci, H, norm, bias)
-        oracle.colsum(G)
-        dH = oracle.aggregate_bwd(rT, cT, G, norm)
-        oracle.linear_bwd(dH, X, W)
-        dt = time.perf_counter() - t0
-        return n, e, len(ci), dt
+        return n, e, len(ci), timed_layer(rp, ci, rT, cT, norm, X, W, bias, G, threads)
 
     cores = oracle.max_threads()
-    n, e, nnz, dt = leg(min(args.cpu_sample_nodes, wl_n), cores)
-    n1, e1, nnz1, dt1 = leg(max(1, min(args.cpu_sample_nodes, wl_n) // 10), 1)
+    full = args.cpu_sample_nodes <= 0 or args.cpu_sample_nodes >= wl_n
+    if full and isinstance(runner, SingleGpu):
+        # the GPU run's own inputs: nothing is regenerated, the host sees the graph in the bench's row order
+        g = runner.g
+        h = lambda t: t.detach().cpu().numpy()  # noqa: E731
+        rp, ci = h(g.rowptr).astype(np.int64), h(g.colidx)
+        rT, cT = h(g.rowptr_t).astype(np.int64), h(g.colidx_t)
+        X, G = np.ascontiguousarray(h(runner.X)), np.ascontiguousarray(h(runner.G))
+        dt = timed_layer(rp, ci, rT, cT, h(g.norm), X, np.ascontiguousarray(h(runner.W)), h(runner.bias), G, cores)
+        n, e, nnz = runner.n, wl_e, int(g.nnz)
+        what = f"{args.workload}: the bench's own graph and inputs (copied from the device), {n} nodes / nnz {nnz}"
+        del rp, ci, rT, cT, X, G
+    else:
+        n, e, nnz, dt = sample_leg(min(max(args.cpu_sample_nodes, 1), wl_n) if not full else wl_n, cores)
+        what = f"{args.workload} scaled to {n} nodes / {e} generated edges (nnz {nnz})" if n < wl_n else f"{args.workload}, regenerated on the host (nnz {nnz})"
+    n1, e1, nnz1, dt1 = sample_leg(max(1, wl_n // 40), 1)
     oracle.set_threads(cores)
     return {"value": nnz / dt, "unit": "edges/s", "cores": cores, "kind": "port",
-            "sample": f"{args.workload} scaled to {n} nodes / {e} generated edges (nnz {nnz}), {F} features, "
-                      f"one layer fwd+bwd in {dt:.2f} s, OpenMP over rows on {cores} threads",
-            "seconds": dt,
+            "sample": f"{what}, {F} features, one layer fwd+bwd in {dt:.2f} s, OpenMP over rows on {cores} threads",
+            "seconds": dt, "full_workload": bool(n >= wl_n),
             "single_thread": {"value": nnz1 / dt1, "unit": "edges/s", "cores": 1,
                               "sample": f"{n1} nodes / {e1} generated edges (nnz {nnz1}), {F} features, {dt1:.2f} s"}}
 

@@ -21,6 +21,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def file_sha256(path):
+    import hashlib
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
@@ -95,7 +100,8 @@ def main():
         json.dump({"workload": os.environ.get("WORKLOAD", "rmat10m_100m_f256"),
                    # provenance bench.py prints beside `traffic` so that a stale file shows: the commit the profiled build was made
                    # from (the GPU box has no .git: the caller passes it) and the graph's non-zeros as the profiled bench reported them
-                   "git_head": os.environ.get("GIT_HEAD"), "nnz": int(os.environ["PROFILED_NNZ"]) if os.environ.get("PROFILED_NNZ") else None,
+                   "git_head": os.environ.get("GIT_HEAD"), "spmm_source_sha256": file_sha256(os.path.join(ROOT, "gnn.cpp_amd", "csrc", "gnnx_spmm.hip")),
+                   "nnz": int(os.environ["PROFILED_NNZ"]) if os.environ.get("PROFILED_NNZ") else None,
                    "command": os.environ.get("PROFILE_CMD", "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"),
                    "note": "per launch; hbm_bytes_corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
                            "MI355X_MICROARCH.md section HBM; calibrate on colsum_stage1 = 4*N*F bytes read once)",
