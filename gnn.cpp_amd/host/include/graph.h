@@ -112,8 +112,10 @@ public:
     float _dropout;
 
 private:
-    size_t _cache_edges = 0, _cache_nodes = 0;
-    cyg::tptr<float> _cache_adj, _cache_norm;  // _cache_adj's Csr keeps the COO it was built from: the cache key (content)
+    // key of the static-graph cache: (storage id, content version) of the edge_index tensor's device copy + the node count
+    size_t _cache_nodes = 0;
+    uint64_t _cache_ei_id = 0, _cache_ei_version = 0;
+    cyg::tptr<float> _cache_adj, _cache_norm;
     std::shared_ptr<Partition> _part;
     cyg::tptr<float> forward_sharded(const cyg::tptr<float> &x_local);
 };

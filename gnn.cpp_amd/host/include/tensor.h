@@ -30,6 +30,7 @@
 #include <tuple>
 #include <typeinfo>
 #include <unordered_map>
+#include <atomic>
 #include <valarray>
 #include <vector>
 
@@ -98,6 +99,12 @@ struct BnStatsRequest {
     }
 };
 
+inline uint64_t next_store_id()
+{
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
+}
+
 template <class T>
 struct Store {
     size_t n = 0;
@@ -105,6 +112,13 @@ struct Store {
     std::valarray<T> *host = nullptr;
     void *dev = nullptr;
     bool host_ok = false, dev_ok = false;
+    // identity of the CONTENT of the device copy: `id` is unique per Store for the life of the process (never an address, so a new
+    // tensor allocated where a freed one lived is a different id), `version` moves whenever the device copy is (re)written -- an
+    // upload after the host side was handed out for writing (data()), a kernel output (d_out), an adopted array.  A consumer that
+    // caches something derived from a tensor (GCNConv's static-graph cache) keys it on (id, version): no device pass, no host
+    // synchronisation per call.
+    uint64_t id = next_store_id();
+    uint64_t version = 0;
 
     explicit Store(size_t n_) : n(n_) {}
     Store(const Store &) = delete;
@@ -120,6 +134,7 @@ struct Store {
         host = h;
         host_ok = true;
         dev_ok = false;
+        version++;
     }
     // host view, valid contents
     std::valarray<T> *h()
@@ -147,6 +162,7 @@ struct Store {
             if (host_ok && n) gx(gnnx_memcpy_h2d(dev, &(*host)[0], n * sizeof(T), current_stream()), "upload");
             else if (n) gx(gnnx_memset(dev, 0, n * sizeof(T), current_stream()), "memset");
             dev_ok = true;
+            version++;
         }
         return static_cast<T *>(dev);
     }
@@ -156,6 +172,7 @@ struct Store {
         ensure_dev_alloc();
         dev_ok = true;
         host_ok = false;
+        version++;
         return static_cast<T *>(dev);
     }
     void host_written()
@@ -379,6 +396,9 @@ public:
         return _st->d();
     }
     T *device_out() { return _st->d_out(); }
+    // (id, version) of the device copy's content (detail::Store): call after device_data(), which brings the copy up to date
+    uint64_t storage_id() const { return _st ? _st->id : 0; }
+    uint64_t storage_version() const { return _st ? _st->version : 0; }
     // valid device contents that a kernel is about to update in place (optimiser step)
     T *device_inplace()
     {

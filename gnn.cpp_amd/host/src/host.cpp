@@ -858,20 +858,16 @@ tptr<float> GCNConv::forward(Data &&input)
 {
     if (_part) return forward_sharded(input.x());  // this rank's rows of a partitioned graph (dist.h)
     if (fused) {
-        // static-graph cache: adjacency (dedupe + diagonal strip) and norm are built once per edge_index tensor
-        // The cache is keyed on the CONTENT of the edge list: the adjacency keeps the device copy of the COO it was built from,
-        // and every forward compares the incoming list with it (one coalesced pass over 2E ints, 0.1 ms at 100 M edges) --
-        // an edge_index edited in place, or a new one allocated at the address of a freed one, rebuilds (reference: rebuilt on
-        // every forward, graph.cpp:172-185).
+        // static-graph cache: adjacency (dedupe + diagonal strip) and norm are built once per edge list.  The key is the CONTENT
+        // identity of the edge_index tensor's device copy -- (storage id, content version), tensor.h detail::Store: the version moves
+        // when the list is uploaded again after the host side was handed out for writing (data()) or set_data() / a kernel rewrote
+        // it, the id is unique per storage (a new tensor at a freed one's address is another id) -- so a forward costs two integer
+        // compares: no pass over the list, no host synchronisation, capturable in a hipGraph.  (The reference rebuilds on every
+        // forward, graph.cpp:172-185.)
         tensor<int> *ei = input.edge_index();
-        bool hit = _cache_adj && _cache_edges == ei->numel() && _cache_nodes == input.num_nodes();
-        if (hit) {
-            auto c = _cache_adj->csr();
-            int same = 0;  // one pass over the [2, E] list, one host synchronisation (the answer decides a host-side branch)
-            detail::gx(gnnx_equal_i32(ei->device_data(), (const int32_t *)c->coo_src, (int64_t)ei->numel(), &same, detail::current_stream()),
-                       "graph cache");
-            hit = same != 0;
-        }
+        (void)ei->device_data();   // brings the device copy up to date (uploads, and bumps the version, if the host side was written)
+        const bool hit = _cache_adj && _cache_ei_id == ei->storage_id() && _cache_ei_version == ei->storage_version() &&
+                         _cache_nodes == input.num_nodes();
         if (!hit) {
             auto adj = edge_to_adj_mat(*ei, nullptr, input.num_nodes());
             adj->fill_diagonal_(0);  // == add_self_loops(..., fillValue 0): self loops removed (graph.cpp:172)
@@ -881,7 +877,8 @@ tptr<float> GCNConv::forward(Data &&input)
             norm *= deg;
             _cache_adj = adj;
             _cache_norm = norm;
-            _cache_edges = ei->numel();
+            _cache_ei_id = ei->storage_id();
+            _cache_ei_version = ei->storage_version();
             _cache_nodes = input.num_nodes();
         }
         tptr<float> out, st_mean, st_var;
