@@ -203,9 +203,16 @@ def main():
                          "communication stream of its own) instead of torch.distributed.  UNVERIFIED for more than one rank: no "
                          "multi-GPU node was available to the builder (one-rank communicator and the in-process transport are tested)")
     ap.add_argument("--force-sharded", action="store_true", help="run the N>1 code path even with one rank (rehearsal)")
-    ap.add_argument("--schedule", default="overlap", choices=["overlap", "sequential"],
-                    help="N>1: overlap = both halo exchanges asynchronous, each chain's compute under the other's exchange (same "
-                         "bits); sequential = GEMM -> exchange -> SpMM ... on one stream")
+    ap.add_argument("--schedule", default="overlap", choices=["overlap", "training", "sequential"],
+                    help="N>1: overlap (default) = the step as N = 1 defines it: X and the upstream gradient G are both INPUTS of the layer "
+                         "step, so the two chains are independent and each chain's compute runs under the other chain's halo exchange "
+                         "(same bits); training = the dependence of a real training step honoured (forward -> loss -> backward: nothing of "
+                         "the backward chain starts before the forward aggregation has finished): the transform runs in --exchange-chunks "
+                         "row chunks and every finished chunk's rows are sent while the next is multiplied, G's rows leave chunk by chunk, "
+                         "dbias runs under the exchange; sequential = GEMM -> exchange -> SpMM ... on one stream")
+    ap.add_argument("--exchange-chunks", type=int, default=0,
+                    help="N>1: row chunks of the pipelined halo exchange (chunk-major halo tail; 0 = 4 for --schedule training and for "
+                         "--train-layers, 1 otherwise)")
     ap.add_argument("--partition", default="deal", choices=["deal", "deal-ascending", "contiguous"],
                     help="N>1: deal = degree-sorted snake deal (equal rows / non-zeros / per-link volume); contiguous = ranges of "
                          "original ids balanced on degree (round 1)")
@@ -285,11 +292,12 @@ def main():
     elif args.train_layers > 0:
         shard = importlib.import_module("gnncpp_amd.shard")
         runner = shard.ShardedTrain(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, args.train_layers,
-                                    partition=args.partition)
+                                    partition=args.partition, n_chunks=args.exchange_chunks or 4)
     else:
         shard = importlib.import_module("gnncpp_amd.shard")
         runner = shard.ShardedBench(ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, args.chunk, native_comm=args.native_comm,
-                                    schedule=args.schedule, partition=args.partition, replicate_input_halo=args.replicate_input_halo)
+                                    schedule=args.schedule, partition=args.partition, replicate_input_halo=args.replicate_input_halo,
+                                    n_chunks=args.exchange_chunks or None)
     torch.cuda.synchronize()
     t_build = time.time() - t_build0
 
@@ -349,6 +357,7 @@ def main():
     roof_mfma = runner.mfma_roofline() if hasattr(runner, "mfma_roofline") else None
     kernels_ms = runner.kernel_times()
     nnz_one, Fp_run, order_run = runner.nnz_total, getattr(runner, "Fp", F), getattr(runner, "vertex_order", None)
+    runner_chunks = getattr(getattr(runner, "plan", None), "n_chunks", 1)
     # control for the vertex order (informational, outside the timed region above): the same runner on the as-generated labels
     order_control = None
     if (world == 1 and not args.force_sharded and not args.train_layers and relabel and graph is None and not args.no_order_control
@@ -392,6 +401,10 @@ def main():
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd of every parameter, SGD; no input gradient); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 and not args.force_sharded else
                        f"1-D vertex shard x{world} ({args.partition}), halo all-to-all-v, schedule {args.schedule}" +
+                       (" (X and G both inputs of the step, as at N = 1: each chain's compute under the other chain's exchange)"
+                        if args.schedule == "overlap" and not args.train_layers else "") +
+                       (f" (forward -> backward dependence honoured; exchanges pipelined in {runner_chunks} row chunks)"
+                        if (args.schedule == "training" or args.train_layers) else "") +
                        (", input halo replicated (first-layer form: one exchange per step)" if args.replicate_input_halo else "") +
                        (" -- REHEARSAL: gloo through host memory, all ranks on GPU 0: not a measurement" if args.dist_backend == "gloo" else ""),
                        "plan_chunk": args.chunk, "hip_graph": graph is not None, "mode": "SYM" if args.sym else "REF",

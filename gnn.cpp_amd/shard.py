@@ -117,38 +117,88 @@ def contiguous_partition(weight, world):
     return owner, nid, cuts
 
 
-class HaloSide:
-    """One direction of the exchange (forward: columns of A; backward: columns of A^T).  Column ids are NEW ids."""
+def chunk_bounds(n_rows, n_chunks):
+    """Row-chunk boundaries [n_chunks + 1] of a rank's local rows: chunk k = rows [(n k) // K, (n (k+1)) // K)."""
+    return [(int(n_rows) * k) // int(n_chunks) for k in range(int(n_chunks) + 1)]
 
-    def __init__(self, rowptr, colidx_nid, lo, hi, cuts):
+
+class HaloSide:
+    """One direction of the exchange (forward: columns of A; backward: columns of A^T).  Column ids are NEW ids.
+
+    n_chunks = K > 1 (the pipelined exchange of the "training" schedule): every rank's local rows are cut into K row chunks
+    (chunk_bounds), and both the halo tail of the receiver and the send buffer of the owner are laid out CHUNK-MAJOR --
+    [chunk 0: from rank 0, rank 1, ... | chunk 1: ...], inside a (chunk, owner) segment ascending id -- so that the rows of chunk k can
+    leave as soon as the producing GEMM has written chunk k: one all-to-all-v per chunk on contiguous segments of both buffers.  K = 1
+    is the plain owner-major layout (what the C-ABI plan builds).  The [local | halo] renumbering of the columns follows the tail
+    order; the order of a row's entries is untouched, so the bits are the same for every K."""
+
+    def __init__(self, rowptr, colidx_nid, lo, hi, cuts, n_chunks=1):
         dev = colidx_nid.device
+        P, K = len(cuts) - 1, int(n_chunks)
         self.n_local = hi - lo
+        self.n_chunks = K
         self.rowptr = rowptr
         remote = (colidx_nid < lo) | (colidx_nid >= hi)
-        halo = torch.unique(colidx_nid[remote])  # sorted ascending => grouped by owner
-        self.halo = halo
-        self.n_halo = int(halo.numel())
+        halo_sorted = torch.unique(colidx_nid[remote])  # sorted ascending => grouped by owner
+        self.halo_sorted = halo_sorted
+        self.n_halo = int(halo_sorted.numel())
+        # (owner, chunk at the owner) of every halo row: boundaries cuts[q] + chunk_bounds(n_q, K)[k], ascending over (q, k)
+        bnd = torch.tensor([cuts[q] + b for q in range(P) for b in chunk_bounds(cuts[q + 1] - cuts[q], K)[:-1]], dtype=torch.int64, device=dev)
+        j = torch.searchsorted(bnd, halo_sorted.to(torch.int64), right=True) - 1   # = owner * K + chunk
+        owner_h, chunk_h = j // K, j % K
+        order = torch.sort(chunk_h, stable=True).indices if K > 1 else torch.arange(self.n_halo, device=dev)
+        self.halo = halo_sorted[order]                     # tail order: chunk-major, owner, ascending id
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(self.n_halo, device=dev)
         col = colidx_nid.to(torch.int64)
         local_id = col - lo
-        halo_id = torch.searchsorted(halo.to(torch.int64), col) + self.n_local
+        pos_sorted = torch.searchsorted(halo_sorted.to(torch.int64), col).clamp_(max=max(self.n_halo - 1, 0))
+        halo_id = (inv[pos_sorted] if self.n_halo else pos_sorted) + self.n_local
         self.colidx = torch.where(remote, halo_id, local_id).to(torch.int32)  # entry order untouched
-        bounds = torch.tensor(cuts, dtype=halo.dtype, device=dev)
-        pos = torch.searchsorted(halo, bounds)  # halo[pos[q]:pos[q+1]] is owned by rank q
-        self.recv_counts = (pos[1:] - pos[:-1]).tolist()
-        self.send_counts = None
-        self.send_idx = None  # local row ids to pack, peer-major
+        cnt = torch.bincount(chunk_h * P + owner_h, minlength=K * P).reshape(K, P) if self.n_halo else torch.zeros((K, P), dtype=torch.int64)
+        self.recv_counts_k = [[int(v) for v in row] for row in cnt.tolist()]   # [chunk][owner]
+        self.recv_counts = [sum(self.recv_counts_k[k][q] for k in range(K)) for q in range(P)]   # owner totals (requests, statistics)
+        self.recv_off = [0]
+        for k in range(K):
+            self.recv_off.append(self.recv_off[-1] + sum(self.recv_counts_k[k]))
+        self.send_counts = None     # peer totals
+        self.send_counts_k = None   # [chunk][peer]
+        self.send_off = None
+        self.send_idx = None        # local row ids to pack, chunk-major then peer-major
 
     def exchange_requests(self, dist, cuts, rank, world):
         """Tell every owner which of its rows this rank reads; learn which of mine the peers read."""
         dev = self.halo.device
+        K = self.n_chunks
         rc = torch.tensor(self.recv_counts, dtype=torch.int64, device=dev)
         sc = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_to_all_single(sc, rc)
         self.send_counts = sc.tolist()
         want = torch.empty(int(sum(self.send_counts)), dtype=self.halo.dtype, device=dev)
-        dist.all_to_all_single(want, self.halo.contiguous(), self.send_counts, self.recv_counts)
-        self.send_idx = (want - cuts[rank]).to(torch.int32)
-        assert self.send_idx.numel() == 0 or (int(self.send_idx.min()) >= 0 and int(self.send_idx.max()) < self.n_local)
+        dist.all_to_all_single(want, self.halo_sorted.contiguous(), self.send_counts, self.recv_counts)   # owner-major, ascending id
+        rows = (want - cuts[rank]).to(torch.int32)
+        assert rows.numel() == 0 or (int(rows.min()) >= 0 and int(rows.max()) < self.n_local)
+        self.set_send_lists(rows, self.send_counts)
+
+    def set_send_lists(self, rows_peer_major, send_counts):
+        """rows_peer_major: my local rows every peer reads, peer-major, ascending inside a peer (what the requests deliver)."""
+        dev = rows_peer_major.device
+        K, P = self.n_chunks, len(send_counts)
+        self.send_counts = [int(c) for c in send_counts]
+        if K == 1:
+            self.send_idx = rows_peer_major
+            self.send_counts_k = [list(self.send_counts)]
+        else:
+            b = torch.tensor(chunk_bounds(self.n_local, K)[1:-1], dtype=torch.int64, device=dev)
+            chunk = torch.searchsorted(b, rows_peer_major.to(torch.int64), right=True)            # chunk of my own row
+            peer = torch.repeat_interleave(torch.arange(P, device=dev), torch.tensor(self.send_counts, device=dev))
+            order = torch.sort(chunk * P + peer, stable=True).indices                                # (chunk, peer), ascending row inside
+            self.send_idx = rows_peer_major[order].contiguous()
+            cnt = torch.bincount(chunk * P + peer, minlength=K * P).reshape(K, P)
+            self.send_counts_k = [[int(v) for v in row] for row in cnt.tolist()]
+        self.send_off = [0]
+        for k in range(K):
+            self.send_off.append(self.send_off[-1] + sum(self.send_counts_k[k]))
 
 
 class HostStagedDist:
@@ -202,26 +252,47 @@ class _Done:
         return True
 
 
-def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None, async_op=False):
+class _All:
+    """Handle of several exchanges: wait() waits for each."""
+
+    def __init__(self, hs):
+        self.hs = hs
+
+    def wait(self):
+        for h in self.hs:
+            h.wait()
+        return True
+
+
+def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None, async_op=False, chunk=None):
     """buf: [n_local + n_halo, F]; rows [:n_local] are this rank's; fills rows [n_local:] from the owners.
     pack(src_rows_view, idx, out) gathers rows (gnnx_gather_rows_f32 on GPU).
     native: a NativeComm => the all-to-all-v runs through the C-ABI (gnnx_halo_exchange_f32, RCCL send/recv group)
     instead of torch.distributed.all_to_all_single (the same RCCL underneath).
     async_op: return a handle at once; handle.wait() orders the CALLER's current stream behind the exchange (the
-    send buffer must then stay untouched until the wait).  Returns (send_buf, handle)."""
+    send buffer must then stay untouched until the wait).
+    chunk: None = every row chunk of the plan, one after the other (a plan with one chunk: one all-to-all-v); k = only chunk k
+    (HaloSide, n_chunks > 1): the local rows of chunk k must have been written, the others may still be in the making.
+    Returns (send_buf, handle)."""
     n_send = int(side.send_idx.numel())
     if send_buf is None or send_buf.shape[0] < n_send:
         send_buf = torch.empty((max(n_send, 1), n_feat), dtype=buf.dtype, device=buf.device)
-    out = send_buf[:n_send]
-    if n_send:
-        pack(buf[: side.n_local], side.send_idx, out)
-    recv = buf[side.n_local: side.n_local + side.n_halo]
-    if native is not None:
-        h = native.halo_exchange(out, side.send_counts, recv, side.recv_counts, n_feat, async_op=async_op)
-    else:
-        h = dist.all_to_all_single(recv, out, side.recv_counts, side.send_counts, async_op=async_op) if async_op else \
-            dist.all_to_all_single(recv, out, side.recv_counts, side.send_counts)
-    return send_buf, (h if (async_op and h is not None) else _Done())
+    handles = []
+    for k in (range(side.n_chunks) if chunk is None else [chunk]):
+        s0, s1 = side.send_off[k], side.send_off[k + 1]
+        r0, r1 = side.n_local + side.recv_off[k], side.n_local + side.recv_off[k + 1]
+        out = send_buf[s0:s1]
+        if s1 > s0:
+            pack(buf[: side.n_local], side.send_idx[s0:s1], out)
+        recv = buf[r0:r1]
+        sc, rc = side.send_counts_k[k], side.recv_counts_k[k]
+        if native is not None:
+            h = native.halo_exchange(out, sc, recv, rc, n_feat, async_op=async_op)
+        else:
+            h = dist.all_to_all_single(recv, out, rc, sc, async_op=async_op) if async_op else dist.all_to_all_single(recv, out, rc, sc)
+        if async_op and h is not None:
+            handles.append(h)
+    return send_buf, (_All(handles) if handles else _Done())
 
 
 class NativeComm:
@@ -299,9 +370,10 @@ class ShardPlan:
     owners, a rank's rows in ascending original id), "contiguous", or a ready (owner, nid, cuts) triple.
     """
 
-    def __init__(self, src, dst, n_nodes, rank, world, dist, csr_builder, partition="deal", row_weight=1):
+    def __init__(self, src, dst, n_nodes, rank, world, dist, csr_builder, partition="deal", row_weight=1, n_chunks=1):
         dev = src.device
         self.rank, self.world, self.n_nodes = rank, world, n_nodes
+        self.n_chunks = int(n_chunks) if world > 1 else 1   # row chunks of the pipelined exchange (HaloSide)
         if isinstance(partition, str):
             # cost model of a vertex: `row_weight` for the dense work on its row (three GEMM passes, ~6 F^2 flop) plus one
             # unit per incident edge for the two aggregations (4 F bytes each): row_weight ~ 0.08 F on MI355X
@@ -323,10 +395,11 @@ class ShardPlan:
         keep = src != dst
         mine = keep & (self.owner[src.long()] == rank)
         rp, ci = csr_builder((nid[src[mine].long()] - lo).to(torch.int32), dst[mine].to(torch.int32), self.n_local, n_nodes)
-        self.fwd = HaloSide(rp, nid[ci.long()], lo, hi, cuts)
+        self.row_chunks = chunk_bounds(self.n_local, self.n_chunks)
+        self.fwd = HaloSide(rp, nid[ci.long()], lo, hi, cuts, self.n_chunks)
         mine_t = keep & (self.owner[dst.long()] == rank)
         rpt, cit = csr_builder((nid[dst[mine_t].long()] - lo).to(torch.int32), src[mine_t].to(torch.int32), self.n_local, n_nodes)
-        self.bwd = HaloSide(rpt, nid[cit.long()], lo, hi, cuts)
+        self.bwd = HaloSide(rpt, nid[cit.long()], lo, hi, cuts, self.n_chunks)
         self.nnz_local = int(ci.numel())
         if world > 1 and dist is not None:
             self.fwd.exchange_requests(dist, cuts, rank, world)
@@ -335,8 +408,7 @@ class ShardPlan:
             pass  # plan without a process group (tests / scripts fill the halo rows themselves)
         else:
             for s in (self.fwd, self.bwd):
-                s.send_counts = [0]
-                s.send_idx = torch.empty(0, dtype=torch.int32, device=dev)
+                s.set_send_lists(torch.empty(0, dtype=torch.int32, device=dev), [0])
         self.s_ext = self.norm = self.norm_ext_bwd = None
 
     def orig_ids(self, new_ids):
@@ -399,20 +471,30 @@ class ShardedGcnStack:
         self.send = torch.empty((ns, fmax), dtype=torch.float32, device=dev)
         self._saved = None
 
-    def _exchange(self, side, buf, F, async_op=False):
+    def _exchange(self, side, buf, F, async_op=False, chunk=None):
         if self.p.world > 1:
             return exchange_rows(self.dist, side, buf, F, self.pack, self.send.view(-1)[: self.send.shape[0] * F].view(-1, F), self.native,
-                                 async_op=async_op)[1]
+                                 async_op=async_op, chunk=chunk)[1]
         return _Done()
 
     def forward(self, X_local):
+        """Per layer: the transform runs row chunk by row chunk (ShardPlan.row_chunks) and every finished chunk's rows leave at once
+        (pack -> asynchronous all-to-all-v of that chunk) while the next chunk is being multiplied -- the one overlap a training step's
+        forward allows, since the aggregation needs the whole halo.  One chunk (n_chunks = 1): GEMM -> exchange -> SpMM.  The chunked
+        product is the same fmaf chain per row, the chunk-major tail is only another numbering: same bits."""
         ops, p, nl = self.ops, self.p, self.p.n_local
         L = len(self.W)
         saved, h = [], X_local
         for l in range(L):
             F = self.dims[l + 1]
-            ops.linear_fwd(h, self.W[l], out=self.Hext[l][:nl])
-            self._exchange(p.fwd, self.Hext[l], F)
+            handles = []
+            for k in range(p.n_chunks):
+                r0, r1 = p.row_chunks[k], p.row_chunks[k + 1]
+                if r1 > r0:
+                    ops.linear_fwd(h[r0:r1], self.W[l], out=self.Hext[l][r0:r1])
+                handles.append(self._exchange(p.fwd, self.Hext[l], F, async_op=True, chunk=k))
+            for hd in handles:
+                hd.wait()
             Y = ops.spmm(p.fwd.rowptr, p.fwd.colidx, self.Hext[l], rowscale=p.norm, bias=self.b[l], plan=self.plan_f, n_rows=nl,
                          relu_out=l + 1 < L)
             saved.append((h, Y))
@@ -451,10 +533,11 @@ class ShardedGcnStack:
 
 class ShardedTrain:
     """bench.py runner for `--train-layers L` on N > 1 ranks: the L-layer training step (forward, softmax-CE over the global batch,
-    backward, parameter all-reduce, SGD) on the sharded graph -- ShardedGcnStack; exchanges are synchronous on the compute stream
-    (a layer's aggregation needs its own halo: no independent chain to put under the exchange inside one training step)."""
+    backward, parameter all-reduce, SGD) on the sharded graph -- ShardedGcnStack: the dependence forward -> loss -> backward is the
+    real one, and what overlaps is what it leaves: a layer's transform is pipelined with the sending of its own rows (row chunks), a
+    layer's weight-gradient product runs under the exchange of the gradient for the layer below."""
 
-    def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, layers, partition="deal"):
+    def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, layers, partition="deal", n_chunks=4):
         import ctypes as C
         self.C, self.ops, self.capi, self.dist, self.F = C, ops, capi, dist, F
         self.rank, self.world, self.layers = rank, world, layers
@@ -468,7 +551,8 @@ class ShardedTrain:
             rp, ci = ops.CsrGraph.csr_from_coo(s_, d_, max(n_rows, n_cols), flags=1)
             return rp[: n_rows + 1].contiguous(), ci
 
-        self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once, partition=partition, row_weight=max(1, round(0.078 * F)))
+        self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once, partition=partition, row_weight=max(1, round(0.078 * F)),
+                                  n_chunks=n_chunks)
         del src, dst
         p.owner = p.nid = None
         ops._ws_cache.clear()
@@ -509,16 +593,20 @@ class ShardedTrain:
     def aggregation_stats(self):
         p = self.plan
         return {"local_rows": p.n_local, "local_nnz": None, "features": None, "spmm_fwd_ms": None, "halo_rows_fwd": p.fwd.n_halo,
-                "halo_rows_bwd": p.bwd.n_halo, "schedule": "synchronous exchanges (training step)"}
+                "halo_rows_bwd": p.bwd.n_halo,
+                "schedule": f"training step: per layer the transform in {p.n_chunks} row chunks, every chunk's rows sent while the next is "
+                            "multiplied; backward exchanges under the weight-gradient products"}
 
 
 class ShardedBench:
     """bench.py runner for N > 1 ranks: same synthetic graph as the single-GPU workload, sharded."""
 
     def __init__(self, ops, capi, pkg, dist, dev, rank, world, n, e, F, abc, seed, chunk, native_comm=False,
-                 global_inputs=False, schedule="overlap", partition="deal", replicate_input_halo=False):
+                 global_inputs=False, schedule="overlap", partition="deal", replicate_input_halo=False, n_chunks=None):
         import ctypes as C
         self.C = C
+        if n_chunks is None:   # the pipelined exchange belongs to the training schedule; the other two send a whole side at once
+            n_chunks = 4 if schedule == "training" else 1
         self.native = NativeComm(capi, ops, dist, rank, world, dev) if native_comm else None
         self.ops, self.capi, self.dist, self.F = ops, capi, dist, F
         self.rank, self.world = rank, world
@@ -534,7 +622,7 @@ class ShardedBench:
             return rp[: n_rows + 1].contiguous(), ci
 
         self.plan = p = ShardPlan(src, dst, n, rank, world, dist, builder_once, partition=partition,
-                                  row_weight=max(1, round(0.078 * F)))
+                                  row_weight=max(1, round(0.078 * F)), n_chunks=n_chunks)
         del src, dst
         p.owner = p.nid = None  # 2 x 4 N bytes the step does not need
         ops._ws_cache.clear()
@@ -588,13 +676,16 @@ class ShardedBench:
         self.ev = []
 
     def set_schedule(self, schedule):
-        assert schedule in ("overlap", "sequential")
+        assert schedule in ("overlap", "sequential", "training")
         self.schedule = schedule
         if getattr(self, "replicate", False):
             self.names = ["pack_send_bwd", "gemm_xwT_local_and_halo", "spmm_fwd", "colsum", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
                           "allreduce"]
         elif schedule == "sequential":
             self.names = ["gemm_xwT", "halo_fwd", "spmm_fwd", "colsum", "halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW", "allreduce"]
+        elif schedule == "training":
+            self.names = ["gemm_xwT_pack_send_chunks", "wait_halo_fwd", "spmm_fwd", "pack_send_bwd_chunks", "colsum", "wait_halo_bwd", "spmm_bwd",
+                          "gemm_dX", "gemm_dW", "allreduce"]
         else:
             self.names = ["pack_send_bwd", "gemm_xwT", "pack_send_fwd", "colsum", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
                           "wait_halo_fwd", "spmm_fwd", "allreduce"]
@@ -633,6 +724,34 @@ class ShardedBench:
             _, hb = run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True))
             run(lambda: ops.linear_fwd(self.Xext, self.W, out=self.Hext))
             run(spmm_f)
+            run(lambda: ops.colsum(Gl, out=self.dbias))
+            run(hb.wait)
+            run(spmm_b)
+            run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
+            run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
+            run(self._reduce_params)
+        elif self.schedule == "training":
+            # The dependence of a real training step -- forward -> loss -> backward (reference tensor.h:260-276: backward starts from the
+            # loss) -- is honoured: nothing of the backward chain is issued before the forward aggregation, although G is a given input
+            # here.  What overlaps is what that dependence leaves:
+            #   forward:  the transform runs in row chunks and every finished chunk's rows are packed and sent at once, while the next
+            #             chunk is multiplied (chunk-major halo tail: HaloSide);
+            #   backward: G's rows leave chunk by chunk (pack k+1 while chunk k is on the links), dbias = colsum(G) under the exchange.
+            # (A multi-layer step also has dW_l under the exchange of G_{l-1}: ShardedGcnStack.loss_and_backward.)
+            def fwd_pipeline():
+                hs = []
+                for k in range(p.n_chunks):
+                    r0, r1 = p.row_chunks[k], p.row_chunks[k + 1]
+                    if r1 > r0:
+                        ops.linear_fwd(self.X[r0:r1], self.W, out=Hl[r0:r1])
+                    hs.append(exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, async_op=True, chunk=k)[1])
+                return _All(hs)
+
+            hf = run(fwd_pipeline)
+            run(hf.wait)
+            run(spmm_f)
+            hb = run(lambda: _All([exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True, chunk=k)[1]
+                                   for k in range(p.n_chunks)]))
             run(lambda: ops.colsum(Gl, out=self.dbias))
             run(hb.wait)
             run(spmm_b)

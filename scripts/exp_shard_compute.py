@@ -4,7 +4,8 @@ in-process loopback world of tests/test_gpu_sharded_loopback.py (real plans, rea
 every rank's step is timed ALONE with the exchange stubbed out (halo rows keep the values of the real exchange).
 Gives the compute side of DESIGN.md section 6's scaling model: what a rank does per step besides waiting for xGMI.
 
-    python scripts/exp_shard_compute.py [world ...] [--workload tiny] [--replicate-input-halo] [--train-layers L]
+    python scripts/exp_shard_compute.py [world ...] [--workload tiny] [--replicate-input-halo] [--train-layers L] [--schedule overlap|training]
+                                        [--ranks 0,7]   (time only these ranks; all are built)
 """
 import importlib
 import json
@@ -52,6 +53,15 @@ def main():
     if "--train-layers" in sys.argv:
         layers = int(sys.argv[sys.argv.index("--train-layers") + 1])
         args = [a for a in args if a != str(layers)] if args.count(str(layers)) == 1 else args
+    schedule = "overlap"
+    if "--schedule" in sys.argv:
+        schedule = sys.argv[sys.argv.index("--schedule") + 1]
+        args = [a for a in args if a != schedule]
+    only = None
+    if "--ranks" in sys.argv:
+        tok = sys.argv[sys.argv.index("--ranks") + 1]
+        only = [int(x) for x in tok.split(",")]
+        args = [a for a in args if a != tok]
     worlds = [int(a) for a in args] or [8]
     n, e, F, abc, seed = WORKLOADS[workload]
     for world in worlds:
@@ -65,7 +75,7 @@ def main():
                     r = shard.ShardedTrain(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 1024, layers)
                 else:
                     r = shard.ShardedBench(ops, capi, pkg, lw.rank_view(rank), dev, rank, world, n, e, F, abc, seed, 1024,
-                                           replicate_input_halo="--replicate-input-halo" in sys.argv)
+                                           replicate_input_halo="--replicate-input-halo" in sys.argv, schedule=schedule)
                 r.step()
                 torch.cuda.synchronize()
                 runners[rank] = r
@@ -83,11 +93,13 @@ def main():
             print(errors[0])
             sys.exit(1)
         for r in runners:
+            if only is not None and r.rank not in only:
+                continue
             r.dist = NullDist()
             if layers:
                 r.net.dist = NullDist()
             else:
-                r.set_schedule("overlap")
+                r.set_schedule(schedule)
             for _ in range(2):
                 r.step()
             torch.cuda.synchronize()
@@ -99,7 +111,7 @@ def main():
             torch.cuda.synchronize()
             kt = {k: round(v, 3) for k, v in r.kernel_times().items()}
             p = r.plan
-            print(json.dumps({"world": world, "rank": r.rank, "rows": p.n_local, "nnz": p.nnz_local, "halo_fwd": p.fwd.n_halo,
+            print(json.dumps({"world": world, "rank": r.rank, "schedule": schedule if not layers else f"train-layers {layers}", "exchange_chunks": p.n_chunks, "rows": p.n_local, "nnz": p.nnz_local, "halo_fwd": p.fwd.n_halo,
                               "halo_bwd": p.bwd.n_halo, "send_rows_fwd": int(p.fwd.send_idx.numel()),
                               "send_rows_bwd": int(p.bwd.send_idx.numel()),
                               "send_per_peer_fwd": p.fwd.send_counts, "compute_ms_per_step": round(a.elapsed_time(b) / 5, 3),

@@ -61,8 +61,10 @@ def main():
     out_ref = oracle.aggregate_fwd(rp, ci, H, norm, bias)
     dH_ref = oracle.aggregate_bwd(rT, cT, G, norm)
 
+    K = int(os.environ.get("CHUNKS", 1))   # row chunks of the pipelined exchange (chunk-major halo tail / send buffer)
     plan = shard.ShardPlan(torch.from_numpy(src), torch.from_numpy(dst), n, rank, world, dist, np_csr,
-                           partition=os.environ.get("PARTITION", "deal"))
+                           partition=os.environ.get("PARTITION", "deal"), n_chunks=K)
+    assert plan.n_chunks == K and plan.row_chunks[0] == 0 and plan.row_chunks[-1] == plan.n_local
     nl = plan.n_local
     mine = plan.verts.numpy()  # original ids of this rank's rows, in local order
     assert plan.cuts[0] == 0 and plan.cuts[-1] == n and all(a <= b for a, b in zip(plan.cuts, plan.cuts[1:]))
@@ -82,9 +84,23 @@ def main():
     # forward: [local | halo] buffer, one exchange, local aggregation
     f = plan.fwd
     Hext = torch.zeros((nl + f.n_halo, F), dtype=torch.float32)
-    Hext[:nl] = torch.from_numpy(H[mine])
-    _, h = shard.exchange_rows(dist, f, Hext, F, pack, async_op=True)
-    h.wait()
+    if K == 1:
+        Hext[:nl] = torch.from_numpy(H[mine])
+        _, h = shard.exchange_rows(dist, f, Hext, F, pack, async_op=True)
+        h.wait()
+    else:
+        # the pipeline of the training schedule: chunk k of the local rows is WRITTEN just before chunk k is exchanged (the later
+        # chunks are still zero), so a chunk's exchange that read a row of another chunk would deliver zeros
+        Hl = torch.from_numpy(H[mine])
+        hs = []
+        for k in range(K):
+            r0, r1 = plan.row_chunks[k], plan.row_chunks[k + 1]
+            Hext[r0:r1] = Hl[r0:r1]
+            hs.append(shard.exchange_rows(dist, f, Hext, F, pack, async_op=True, chunk=k)[1])
+        for h in hs:
+            h.wait()
+        assert sum(sum(r) for r in f.recv_counts_k) == f.n_halo and sum(sum(r) for r in f.send_counts_k) == int(f.send_idx.numel())
+        assert [sum(f.recv_counts_k[k][q] for k in range(K)) for q in range(world)] == f.recv_counts
     assert np.array_equal(Hext[nl:].numpy(), H[halo_f]), "forward halo rows wrong"
     out = oracle.aggregate_fwd(f.rowptr.numpy().astype(np.int64), f.colidx.numpy(), Hext.numpy(), plan.norm.numpy(), bias,
                                n_rows=nl)

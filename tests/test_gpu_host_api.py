@@ -198,7 +198,7 @@ def test_bench_contract_single_gpu_and_sharded_rehearsal():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert cb["full_workload"] and "the bench's own graph" in cb["sample"], "the CPU baseline runs the bench's own workload by default"
-    for sched in ("overlap", "sequential"):
+    for sched in ("overlap", "training", "sequential"):
         s = _run_bench(["--workload", "tiny", "--steps", "2", "--warmup", "1", "--force-sharded", "--no-cpu-baseline", "--schedule", sched])
         assert s["n_gpus"] == 1 and "halo all-to-all-v" in s["config"]["parallelism"] and s["roofline"]["schedule"] == sched
         assert s["config"]["nnz"] == d["config"]["nnz"], "the sharded path must see the same graph"

@@ -76,6 +76,7 @@ class _RankDist:
 
 @pytest.mark.parametrize("world,schedule,partition,chunk", [(2, "overlap", "deal", 0), (4, "overlap", "deal", 64), (8, "overlap", "deal", 0),
                                                             (4, "sequential", "deal", 0), (8, "sequential", "contiguous", 64),
+                                                            (2, "training", "deal", 64), (8, "training", "deal", 0), (3, "training", "deal", 256),
                                                             (4, "replicate-input-halo", "deal", 0),
                                                             (8, "replicate-input-halo", "deal", 256)])
 def test_sharded_step_equals_single_gpu(world, schedule, partition, chunk):
@@ -398,3 +399,109 @@ def test_sharded_multi_layer_training_step_equals_single_gpu(world, dims):
             assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1e-6)
         for a, b in zip(W, W_after):
             assert float((a - b).abs().max()) <= 1e-6 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.parametrize("workload", ["rmat10m_100m_f256", "products_2p4m_62m_f100"])
+def test_one_rank_of_eight_at_baseline_sizes(workload):
+    """BASELINE configs[3] / [4] in their x8 form: ranks 0 and 7 of the P = 8 partition of the FULL-SIZE bench graph, built by the
+    product planner both ways (shard.ShardPlan -- with the chunk-major tail of the training schedule -- and the C-ABI plan behind
+    gnnx_partition_deal / gnnx_shard_select_edges / gnnx_halo_plan_create, compared array for array), the halo tail filled from the
+    single-GPU matrices (no second GPU on this box: the exchange itself is covered by the loopback and gloo tests), then the PLANNED
+    forward / backward aggregation and the three dense products on the shard:
+      * norm of the shard (s of the halo columns handed over) == the single-GPU norm of those vertices;
+      * X.W^T, norm (.) (A.H) + bias, A^T.(norm (.) G) and dH.W of the shard's rows are torch.equal to the single-GPU rows -- which
+        test_headline_config_whole_graph_vs_oracle / test_multi_layer_gcn_at_baseline_sizes_vs_oracle pin to the oracle bit for bit;
+      * dH^T.X over the shard's rows against float64 (a rank's partial sum has no single-GPU counterpart).
+    The [local | halo] renumbering, the hub plan ON A SHARD (hub rows keep all their non-zeros: 1/8 of the rows, the same longest
+    row) and the 128-float padded layout of the products-shaped width meet the full-size graphs here."""
+    import torch
+    ops = importlib.import_module("gnncpp_amd.ops")
+    shard = importlib.import_module("gnncpp_amd.shard")
+    sn = importlib.import_module("gnncpp_amd.shard_native")
+    bench = importlib.import_module("bench")
+    dev = torch.device("cuda:0")
+    n, e, F, abc, seed = bench.WORKLOADS[workload]
+    world, chunk = 8, 1024
+    src, dst = ops.rmat_edges(seed, n, e, *abc, device=dev)
+    g = ops.CsrGraph.from_coo(src, dst, n)
+    g.make_plans(chunk, F)
+    Fp = -(-F // 128) * 128   # streamed rows (X, dH, dX, W) on the 128-float stride, as bench.py / GcnStack lay them out
+    def padded(t):
+        if Fp == F:
+            return t
+        p_ = torch.zeros((t.shape[0], Fp), dtype=torch.float32, device=dev)
+        p_[:, :F] = t
+        return p_
+    Xp = padded(ops.uniform_pm1(seed + 10, (n, F), device=dev))
+    Wp = torch.zeros((Fp, Fp), dtype=torch.float32, device=dev)
+    Wp[:F, :F] = ops.uniform_pm1(seed + 11, (F, F), scale=F ** -0.5, device=dev)
+    bias = ops.uniform_pm1(seed + 13, (F,), scale=0.1, device=dev)
+    G = ops.uniform_pm1(seed + 12, (n, F), device=dev)
+    H = ops.linear_fwd(Xp, Wp[:F])                       # [n, F]: gathered rows keep their own width
+    out = ops.aggregate_fwd(g, H, bias)
+    dHp = torch.zeros((n, Fp), dtype=torch.float32, device=dev)
+    ops.aggregate_bwd(g, G, out=dHp[:, :F])
+    dXp = ops.gemm(dHp, Wp)
+    torch.cuda.synchronize()
+
+    def builder(s_, d_, n_rows, n_cols):
+        rp, ci = ops.CsrGraph.csr_from_coo(s_, d_, max(n_rows, n_cols), flags=1)
+        return rp[: n_rows + 1].contiguous(), ci
+
+    def degree_norm(rowptr, colidx, n_rows, s_out, s_cols, norm_out):
+        capi = importlib.import_module("gnncpp_amd.capi")
+        capi.call("gnnx_degree_norm_f32", ops._ptr(rowptr), ops._ptr(colidx), n_rows, ops._ptr(s_out), ops._ptr(s_cols), ops._ptr(norm_out),
+                  ops._stream())
+
+    rw = max(1, round(0.078 * F))
+    for rank in (0, world - 1):
+        pn = sn.NativeShardPlan(src, dst, n, rank, world, None, row_weight=rw)
+        pt1 = shard.ShardPlan(src, dst, n, rank, world, None, builder, row_weight=rw)                 # owner-major tail: the C-ABI layout
+        assert pn.cuts == pt1.cuts and torch.equal(pn.owner, pt1.owner) and torch.equal(pn.nid, pt1.nid)
+        for a, b in ((pn.fwd, pt1.fwd), (pn.bwd, pt1.bwd)):
+            assert a.n_local == b.n_local and a.n_halo == b.n_halo and a.recv_counts == b.recv_counts
+            assert torch.equal(a.rowptr, b.rowptr) and torch.equal(a.colidx, b.colidx) and torch.equal(a.halo(dev), b.halo.to(torch.int32))
+        part = (pt1.owner, pt1.nid, pt1.cuts)
+        del pn, pt1
+        pt = shard.ShardPlan(src, dst, n, rank, world, None, builder, partition=part, n_chunks=4)      # chunk-major tail (training schedule)
+        nl, v = pt.n_local, pt.verts
+        assert abs(nl - n / world) <= 1
+        # ---- norm: s of the halo columns from the single-GPU vector
+        s_ext = torch.zeros((nl + pt.fwd.n_halo, 1), dtype=torch.float32, device=dev)
+        degree_norm(pt.fwd.rowptr, pt.fwd.colidx, nl, s_ext[:nl], None, None)
+        assert torch.equal(s_ext[:nl, 0], g.s[v])
+        s_ext[nl:, 0] = g.s[pt.orig_ids(pt.fwd.halo)]
+        norm = torch.zeros(nl, dtype=torch.float32, device=dev)
+        degree_norm(pt.fwd.rowptr, pt.fwd.colidx, nl, None, s_ext, norm)
+        assert torch.equal(norm, g.norm[v]), "shard norm"
+        plan_f, plan_b = ops.SpmmPlan(pt.fwd.rowptr, chunk, F), ops.SpmmPlan(pt.bwd.rowptr, chunk, F)
+        assert plan_f.n_split_rows > 0 and plan_b.n_split_rows > 0, "a shard of the bench graph has hub rows"
+        # ---- forward: transform of the local rows, halo rows of H from the single-GPU matrix, planned aggregation
+        Xl = Xp[v].contiguous()
+        Hext = torch.empty((nl + pt.fwd.n_halo, F), dtype=torch.float32, device=dev)
+        for k in range(pt.n_chunks):   # row chunks, as the training schedule multiplies them
+            r0, r1 = pt.row_chunks[k], pt.row_chunks[k + 1]
+            ops.linear_fwd(Xl[r0:r1], Wp[:F], out=Hext[r0:r1])
+        assert torch.equal(Hext[:nl], H[v]), "X.W^T of the shard's rows (in row chunks)"
+        Hext[nl:] = H[pt.orig_ids(pt.fwd.halo)]
+        o = ops.spmm(pt.fwd.rowptr, pt.fwd.colidx, Hext, rowscale=norm, bias=bias, plan=plan_f, n_rows=nl)
+        assert torch.equal(o, out[v]), f"rank {rank}: planned forward aggregation of the shard != single-GPU rows"
+        del Hext, o
+        # ---- backward
+        Gext = torch.empty((nl + pt.bwd.n_halo, F), dtype=torch.float32, device=dev)
+        Gext[:nl] = G[v]
+        hb = pt.orig_ids(pt.bwd.halo)
+        Gext[nl:] = G[hb]
+        norm_ext = torch.cat([norm, g.norm[hb]])
+        vals = ops.gather_rows(norm_ext.reshape(-1, 1), pt.bwd.colidx).reshape(-1)
+        dHl = torch.zeros((nl, Fp), dtype=torch.float32, device=dev)
+        ops.spmm(pt.bwd.rowptr, pt.bwd.colidx, Gext, out=dHl[:, :F], vals=vals, plan=plan_b, n_rows=nl)
+        assert torch.equal(dHl, dHp[v]), f"rank {rank}: planned backward aggregation of the shard != single-GPU rows"
+        assert torch.equal(ops.gemm(dHl, Wp), dXp[v]), "dH.W of the shard's rows"
+        dW = ops.gemm(dHl, Xl, transA=True)
+        ref = dHl.double().t() @ Xl.double()
+        bound = 1e-5 * torch.maximum(torch.maximum(ref.abs(), dHl.abs().double().t() @ Xl.abs().double()), torch.ones_like(ref))
+        assert bool(((dW.double() - ref).abs() <= bound).all()), "dH^T.X of the shard's rows vs float64"
+        del Gext, dHl, dW, ref, bound, pt, plan_f, plan_b, Xl, vals
+        ops._ws_cache.clear()
+        torch.cuda.empty_cache()

@@ -30,6 +30,13 @@ def test_sharded_aggregation_bit_identical(world, port):
     run_world(world, port)
 
 
+@pytest.mark.parametrize("world,port,chunks", [(2, 29625, 4), (3, 29626, 3)])
+def test_sharded_aggregation_pipelined_exchange_chunks(world, port, chunks):
+    """The training schedule's pipelined exchange: local rows cut into row chunks, halo tail and send buffer chunk-major, one
+    all-to-all-v per chunk issued as soon as that chunk's rows exist -- norm, forward and backward aggregation stay bit-identical."""
+    run_world(world, port, CHUNKS=chunks)
+
+
 def test_sharded_aggregation_bit_identical_contiguous_partition():
     """The round-1 partition (contiguous original-id ranges) stays available and exact."""
     run_world(2, 29624, PARTITION="contiguous")
