@@ -83,6 +83,7 @@ _SIGS = {
     "gnnx_spmm_plan_create": [_vp, _i32, _i32, _i32, C.POINTER(_vp), _vp],
     "gnnx_spmm_plan_destroy": [_vp],
     "gnnx_spmm_plan_info": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
+    "gnnx_spmm_plan_set_big_row_threshold": [_vp, _i32],
     "gnnx_spmm_csr_bn_sums_workspace": [_i32, _i32, _vp, C.POINTER(_sz)],
     "gnnx_spmm_csr_bn_sums_f32": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _vp,
                                   _vp, _sz, _vp, _vp],

@@ -22,6 +22,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include <rocprim/device/device_scan.hpp>
@@ -39,7 +40,13 @@ struct gnnx_spmm_plan {
     int32_t n_split_rows = 0;   // rows with degree > chunk (the hub rows)
     int64_t n_hub_nnz = 0;      // their non-zeros
     int32_t max_hub_degree = 0;
-    int32_t *d_hub_rows = nullptr;  // [n_split_rows] the hub rows, longest first: work list of spmm_hub_kernel
+    // the first n_big_rows of the list (degree > big_row_threshold) go to the producer / consumer kernel (spmm_hubpc_kernel): rows
+    // whose time is their own chain of dependent adds, not their bytes
+    int32_t big_row_threshold = 0;
+    int32_t n_big_rows = 0;
+    int64_t n_big_nnz = 0;
+    std::vector<int32_t> h_hub_degrees;  // host copy of the sorted degrees (gnnx_spmm_plan_set_big_row_threshold)
+    int32_t *d_hub_rows = nullptr;  // [n_split_rows] the hub rows, longest first: work list of the hub kernels
     unsigned long long *d_counters = nullptr;
     // non-zero-balanced row blocks for the streaming kernel: block k owns rows [d_block_starts[k], [k+1])
     int32_t block_nnz = 0;
@@ -67,6 +74,7 @@ struct SpmmArgs {
     const int32_t *hub_rows; // the plan's hub rows, longest first
     int32_t n_hub_rows;
     int32_t hub_beside;      // run the hub kernel on the side stream, beside the row kernel (its time is one row's add chain)
+    int32_t n_big_rows;      // the first n_big_rows hub rows take the producer / consumer kernel (f32 rows of 16-byte pieces)
     // row blocks of the streaming kernel (plan): nullptr => fixed blocks of StreamCfg<G>::R rows
     const int32_t *block_starts;
     int32_t n_blocks;
@@ -605,6 +613,9 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int kHubSlab = 64;   // features per work item
 constexpr int kHubSub = 16;    // neighbours per sub-chunk: 4 KiB of LDS
 constexpr int kHubChunk = 64;  // neighbours per index chunk
+// hub rows longer than this take the producer / consumer kernel (spmm_hubpc_kernel): at 12 ns per neighbour a longer row's chain in
+// spmm_hub_kernel is more than ~0.1 ms, which is what a rank's share of the other hub rows' bytes takes on an 8-way shard
+constexpr int kHubBigRow = 8192;
 
 template <int OFF, class T>
 __device__ __forceinline__ void hub_lds_read(T &dst, uint32_t addr)
@@ -653,7 +664,7 @@ struct HubCfg {
 };
 
 template <int VEC, int MODE, int LAS, class XT, bool SUMS = false, int SLAB = kHubSlab>
-__global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t *hub_rows, int32_t n_slabs, int32_t n_groups)
+__global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t *hub_rows, int32_t n_slabs, int32_t n_groups, int32_t ordinal0)
 {
     using K = HubCfg<VEC, MODE, LAS, XT, SLAB>;
     constexpr int EPI = K::EPI, IPS = K::IPS, NS = K::NS, SUBS = K::SUBS, DI = K::DI, NC = K::NC, NI = K::NI;
@@ -874,7 +885,348 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
                 if (!(z > 0.f)) g = 0.f;
             }
             const float xhat = (h - mean) * (1.0f / sqrtf(var + a.pro_eps));
-            float *prow = a.bn_partial + ((int64_t)a.n_stream_waves + (int64_t)(blockIdx.x / n_groups)) * 2 * a.n_feat;
+            float *prow = a.bn_partial + ((int64_t)a.n_stream_waves + (int64_t)ordinal0 + (int64_t)(blockIdx.x / n_groups)) * 2 * a.n_feat;
+            prow[f] = g;
+            prow[a.n_feat + f] = g * xhat;
+        }
+    }
+}
+
+// ---- the LONGEST hub rows: producer / consumer form ---------------------------------------------------------------------
+// A hub row's time in spmm_hub_kernel is one wavefront's instruction stream per neighbour: the LDS-DMA issue (a quarter of a
+// ~60-cycle wave-instruction), the index read, the address mad, the value read and the add -- ~29 cycles = 12 ns per neighbour, whatever is in
+// flight.  On the whole graph that hides behind the bytes of the other hub rows; on one rank's shard of it (1/8 of the rows, the
+// same longest row) or on a small graph the longest rows ARE the aggregation's time (a 250 k-entry row: 3.0 ms).  The sum itself
+// cannot be split -- one accumulator per feature, the reference's order -- so everything else is taken out of its wavefront:
+//   * a workgroup = (row, 64-feature slab) = ONE consumer wavefront + hubpc::NP producer wavefronts, a CU of its own (the ring
+//     takes 128 KiB of its LDS: a CU can only feed ~3 ns per neighbour if ~2 us of memory latency are in flight);
+//   * producers own the index chunks (64 neighbours) round-robin: index chunk -> LDS by DMA, column -> address, the slab's slices
+//     of 16 neighbours per ring slot by LDS-DMA (+ the per-entry values / gathered column scales of those 16 into small rings),
+//     up to LAS sub-chunks in flight each; when a sub-chunk has LANDED (the producer's own vmcnt) its count goes to an LDS flag;
+//   * the consumer reads a landed slot with 8 ds_read2st64_b32 (neighbours e, e + 1 of its feature in one instruction), the next
+//     slot's reads in flight while this slot's 16 adds run -- strictly in descending column order, separately rounded: the same bits
+//     as every other path -- and publishes the slots it has left (the producers' back-pressure).  ~6-7 cycles per neighbour.
+// Flags are LDS words (ds_write / ds_read of one CU's LDS unit are processed in order; a producer writes its flag after the
+// s_waitcnt that covers the DMA).  No barrier after the start, no spin without progress: a producer blocks only when nothing of
+// its own is in flight and the ring is full, the consumer only on a sub-chunk that is not there yet.
+namespace hubpc {
+constexpr int NP = 3;      // producer wavefronts
+constexpr int LAS = 10;    // sub-chunks in flight per producer
+constexpr int S = 32;      // ring slots (one sub-chunk of 16 neighbours x 256 B each): 128 KiB
+constexpr int IPS = 4;     // data DMA instructions per sub-chunk
+constexpr int NCX = 3;     // index chunks fetched ahead per producer (4 NCX >= LAS + 2)
+constexpr int NI = NCX + 1;
+constexpr int SUBF = kHubSub * kHubSlab;   // floats per ring slot
+constexpr int kSpinCap = 1 << 22;          // polls of an LDS flag before a wait gives up (seconds; a wait lasts microseconds)
+static_assert((S & (S - 1)) == 0 && S > NP * LAS, "ring: a power of two, and room for everything in flight plus the slot being added");
+static_assert(4 * NCX >= LAS + 2, "an index chunk has landed when its first sub-chunk is issued (see the producer loop)");
+template <int MODE> struct Lay {
+    static constexpr int IPSX = IPS + (has_val(MODE) ? 1 : 0) + (has_sc(MODE) ? 1 : 0);   // VMEM operations per sub-chunk
+    static constexpr int VR = S * SUBF;                              // [S][16] per-entry values
+    static constexpr int SR = VR + (has_val(MODE) ? S * kHubSub : 0);   // [S][16] gathered column scales
+    static constexpr int IR = SR + (has_sc(MODE) ? S * kHubSub : 0);    // [NP][NI][64] column indices
+    static constexpr int FL = IR + NP * NI * kHubChunk;              // landed[NP], consumed
+    static constexpr int LDS_FLOATS = FL + 8;
+    static_assert((LAS - 1) * IPSX + NCX <= 63, "vmcnt is a 6-bit counter");
+};
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int32_t flag_read(uint32_t addr)   // one LDS word, wave-uniform
+{
+    int32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ void flag_write(uint32_t addr, int32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+template <int K> __device__ __forceinline__ void wait_vm_sub(int k)   // s_waitcnt vmcnt(k * IPSX): the k youngest sub-chunks stay in flight
+{
+#define GNNX_PC_CASE(i) case i: hub_wait_vm<(i) * K>(); break;
+    switch (k) {
+        GNNX_PC_CASE(0) GNNX_PC_CASE(1) GNNX_PC_CASE(2) GNNX_PC_CASE(3) GNNX_PC_CASE(4) GNNX_PC_CASE(5) GNNX_PC_CASE(6) GNNX_PC_CASE(7) GNNX_PC_CASE(8)
+    default: hub_wait_vm<(LAS - 1) * K>(); break;
+    }
+#undef GNNX_PC_CASE
+}
+// own sequence number u of a producer -> the row's sub-chunk; and back
+__device__ __forceinline__ int32_t t_of(int32_t p, int32_t u) { return 4 * (p + (u >> 2) * NP) + (u & 3); }
+}  // namespace hubpc
+
+template <int MODE, bool SUMS>
+__global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmArgs a, const int32_t *hub_rows, int32_t n_slabs)
+{
+    using namespace hubpc;
+    using L = Lay<MODE>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int32_t ordinal = (int32_t)(blockIdx.x / n_slabs);
+    const int32_t row = __builtin_amdgcn_readfirstlane(hub_rows[ordinal]);
+    const int32_t f_slab = (int32_t)(blockIdx.x % n_slabs) * kHubSlab;
+    const int32_t lo = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
+    const int32_t hi = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
+    const int32_t total = hi - lo;
+    const int32_t nsub = (total + kHubSub - 1) / kHubSub;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t *)lds;
+    const uint32_t fl0 = lds0 + (uint32_t)L::FL * 4u;   // landed[p] at fl0 + 4 p, consumed at fl0 + 4 NP
+    if (threadIdx.x < 8) reinterpret_cast<int32_t *>(lds + L::FL)[threadIdx.x] = 0;
+    __syncthreads();
+
+    if (wv > 0) {
+        // ------------------------------------------------------------------ producer p
+        const int32_t p = wv - 1;
+        const int32_t nchunk = (nsub + 3) >> 2;
+        const int32_t n_own_chunks = nchunk > p ? (nchunk - p + NP - 1) / NP : 0;
+        int32_t n_own = 4 * n_own_chunks;                              // own sub-chunks: the row's last index chunk may be short
+        if (n_own_chunks > 0 && p + (n_own_chunks - 1) * NP == nchunk - 1) n_own -= 4 * nchunk - nsub;
+        // DMA source of this lane: neighbour sub_e of the instruction, 4 features at foff (lanes past the row's width re-read the
+        // slab's first piece; their LDS words are never stored)
+        const int sub_e = lane >> 4;
+        int32_t foff = f_slab + (lane & 15) * 4;
+        if (foff + 4 > a.n_feat) foff = f_slab;
+        const char *xsrc = reinterpret_cast<const char *>(a.X + foff);
+        const uint32_t row_bytes = (uint32_t)(a.ldx * (int64_t)sizeof(float));
+        float *iring = lds + L::IR + p * NI * kHubChunk;
+        const uint32_t col_lane = lds0 + (uint32_t)(L::IR + p * NI * kHubChunk + sub_e) * 4u;
+        const uint32_t col16 = lds0 + (uint32_t)(L::IR + p * NI * kHubChunk + (lane & 15)) * 4u;
+
+        auto idx_dma = [&](int32_t j) {   // own index chunk j -> its ring slot: lane i brings neighbour chunk * 64 + i (clamped into the row)
+            const int32_t c = p + j * NP;
+            int32_t q = hi - 1 - (c * kHubChunk + lane);
+            q = q < lo ? lo : q;
+            __builtin_amdgcn_global_load_lds(a.colidx + q, (lds_void_t *)(iring + (j & (NI - 1)) * kHubChunk), 4, 0, 0);
+        };
+        auto issue = [&](int32_t u) {     // own sub-chunk u: columns from the index ring, slices (+ values / column scales) into ring slot t % S
+            const int32_t t = t_of(p, u);
+            const int islot = (u >> 2) & (NI - 1), k0 = (u & 3) * kHubSub, slot = t & (S - 1);
+            int32_t c[IPS], c16 = 0;
+            const uint32_t ca = col_lane + (uint32_t)(islot * kHubChunk + k0) * 4u;
+            hub_lds_read<0 * 16>(c[0], ca);
+            hub_lds_read<1 * 16>(c[1], ca);
+            hub_lds_read<2 * 16>(c[2], ca);
+            hub_lds_read<3 * 16>(c[3], ca);
+            if constexpr (has_sc(MODE)) hub_lds_read<0>(c16, col16 + (uint32_t)(islot * kHubChunk + k0) * 4u);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c16)::"memory");
+            float *dst = lds + slot * SUBF;
+#pragma unroll
+            for (int i = 0; i < IPS; i++) {
+                const char *srcp = xsrc + (uint64_t)(uint32_t)c[i] * row_bytes;
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(srcp), (lds_void_t *)(dst + i * 256), 16, 0, 0);
+            }
+            if constexpr (has_val(MODE) || has_sc(MODE)) {
+                if (lane < kHubSub) {   // 16 lanes: one word per neighbour of the sub-chunk
+                    if constexpr (has_val(MODE)) {
+                        int32_t q = hi - 1 - (t * kHubSub + lane);
+                        q = q < lo ? lo : q;
+                        __builtin_amdgcn_global_load_lds(a.vals + q, (lds_void_t *)(lds + L::VR + slot * kHubSub), 4, 0, 0);
+                    }
+                    if constexpr (has_sc(MODE))
+                        __builtin_amdgcn_global_load_lds(a.colscale + c16, (lds_void_t *)(lds + L::SR + slot * kHubSub), 4, 0, 0);
+                }
+            }
+        };
+
+#pragma unroll
+        for (int j = 0; j < NCX; j++) idx_dma(j);
+        hub_wait_vm<0>();
+        int32_t issued = 0, landed = 0, consumed = 0, spins = 0;
+        while (landed < n_own) {
+            // put in flight whatever the window (LAS) and the ring (a slot is free once the consumer has left sub-chunk t - S) allow
+            while (issued < n_own && issued - landed < LAS) {
+                const int32_t need = t_of(p, issued) - S + 1;
+                if (need > consumed) {
+                    consumed = flag_read(fl0 + 4u * NP);
+                    if (need > consumed) break;
+                }
+                issue(issued);
+                // the index chunk NCX ahead, behind the first sub-chunk of every own chunk: by the time its first sub-chunk is issued
+                // (LAS window: at least 2 sub-chunks issued after this DMA have landed, VMEM returns in order) it is in LDS, and
+                // the slot it overwrites (own chunk - 1) has been read to the end
+                if ((issued & 3) == 0) idx_dma((issued >> 2) + NCX);
+                issued++;
+            }
+            if (issued == landed) {   // ring full and nothing of ours in flight: the consumer is behind
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > kSpinCap) break;   // (never reached: every wait here ends when the consumer moves; a bounded exit all the same)
+                continue;
+            }
+            spins = 0;
+            wait_vm_sub<L::IPSX>(issued - landed - 1);   // own sub-chunk `landed` is in LDS (index DMAs in between only make the wait stricter)
+            landed++;
+            flag_write(fl0 + 4u * (uint32_t)p, landed);
+        }
+        hub_wait_vm<0>();   // index DMAs past the end of the row
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    const int32_t f = f_slab + lane;
+    const bool active = f < a.n_feat;
+    const ProConst<1> pc = pro_load<1, MODE>(a, active ? f : 0, active);
+    const uint32_t ring_lane = lds0 + (uint32_t)lane * 4u;
+    struct Set {
+        v2f d[8];
+        v4f vv[4], sv[4];
+        int32_t fl;
+    };
+    constexpr int NREADS = 8 + (has_val(MODE) ? 4 : 0) + (has_sc(MODE) ? 4 : 0) + 1;   // LDS operations of one issue_reads
+    constexpr bool PIPE = NREADS <= 15;                                                 // lgkmcnt is a 4-bit counter
+    // what sub-chunk t needs: producer (t / 4) % NP has landed own sub-chunk 4 ((t / 4) / NP) + t % 4
+    auto flag_of = [&](int32_t t) { return fl0 + 4u * (uint32_t)((t >> 2) % NP); };
+    auto need_of = [&](int32_t t) { return 4 * ((t >> 2) / NP) + (t & 3) + 1; };
+    auto issue_reads = [&](Set &s, int32_t t) {   // slot t % S -> registers; with it the flag sub-chunk t + 2 will be checked against
+        const uint32_t ad = ring_lane + (uint32_t)(t & (S - 1)) * (uint32_t)(SUBF * 4);
+#define GNNX_PC_R2(i) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(s.d[i]) : "v"(ad), "i"(2 * (i)), "i"(2 * (i) + 1) : "memory")
+        GNNX_PC_R2(0); GNNX_PC_R2(1); GNNX_PC_R2(2); GNNX_PC_R2(3); GNNX_PC_R2(4); GNNX_PC_R2(5); GNNX_PC_R2(6); GNNX_PC_R2(7);
+#undef GNNX_PC_R2
+        if constexpr (has_val(MODE)) {   // the 16 per-entry values: the same 64 bytes to every lane (broadcast reads)
+            const uint32_t va = lds0 + (uint32_t)(L::VR + (t & (S - 1)) * kHubSub) * 4u;
+#define GNNX_PC_R4(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.vv[i]) : "v"(va), "i"(16 * (i)) : "memory")
+            GNNX_PC_R4(0); GNNX_PC_R4(1); GNNX_PC_R4(2); GNNX_PC_R4(3);
+#undef GNNX_PC_R4
+        }
+        if constexpr (has_sc(MODE)) {
+            const uint32_t sa = lds0 + (uint32_t)(L::SR + (t & (S - 1)) * kHubSub) * 4u;
+#define GNNX_PC_R4(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.sv[i]) : "v"(sa), "i"(16 * (i)) : "memory")
+            GNNX_PC_R4(0); GNNX_PC_R4(1); GNNX_PC_R4(2); GNNX_PC_R4(3);
+#undef GNNX_PC_R4
+        }
+        asm volatile("ds_read_b32 %0, %1" : "=v"(s.fl) : "v"(flag_of(t + 2)) : "memory");
+    };
+    // this set's reads have returned; N: the LDS operations issued after them that stay in flight.  The set's registers are in-out
+    // operands so that no use of them is scheduled in front of the wait (only the fields the MODE reads: an unused operand costs a copy)
+    auto wait_set = [&](Set &s, auto keep) {
+        constexpr int N = decltype(keep)::value;
+        if constexpr (has_val(MODE) && has_sc(MODE))
+            asm volatile("s_waitcnt lgkmcnt(%17)"
+                         : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7]), "+v"(s.vv[0]),
+                           "+v"(s.vv[1]), "+v"(s.vv[2]), "+v"(s.vv[3]), "+v"(s.sv[0]), "+v"(s.sv[1]), "+v"(s.sv[2]), "+v"(s.sv[3]), "+v"(s.fl)
+                         : "i"(N)
+                         : "memory");
+        else if constexpr (has_val(MODE))
+            asm volatile("s_waitcnt lgkmcnt(%13)"
+                         : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7]), "+v"(s.vv[0]),
+                           "+v"(s.vv[1]), "+v"(s.vv[2]), "+v"(s.vv[3]), "+v"(s.fl)
+                         : "i"(N)
+                         : "memory");
+        else if constexpr (has_sc(MODE))
+            asm volatile("s_waitcnt lgkmcnt(%13)"
+                         : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7]), "+v"(s.sv[0]),
+                           "+v"(s.sv[1]), "+v"(s.sv[2]), "+v"(s.sv[3]), "+v"(s.fl)
+                         : "i"(N)
+                         : "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(%9)"
+                         : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7]), "+v"(s.fl)
+                         : "i"(N)
+                         : "memory");
+    };
+    auto wait_landed = [&](int32_t t, int32_t seen) {   // sub-chunk t is in LDS (`seen`: an earlier reading of its producer's flag)
+        const int32_t need = need_of(t);
+        if (seen >= need) return;
+        int32_t spins = 0;
+        while (flag_read(flag_of(t)) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > kSpinCap) break;   // bounded exit (never reached: the producers do not wait for anything but this wavefront)
+        }
+    };
+    float acc = 0.f;
+    auto adds = [&](Set &s, auto full, int32_t cnt) {   // full: all 16 neighbours of the sub-chunk exist (every sub-chunk but the row's last)
+        float v[kHubSub];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            v[2 * i] = s.d[i].x;
+            v[2 * i + 1] = s.d[i].y;
+        }
+        if constexpr (has_pro(MODE)) {   // the prologue of the sub-chunk in straight-line code (as spmm_hub_kernel's pro_batch)
+            if constexpr (pro_bn(MODE)) {
+                float d[kHubSub];
+                bool bad = false;
+#pragma unroll
+                for (int j = 0; j < kHubSub; j++) {
+                    d[j] = __fsub_rn(v[j], pc.mean);
+                    v[j] = (float)((double)d[j] * pc.rsd[0]);
+                    bad |= !(fabsf(v[j]) >= 1.17549435e-38f) && d[j] != 0.f;
+                }
+                if (__builtin_expect(bad, 0)) {
+#pragma unroll
+                    for (int j = 0; j < kHubSub; j++) v[j] = __fdiv_rn(d[j], pc.sd);
+                }
+#pragma unroll
+                for (int j = 0; j < kHubSub; j++) v[j] = __fadd_rn(__fmul_rn(v[j], pc.gamma), pc.beta);
+            }
+            if constexpr (pro_relu(MODE)) {
+#pragma unroll
+                for (int j = 0; j < kHubSub; j++) v[j] = relu1(v[j]);
+            }
+        }
+        if constexpr (has_sc(MODE)) {
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++) v[j] = mul_rn(v[j], s.sv[j >> 2][j & 3]);
+        }
+        if constexpr (has_val(MODE)) {
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++) v[j] = mul_rn(v[j], s.vv[j >> 2][j & 3]);
+        }
+        if constexpr (decltype(full)::value) {
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++) acc = add_rn(acc, v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kHubSub; j++)
+                if (j < cnt) acc = add_rn(acc, v[j]);
+        }
+    };
+    using Keep = std::integral_constant<int, PIPE ? NREADS : 0>;
+    using None = std::integral_constant<int, 0>;
+    // a step with a successor: sub-chunk t (its reads issued one step earlier into `cur`) is added while the reads of t + 1 go out
+    // into `nxt`; nxt.fl still holds the flag that travelled with sub-chunk t - 1: the reading sub-chunk t + 1 is checked against
+    auto step = [&](Set &cur, Set &nxt, int32_t t) {
+        wait_landed(t + 1, __builtin_amdgcn_readfirstlane(nxt.fl));
+        issue_reads(nxt, t + 1);
+        wait_set(cur, Keep{});
+        flag_write(fl0 + 4u * NP, t + 1);   // the slot of sub-chunk t is free (its words are in registers)
+        adds(cur, std::true_type{}, kHubSub);
+    };
+    auto last = [&](Set &cur, int32_t t) {   // the row's last sub-chunk (possibly short)
+        wait_set(cur, None{});
+        adds(cur, std::false_type{}, total - t * kHubSub);
+    };
+    Set A, B;
+    B.fl = 0;
+    wait_landed(0, 0);
+    issue_reads(A, 0);
+    int32_t t = 0;
+    for (; t + 2 < nsub; t += 2) {
+        step(A, B, t);
+        step(B, A, t + 1);
+    }
+    if (t + 1 < nsub) {   // A holds the reads of sub-chunk t: one or two sub-chunks are left
+        step(A, B, t);
+        last(B, t + 1);
+    } else {
+        last(A, t);
+    }
+    if (active) {  // the epilogue of epilogue_store<1>, same op order
+        float v = acc;
+        if (a.rowscale) v = mul_rn(v, a.rowscale[row]);
+        if (a.bias) v = add_rn(v, a.bias[f]);
+        float *dst = a.Y + (int64_t)row * a.ldy + f;
+        if (a.beta) v = add_rn(*dst, v);
+        if (a.relu_out) v = relu1(v);
+        *dst = v;
+        if constexpr (SUMS) {   // this row's term of BatchNorm's backward sums (bn_sums_rows' arithmetic), a partial row of its own
+            const float h = a.bn_h[(int64_t)row * a.bn_ldh + f];
+            const float mean = a.pro_mean[f], var = a.pro_var[f];
+            float g = v;
+            if (a.bn_relu) {
+                float z = __fdiv_rn(__fsub_rn(h, mean), sqrtf(__fadd_rn(var, a.pro_eps)));
+                if (a.pro_gamma) z = __fmul_rn(z, a.pro_gamma[f]);
+                if (a.pro_beta) z = __fadd_rn(z, a.pro_beta[f]);
+                if (!(z > 0.f)) g = 0.f;
+            }
+            const float xhat = (h - mean) * (1.0f / sqrtf(var + a.pro_eps));
+            float *prow = a.bn_partial + ((int64_t)a.n_stream_waves + (int64_t)ordinal) * 2 * a.n_feat;
             prow[f] = g;
             prow[a.n_feat + f] = g * xhat;
         }
@@ -941,7 +1293,7 @@ __global__ void plan_block_fill_kernel(const int32_t *flag, const int32_t *pos, 
 }
 
 template <int VEC, int MODE, class XT, bool SUMS, int SLAB>
-int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int32_t n_rows_hub)
+int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int32_t n_rows_hub, int32_t ordinal0)
 {
     // look-ahead in sub-chunks of 16 neighbours: 8 where a sub-chunk is 4 DMA instructions, less where it is 8 or 16 (vmcnt counts
     // at most 63 operations).
@@ -966,7 +1318,7 @@ int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int3
     }
     const dim3 grid((uint32_t)((int64_t)n_rows_hub * n_groups));
     const size_t lds_wg = lds_wave * waves;
-    hipLaunchKernelGGL((spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS, SLAB>), grid, dim3(64 * waves), lds_wg, st, a, rows, n_slabs, n_groups);
+    hipLaunchKernelGGL((spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS, SLAB>), grid, dim3(64 * waves), lds_wg, st, a, rows, n_slabs, n_groups, ordinal0);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }
@@ -974,7 +1326,8 @@ int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int3
 template <int VEC, int MODE, class XT, bool SUMS = false>
 int launch_hub_kernel(hipStream_t st, const SpmmArgs &a)
 {
-    return launch_hub_rows<VEC, MODE, XT, SUMS, kHubSlab>(st, a, a.hub_rows, a.n_hub_rows);
+    // the rows behind the first n_big_rows (those belong to spmm_hubpc_kernel: launch_hubpc)
+    return launch_hub_rows<VEC, MODE, XT, SUMS, kHubSlab>(st, a, a.hub_rows + a.n_big_rows, a.n_hub_rows - a.n_big_rows, a.n_big_rows);
 }
 
 template <int VEC>
@@ -998,6 +1351,42 @@ int launch_hub(int mode, hipStream_t st, const SpmmArgs &a)
     case 4: return launch_hub_kernel<VEC, 4, float>(st, a);
     case 5: return launch_hub_kernel<VEC, 5, float>(st, a);
     default: return launch_hub_kernel<VEC, 6, float>(st, a);
+    }
+}
+
+template <int MODE, bool SUMS>
+int launch_hubpc_kernel(hipStream_t st, const SpmmArgs &a)
+{
+    using L = hubpc::Lay<MODE>;
+    static std::atomic<uint64_t> done{0};
+    constexpr size_t lds_bytes = sizeof(float) * L::LDS_FLOATS;
+    static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {  // dynamic-LDS opt-in, once per kernel and device
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hubpc_kernel<MODE, SUMS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    const int32_t n_slabs = (int32_t)ceil_div(a.n_feat, kHubSlab);
+    const dim3 grid((uint32_t)((int64_t)a.n_big_rows * n_slabs));
+    hipLaunchKernelGGL((spmm_hubpc_kernel<MODE, SUMS>), grid, dim3(64 * (1 + hubpc::NP)), lds_bytes, st, a, a.hub_rows, n_slabs);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+
+// the first n_big_rows hub rows (f32 rows of 16-byte pieces) on the producer / consumer kernel
+int launch_hubpc(int mode, hipStream_t st, const SpmmArgs &a)
+{
+    if (a.bn_partial) return launch_hubpc_kernel<2, true>(st, a);
+    switch (mode) {
+    case 0: return launch_hubpc_kernel<0, false>(st, a);
+    case 1: return launch_hubpc_kernel<1, false>(st, a);
+    case 2: return launch_hubpc_kernel<2, false>(st, a);
+    case 3: return launch_hubpc_kernel<3, false>(st, a);
+    case 4: return launch_hubpc_kernel<4, false>(st, a);
+    case 5: return launch_hubpc_kernel<5, false>(st, a);
+    default: return launch_hubpc_kernel<6, false>(st, a);
     }
 }
 
@@ -1140,18 +1529,24 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     } joiner;
     static const int side_env = [] { const char *e = experiment_env("GNNX_SPMM_SIDE"); return e ? atoi(e) : -1; }();   // A/B: 0 never, 1 always
     const bool beside = side_env < 0 ? a.hub_beside != 0 : side_env != 0;
-    if (a.n_hub_rows > 0 && !beside) {
-        const int rc = launch_hub<VEC>(mode, st, a);
-        if (rc != GNNX_OK) return rc;
-    } else if (a.n_hub_rows > 0) {
+    const int32_t n_rest = a.n_hub_rows - a.n_big_rows;   // hub rows of spmm_hub_kernel
+    if (a.n_big_rows > 0 || (n_rest > 0 && beside)) {
         side = side_stream(st);
         GNNX_REQUIRE(side, GNNX_ERR_HIP, "could not create the aggregation's side stream");
         GNNX_HIP_CHECK(hipEventRecord(side->fork, st));
         GNNX_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-        const int rc = launch_hub<VEC>(mode, side->stream, a);
         // from here on every exit path joins the side stream back into the caller's (JoinGuard): an error return must not leave
         // work of this call running beside whatever the caller enqueues next
         joiner.arm(side, st);
+    }
+    if (a.n_big_rows > 0) {
+        // the longest rows -- each a chain of dependent adds, a CU of its own per (row, slab) -- always beside everything else, first:
+        // their workgroups take a whole CU's LDS, the other hub rows' workgroups fill the CUs they leave
+        const int rc = launch_hubpc(mode, side->stream, a);
+        if (rc != GNNX_OK) return rc;
+    }
+    if (n_rest > 0) {
+        const int rc = launch_hub<VEC>(mode, beside ? side->stream : st, a);
         if (rc != GNNX_OK) return rc;
     }
     if (stream) {
@@ -1207,6 +1602,8 @@ int plan_build(gnnx_spmm_plan *plan, const int32_t *d_rowptr, int32_t n_rows, in
         std::vector<int32_t> h_hub(h_rows.size());
         for (size_t i = 0; i < h_rows.size(); i++) h_hub[i] = h_rows[i].x;
         plan->max_hub_degree = h_rows.empty() ? 0 : h_rows[0].y;
+        plan->h_hub_degrees.resize(h_rows.size());
+        for (size_t i = 0; i < h_rows.size(); i++) plan->h_hub_degrees[i] = h_rows[i].y;
         GNNX_HIP_CHECK(hipMalloc(&plan->d_hub_rows, sizeof(int32_t) * h_hub.size()));
         GNNX_HIP_CHECK(hipMemcpyAsync(plan->d_hub_rows, h_hub.data(), sizeof(int32_t) * h_hub.size(), hipMemcpyHostToDevice, st));
         GNNX_HIP_CHECK(hipStreamSynchronize(st));
@@ -1257,7 +1654,22 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
         (void)gnnx_spmm_plan_destroy(plan);
         return rc;
     }
+    (void)gnnx_spmm_plan_set_big_row_threshold(plan, kHubBigRow);
     *plan_out = plan;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_spmm_plan_set_big_row_threshold(gnnx_spmm_plan *plan, int32_t threshold)
+{
+    GNNX_REQUIRE(plan && threshold >= 0, GNNX_ERR_INVALID_ARG, "plan / threshold");
+    plan->big_row_threshold = threshold;
+    plan->n_big_rows = 0;
+    plan->n_big_nnz = 0;
+    for (int32_t d : plan->h_hub_degrees) {   // sorted, longest first
+        if (d <= threshold) break;
+        plan->n_big_rows++;
+        plan->n_big_nnz += d;
+    }
     return GNNX_OK;
 }
 
@@ -1306,7 +1718,7 @@ int64_t bn_sums_stream_waves(int32_t n_rows, int32_t n_feat, const gnnx_spmm_pla
 //   chain: kHubNsPerNeighbour per non-zero of the longest row (one accumulator per feature, the reference's order);
 //   bytes: hub non-zeros x row bytes at kHubBytesPerNs.
 // RMAT 1M / 10M, F = 128: beside (0.92 -> 0.79 ms); RMAT 10M / 100M, F = 256 (28 GB of hub rows): in front (13.59 vs 13.76 ms beside).
-constexpr double kHubNsPerNeighbour = 12.0;   // profiles/r03: 0.75 ms for the 62 k-entry longest row of RMAT 1M / 10M
+constexpr double kHubNsPerNeighbour = 12.0;   // spmm_hub_kernel (the rows up to kHubBigRow)   // profiles/r03: 0.75 ms for the 62 k-entry longest row of RMAT 1M / 10M
 constexpr double kHubBytesPerNs = 7000.0;     // ~7 TB/s on the hub rows of the headline graph
 bool hub_is_chain_bound(int32_t max_hub_degree, int64_t n_hub_nnz, int32_t n_feat, int bytes_per_feature)
 {
@@ -1384,6 +1796,7 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         // Hub kernel beside the row kernel (side stream) or in front of it (same stream)?  Beside, when its time is the dependent-add
         // chain of its longest row (~12 ns per neighbour) rather than its bytes (hub non-zeros x row bytes at ~7 TB/s):
         // RMAT 1M / 10M, F = 128: 0.92 -> 0.79 ms; RMAT 10M / 100M, F = 256 (28 GB of hub rows): in front, 13.59 vs 13.76 ms beside.
+        a.n_big_rows = plan->n_big_rows;
         a.hub_beside = hub_is_chain_bound(plan->max_hub_degree, plan->n_hub_nnz, n_feat, x_bf16 ? 2 : 4);
     }
     hipStream_t st = as_stream(stream);
@@ -1391,6 +1804,10 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
     const bool vec4 = (n_feat % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (x_bf16 ? (reinterpret_cast<uintptr_t>(d_X) & 7u) == 0 : aligned16(d_X)) && aligned16(d_Y) &&
                       aligned16(d_bias) && aligned16(a.pro_mean) && aligned16(a.pro_var) && aligned16(a.pro_gamma) &&
                       aligned16(a.pro_beta);
+    if (x_bf16 || !vec4) a.n_big_rows = 0;   // the producer / consumer kernel reads f32 rows in 16-byte pieces; other rows: spmm_hub_kernel
+    else if (a.n_big_rows > 0)            // what is left for spmm_hub_kernel: is IT bound by its longest row's chain?
+        a.hub_beside = hub_is_chain_bound(plan->h_hub_degrees[(size_t)a.n_big_rows < plan->h_hub_degrees.size() ? a.n_big_rows : 0],
+                                          plan->n_hub_nnz - plan->n_big_nnz, n_feat, 4) || a.n_big_rows == plan->n_split_rows;
     if (x_bf16 && !vec4) {
         // bf16 rows that are not 8-byte pieces (n_feat % 4 != 0 or an unaligned X): LDS-DMA moves one DWORD per lane whatever the
         // load size, so a 2-byte-per-lane ring layout does not exist -- the hub rows stay with the row / streaming kernel (same bits)

@@ -65,6 +65,11 @@ class SpmmPlan:
         capi.call("gnnx_spmm_plan_info", self.h, C.byref(a), C.byref(b))
         self.n_split_rows, self.n_hub_nnz = a.value, b.value   # hub rows (degree > chunk) and their non-zeros
 
+    def set_big_row_threshold(self, threshold):
+        """Hub rows longer than `threshold` take the producer / consumer hub kernel (default 8192; same bits for every value)."""
+        capi.call("gnnx_spmm_plan_set_big_row_threshold", self.h, int(threshold))
+        return self
+
     def __del__(self):
         try:
             capi.lib().gnnx_spmm_plan_destroy(self.h)
@@ -169,11 +174,16 @@ class CsrGraph:
         capi.call("gnnx_degree_norm_f32", _ptr(self.rowptr), _ptr(self.colidx), self.n, None, _ptr(s), _ptr(norm), _stream())
         return s, norm
 
-    def make_plans(self, chunk, max_feat):
-        """Load-balancing plans for power-law rows (forward CSR and transposed CSR)."""
+    def make_plans(self, chunk, max_feat, big_rows=None):
+        """Load-balancing plans for power-law rows (forward CSR and transposed CSR).  big_rows: the threshold above which a hub row
+        takes the producer / consumer kernel (SpmmPlan.set_big_row_threshold; None = the library's default)."""
         self.plan = SpmmPlan(self.rowptr, chunk, max_feat)
         if self.rowptr_t is not None:
             self.plan_t = SpmmPlan(self.rowptr_t, chunk, max_feat)
+        if big_rows is not None:
+            for pl in (self.plan, self.plan_t):
+                if pl is not None:
+                    pl.set_big_row_threshold(big_rows)
         return self.plan, self.plan_t
 
 

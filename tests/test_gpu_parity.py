@@ -261,6 +261,61 @@ def test_plan_hub_rows_keep_the_reference_order(env, n, e, F, chunk):
     assert torch.equal(ops.aggregate_fwd(g, dev(env, H), dev(env, bias)), out)
 
 
+@pytest.mark.parametrize("n,e,F,chunk,big", [(30000, 600000, 256, 256, 0), (30000, 600000, 256, 64, 700), (30000, 600000, 128, 64, 0),
+                                             (20000, 400000, 100, 64, 0), (20000, 400000, 36, 64, 0), (8000, 200000, 320, 128, 300),
+                                             (8000, 200000, 64, 16, 0), (3000, 200000, 256, 16, 0)])
+def test_hub_rows_on_the_producer_consumer_kernel(env, n, e, F, chunk, big):
+    """spmm_hubpc_kernel -- the longest hub rows: one consumer wavefront adds (the reference's order, one accumulator per feature),
+    three producer wavefronts keep the row's slices coming through a 128 KiB LDS ring -- forced onto EVERY hub row (big = 0) or the
+    rows above `big` (the rest on spmm_hub_kernel): every mode against the oracle / the unplanned kernels, BIT FOR BIT: forward
+    (rowscale + bias), backward (per-entry norm), beta = 1, ReLU epilogue, column scale, values + column scale, the BatchNorm / ReLU
+    prologue, the BatchNorm-backward sums; rows of every length (a few neighbours to tens of thousands: shorter than the ring, sub-chunk
+    tails, rows longer than the ring many times over), full and ragged slabs, strided rows, run to run."""
+    ops, torch = env["ops"], env["torch"]
+    src, dst, rp, ci, g = make_graph(env, n, e, seed=270 + F + chunk)
+    deg = np.diff(rp)
+    assert (deg > max(chunk, big)).sum() >= 4, "test graph should have hub rows above the threshold"
+    s, norm = oracle.degree_norm(rp, ci, n)
+    H = synth.uniform_pm1(41, (n, F))
+    bias = synth.uniform_pm1(42, (F,))
+    g.make_plans(chunk=chunk, max_feat=F, big_rows=big)
+    ref = oracle.aggregate_fwd(rp, ci, H, norm, bias)
+    Hd, bd = dev(env, H), dev(env, bias)
+    out = ops.aggregate_fwd(g, Hd, bd)
+    assert same(host(out), ref), "forward"
+    G = synth.uniform_pm1(43, (n, F))
+    Gd = dev(env, G)
+    rT, cT = oracle.csr_transpose(rp, ci, n)
+    assert same(host(ops.aggregate_bwd(g, Gd)), oracle.aggregate_bwd(rT, cT, G, norm)), "backward"
+    acc0 = synth.uniform_pm1(44, (n, F))
+    assert torch.equal(ops.aggregate_bwd(g, Gd, out=dev(env, acc0), beta=1.0), ops.aggregate_bwd(g, Gd, out=dev(env, acc0), beta=1.0, use_plan=False))
+    assert torch.equal(ops.aggregate_fwd(g, Hd, bd, relu_out=True), ops.aggregate_fwd(g, Hd, bd, relu_out=True, use_plan=False)), "ReLU epilogue"
+    assert torch.equal(ops.aggregate_fwd_sym(g, Hd, bd), ops.aggregate_fwd_sym(g, Hd, bd, use_plan=False)), "colscale"
+    vals = dev(env, synth.uniform_pm1(45, (len(ci),)))
+    assert torch.equal(ops.spmm(g.rowptr, g.colidx, Hd, vals=vals, colscale=g.s, rowscale=g.norm, plan=g.plan),
+                       ops.spmm(g.rowptr, g.colidx, Hd, vals=vals, colscale=g.s, rowscale=g.norm)), "vals + colscale"
+    # the BatchNorm / ReLU prologue on every gathered row (modes 3, 4, 5)
+    mean, var = ops.bn_stats(Hd)
+    gamma, beta = dev(env, synth.uniform_pm1(46, (F,)) + 1.5), dev(env, synth.uniform_pm1(47, (F,), scale=0.3))
+    for bn, relu_in in (((mean, var, gamma, beta, 1e-5), True), ((mean, var, gamma, beta, 1e-5), False), (None, True)):
+        assert torch.equal(ops.aggregate_fwd(g, Hd, bd, bn=bn, relu_in=relu_in), ops.aggregate_fwd(g, Hd, bd, bn=bn, relu_in=relu_in, use_plan=False)), (bn is None, relu_in)
+    if F % 4 == 0 and F > 64:   # BatchNorm-backward sums riding in the backward aggregation: same dY, sums to rounding, run to run
+        dY1, dg1, db1 = ops.aggregate_bwd_bn_sums(g, Gd, Hd, mean, var, gamma, beta)
+        dY0, dg0, db0 = ops.aggregate_bwd_bn_sums(g, Gd, Hd, mean, var, gamma, beta, use_plan=False)
+        assert torch.equal(dY1, dY0) and torch.equal(dY1, ops.aggregate_bwd(g, Gd))
+        tol = 1e-5 * float(dY1.abs().double().sum(0).max()) * 4
+        assert float((dg1 - dg0).abs().max()) <= tol and float((db1 - db0).abs().max()) <= tol
+        dY2, dg2, db2 = ops.aggregate_bwd_bn_sums(g, Gd, Hd, mean, var, gamma, beta)
+        assert torch.equal(dg2, dg1) and torch.equal(db2, db1)
+        Hp = torch.zeros((n, F + 12), dtype=torch.float32, device=env["dev"])
+        Hp[:, :F] = Hd
+        Yp = torch.zeros((n, F + 4), dtype=torch.float32, device=env["dev"])
+        ops.aggregate_fwd(g, Hp[:, :F], bd, out=Yp[:, :F])
+        assert torch.equal(Yp[:, :F], out) and float(Yp[:, F:].abs().max()) == 0.0, "strided rows"
+    for _ in range(3):
+        assert torch.equal(ops.aggregate_fwd(g, Hd, bd), out), "run to run"
+
+
 @pytest.mark.parametrize("n,e,F,chunk,relu,affine", [(30000, 600000, 256, 256, True, True), (30000, 600000, 128, 64, True, True),
                                                      (20000, 400000, 100, 64, True, False), (20000, 300000, 256, 0, False, True)])
 def test_backward_aggregation_with_batchnorm_sums(env, n, e, F, chunk, relu, affine):
