@@ -39,13 +39,14 @@ struct gnnx_spmm_plan {
     int32_t chunk = 0;
     int32_t n_split_rows = 0;   // rows with degree > chunk (the hub rows)
     int64_t n_hub_nnz = 0;      // their non-zeros
+    int64_t nnz = 0;            // all non-zeros (rowptr[n_rows])
     int32_t max_hub_degree = 0;
-    // the first n_big_rows of the list (degree > big_row_threshold) go to the producer / consumer kernel (spmm_hubpc_kernel): rows
-    // whose time is their own chain of dependent adds, not their bytes
-    int32_t big_row_threshold = 0;
-    int32_t n_big_rows = 0;
-    int64_t n_big_nnz = 0;
-    std::vector<int32_t> h_hub_degrees;  // host copy of the sorted degrees (gnnx_spmm_plan_set_big_row_threshold)
+    // the longest rows of the list go to the producer / consumer kernel (spmm_hubpc_kernel): rows whose time is their own chain of
+    // dependent adds, not their bytes.  How many is decided per call (big_rows_for: it depends on the feature width) unless a caller
+    // fixed the threshold (gnnx_spmm_plan_set_big_row_threshold, >= 0)
+    int32_t big_row_threshold = -1;
+    std::vector<int32_t> h_hub_degrees;  // host copy of the sorted degrees, longest first
+    std::vector<int64_t> h_hub_prefix;   // h_hub_prefix[k] = non-zeros of the k longest rows
     int32_t *d_hub_rows = nullptr;  // [n_split_rows] the hub rows, longest first: work list of the hub kernels
     unsigned long long *d_counters = nullptr;
     // non-zero-balanced row blocks for the streaming kernel: block k owns rows [d_block_starts[k], [k+1])
@@ -75,6 +76,7 @@ struct SpmmArgs {
     int32_t n_hub_rows;
     int32_t hub_beside;      // run the hub kernel on the side stream, beside the row kernel (its time is one row's add chain)
     int32_t n_big_rows;      // the first n_big_rows hub rows take the producer / consumer kernel (f32 rows of 16-byte pieces)
+    int32_t pc_experiment;   // EXPERIMENTS build only (GNNX_PC_EXP): 1 = the consumer does not wait for the producers (timing only)
     // row blocks of the streaming kernel (plan): nullptr => fixed blocks of StreamCfg<G>::R rows
     const int32_t *block_starts;
     int32_t n_blocks;
@@ -613,9 +615,9 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int kHubSlab = 64;   // features per work item
 constexpr int kHubSub = 16;    // neighbours per sub-chunk: 4 KiB of LDS
 constexpr int kHubChunk = 64;  // neighbours per index chunk
-// hub rows longer than this take the producer / consumer kernel (spmm_hubpc_kernel): at 12 ns per neighbour a longer row's chain in
-// spmm_hub_kernel is more than ~0.1 ms, which is what a rank's share of the other hub rows' bytes takes on an 8-way shard
-constexpr int kHubBigRow = 8192;
+// no row shorter than this takes the producer / consumer kernel (spmm_hubpc_kernel): its start-up (flags, first index chunks, a CU
+// of its own) is worth it only for a chain of thousands of adds
+constexpr int kHubBigRowMin = 4096;
 
 template <int OFF, class T>
 __device__ __forceinline__ void hub_lds_read(T &dst, uint32_t addr)
@@ -893,41 +895,57 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
 }
 
 // ---- the LONGEST hub rows: producer / consumer form ---------------------------------------------------------------------
-// A hub row's time in spmm_hub_kernel is one wavefront's instruction stream per neighbour: the LDS-DMA issue (a quarter of a
-// ~60-cycle wave-instruction), the index read, the address mad, the value read and the add -- ~29 cycles = 12 ns per neighbour, whatever is in
-// flight.  On the whole graph that hides behind the bytes of the other hub rows; on one rank's shard of it (1/8 of the rows, the
+// In spmm_hub_kernel a (row, slab) is ONE wavefront that issues the DMAs, reads the ring and adds, with 32 KiB in flight: ~12 ns per
+// neighbour.  On the whole graph that hides behind the bytes of the other hub rows; on one rank's shard of it (1/8 of the rows, the
 // same longest row) or on a small graph the longest rows ARE the aggregation's time (a 250 k-entry row: 3.0 ms).  The sum itself
-// cannot be split -- one accumulator per feature, the reference's order -- so everything else is taken out of its wavefront:
-//   * a workgroup = (row, 64-feature slab) = ONE consumer wavefront + hubpc::NP producer wavefronts, a CU of its own (the ring
-//     takes 128 KiB of its LDS: a CU can only feed ~3 ns per neighbour if ~2 us of memory latency are in flight);
-//   * producers own the index chunks (64 neighbours) round-robin: index chunk -> LDS by DMA, column -> address, the slab's slices
-//     of 16 neighbours per ring slot by LDS-DMA (+ the per-entry values / gathered column scales of those 16 into small rings),
-//     up to LAS sub-chunks in flight each; when a sub-chunk has LANDED (the producer's own vmcnt) its count goes to an LDS flag;
-//   * the consumer reads a landed slot with 8 ds_read2st64_b32 (neighbours e, e + 1 of its feature in one instruction), the next
-//     slot's reads in flight while this slot's 16 adds run -- strictly in descending column order, separately rounded: the same bits
-//     as every other path -- and publishes the slots it has left (the producers' back-pressure).  ~6-7 cycles per neighbour.
+// cannot be split -- one accumulator per feature, the reference's order -- so everything else is taken out of its wavefront and the
+// row is spread over more CUs:
+//   * a workgroup = (row, SLAB-feature slab) = ONE consumer wavefront + hubpc::NP producer wavefronts, a CU of its own (the ring takes
+//     128 KiB of its LDS);
+//   * producers own the index chunks (64 neighbours) round-robin: index chunk -> LDS by DMA, column -> address, the slab's slices of
+//     16 neighbours per ring slot by LDS-DMA (+ per index chunk the 64 per-entry values / gathered column scales into small
+//     rings), up to LAS sub-chunks in flight each; when a sub-chunk has LANDED (the producer's own vmcnt) its count goes to an LDS flag;
+//   * the consumer reads a landed slot with 8 two-address LDS reads (neighbours e, e + 1 of its feature in one instruction), the
+//     next slot's reads in flight while this slot's 16 adds run -- strictly in descending column order, separately rounded: the same
+//     bits as every other path -- and publishes the slots it has left (the producers' back-pressure).  ~6-7 cycles per neighbour.
 // Flags are LDS words (ds_write / ds_read of one CU's LDS unit are processed in order; a producer writes its flag after the
-// s_waitcnt that covers the DMA).  No barrier after the start, no spin without progress: a producer blocks only when nothing of
+// s_waitcnt that covers the DMA).  No barrier after the start, no wait without progress: a producer blocks only when nothing of
 // its own is in flight and the ring is full, the consumer only on a sub-chunk that is not there yet.
 namespace hubpc {
-constexpr int NP = 3;      // producer wavefronts
-constexpr int LAS = 10;    // sub-chunks in flight per producer
-constexpr int S = 32;      // ring slots (one sub-chunk of 16 neighbours x 256 B each): 128 KiB
-constexpr int IPS = 4;     // data DMA instructions per sub-chunk
-constexpr int NCX = 3;     // index chunks fetched ahead per producer (4 NCX >= LAS + 2)
-constexpr int NI = NCX + 1;
-constexpr int SUBF = kHubSub * kHubSlab;   // floats per ring slot
-constexpr int kSpinCap = 1 << 22;          // polls of an LDS flag before a wait gives up (seconds; a wait lasts microseconds)
-static_assert((S & (S - 1)) == 0 && S > NP * LAS, "ring: a power of two, and room for everything in flight plus the slot being added");
-static_assert(4 * NCX >= LAS + 2, "an index chunk has landed when its first sub-chunk is issued (see the producer loop)");
-template <int MODE> struct Lay {
-    static constexpr int IPSX = IPS + (has_val(MODE) ? 1 : 0) + (has_sc(MODE) ? 1 : 0);   // VMEM operations per sub-chunk
-    static constexpr int VR = S * SUBF;                              // [S][16] per-entry values
-    static constexpr int SR = VR + (has_val(MODE) ? S * kHubSub : 0);   // [S][16] gathered column scales
-    static constexpr int IR = SR + (has_sc(MODE) ? S * kHubSub : 0);    // [NP][NI][64] column indices
-    static constexpr int FL = IR + NP * NI * kHubChunk;              // landed[NP], consumed
+constexpr int NP = 3;                 // producer wavefronts
+constexpr int kSpinCap = 1 << 22;     // polls of an LDS flag before a wait gives up (seconds; a wait lasts microseconds)
+constexpr int kBigSlab = 16;          // features per workgroup
+constexpr int kMaxLdsBytes = 152000;  // the largest workgroup LDS footprint this file uses (validated: 151 584 bytes)
+// SLAB features per workgroup: 16 -- a row of F features is spread over F / 16 CUs.  While the row kernel streams beside it every
+// CU keeps ~128 KiB in flight and the memory system serves them at about the same rate each (~30 GB/s per CU at 8 TB/s over 256
+// CUs), so a row's rate is the number of CUs it sits on: with 64-feature slabs the 62 k-entry row of RMAT 1M / 10M took 0.51 ms
+// (8 ns per neighbour: its two CUs' share of the bytes, not the add chain); 64-byte slices put it on 8.
+template <int MODE, int SLAB> struct Cfg {
+    static constexpr int SB = SLAB * 4;                  // bytes of a neighbour's slice
+    static constexpr int EPI = 1024 / SB;                // neighbours per DMA wave-instruction
+    static constexpr int LPE = 64 / EPI;                 // lanes per neighbour
+    static constexpr int IPS = kHubSub / EPI;            // DMA instructions per sub-chunk of 16 neighbours
+    static constexpr int SUBF = kHubSub * SLAB;          // floats per ring slot
+    // ring slots: 128 KiB -- 64 KiB when per-entry values AND column scales ride along (the rare weighted Mode SYM): with the full ring
+    // that layout reaches 156 KiB, and workgroup LDS addresses above ~152 KB misbehaved on the MI355X boxes of this pool (wrong words
+    // from producers 1 and 2, whose index rings sat there; every layout up to 151 584 bytes is exact) -- kMaxLdsBytes keeps all of them below
+    static constexpr bool kBoth = has_val(MODE) && has_sc(MODE);
+    static constexpr int S = (kBoth ? 16384 : 32768) / SUBF;
+    static constexpr int LAS = SLAB == 64 ? (kBoth ? 5 : 10) : (kBoth ? 16 : 32);     // sub-chunks in flight per producer
+    static constexpr int NCX = (LAS + 2 + 3) / 4;        // index chunks fetched ahead per producer (4 NCX >= LAS + 2)
+    static constexpr int NI = NCX < 4 ? 4 : 16;          // index ring slots per producer (a power of two > NCX)
+    static constexpr int XC = 1 + (has_val(MODE) ? 1 : 0) + (has_sc(MODE) ? 1 : 0);   // VMEM operations per index chunk besides the slices
+    static constexpr int VR = S * SUBF;                                // [S][16] per-entry values (written 64 at a time, by index chunk)
+    static constexpr int SR = VR + (has_val(MODE) ? S * kHubSub : 0);  // [S][16] gathered column scales
+    static constexpr int IR = SR + (has_sc(MODE) ? S * kHubSub : 0);   // [NP][NI][64] column indices
+    static constexpr int FL = IR + NP * NI * kHubChunk;                // landed[NP], consumed
     static constexpr int LDS_FLOATS = FL + 8;
-    static_assert((LAS - 1) * IPSX + NCX <= 63, "vmcnt is a 6-bit counter");
+    static_assert(SLAB == 64 || SLAB == 16, "slice = 256 or 64 bytes");
+    static_assert(LDS_FLOATS * 4 <= kMaxLdsBytes, "stay inside the validated LDS range");
+    static_assert((S & (S - 1)) == 0 && S % 4 == 0 && S > NP * LAS, "ring: a power of two, and room for everything in flight plus the slot being added");
+    static_assert(4 * NCX >= LAS + 2 && NI > NCX, "an index chunk has landed when its first sub-chunk is issued (see the producer loop)");
+    static_assert((LAS - 1) * IPS + (LAS / 4 + 2) * XC <= 63, "vmcnt is a 6-bit counter");
+    static_assert(LAS <= 32, "wait_vm_sub");
 };
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -939,37 +957,46 @@ __device__ __forceinline__ int32_t flag_read(uint32_t addr)   // one LDS word, w
     return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ __forceinline__ void flag_write(uint32_t addr, int32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
-template <int K> __device__ __forceinline__ void wait_vm_sub(int k)   // s_waitcnt vmcnt(k * IPSX): the k youngest sub-chunks stay in flight
+// s_waitcnt vmcnt(k * K): the k youngest sub-chunks (K slice DMAs each) stay in flight; k < LAS
+template <int K, int LAS> __device__ __forceinline__ void wait_vm_sub(int k)
 {
-#define GNNX_PC_CASE(i) case i: hub_wait_vm<(i) * K>(); break;
+#define GNNX_PC_CASE(i) case i: if constexpr ((i) < LAS) hub_wait_vm<((i) < LAS ? (i) : 0) * K>(); break;
     switch (k) {
-        GNNX_PC_CASE(0) GNNX_PC_CASE(1) GNNX_PC_CASE(2) GNNX_PC_CASE(3) GNNX_PC_CASE(4) GNNX_PC_CASE(5) GNNX_PC_CASE(6) GNNX_PC_CASE(7) GNNX_PC_CASE(8)
-    default: hub_wait_vm<(LAS - 1) * K>(); break;
+        GNNX_PC_CASE(0) GNNX_PC_CASE(1) GNNX_PC_CASE(2) GNNX_PC_CASE(3) GNNX_PC_CASE(4) GNNX_PC_CASE(5) GNNX_PC_CASE(6) GNNX_PC_CASE(7)
+        GNNX_PC_CASE(8) GNNX_PC_CASE(9) GNNX_PC_CASE(10) GNNX_PC_CASE(11) GNNX_PC_CASE(12) GNNX_PC_CASE(13) GNNX_PC_CASE(14) GNNX_PC_CASE(15)
+        GNNX_PC_CASE(16) GNNX_PC_CASE(17) GNNX_PC_CASE(18) GNNX_PC_CASE(19) GNNX_PC_CASE(20) GNNX_PC_CASE(21) GNNX_PC_CASE(22) GNNX_PC_CASE(23)
+        GNNX_PC_CASE(24) GNNX_PC_CASE(25) GNNX_PC_CASE(26) GNNX_PC_CASE(27) GNNX_PC_CASE(28) GNNX_PC_CASE(29) GNNX_PC_CASE(30) GNNX_PC_CASE(31)
+    default: hub_wait_vm<0>(); break;
     }
 #undef GNNX_PC_CASE
 }
-// own sequence number u of a producer -> the row's sub-chunk; and back
+// own sequence number u of producer p -> the row's sub-chunk: producers own the index chunks (4 sub-chunks) round-robin
 __device__ __forceinline__ int32_t t_of(int32_t p, int32_t u) { return 4 * (p + (u >> 2) * NP) + (u & 3); }
 }  // namespace hubpc
 
-template <int MODE, bool SUMS>
+template <int MODE, bool SUMS, int SLAB>
 __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmArgs a, const int32_t *hub_rows, int32_t n_slabs)
 {
     using namespace hubpc;
-    using L = Lay<MODE>;
+    using K = Cfg<MODE, SLAB>;
+    constexpr int S = K::S, LAS = K::LAS, IPS = K::IPS, NI = K::NI, NCX = K::NCX, SUBF = K::SUBF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int32_t ordinal = (int32_t)(blockIdx.x / n_slabs);
     const int32_t row = __builtin_amdgcn_readfirstlane(hub_rows[ordinal]);
-    const int32_t f_slab = (int32_t)(blockIdx.x % n_slabs) * kHubSlab;
+    int32_t sidx = (int32_t)(blockIdx.x % n_slabs);
+    // workgroups b and b + 8 land on one XCD (observed round-robin dispatch; only speed depends on it): give them the two 64-byte
+    // slabs of one 128-byte line
+    if (SLAB == 16 && (n_slabs & 15) == 0) sidx = (sidx & ~15) | ((sidx & 7) << 1) | ((sidx >> 3) & 1);
+    const int32_t f_slab = sidx * SLAB;
     const int32_t lo = __builtin_amdgcn_readfirstlane(a.rowptr[row]);
     const int32_t hi = __builtin_amdgcn_readfirstlane(a.rowptr[row + 1]);
     const int32_t total = hi - lo;
     const int32_t nsub = (total + kHubSub - 1) / kHubSub;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void_t *)lds;
-    const uint32_t fl0 = lds0 + (uint32_t)L::FL * 4u;   // landed[p] at fl0 + 4 p, consumed at fl0 + 4 NP
-    if (threadIdx.x < 8) reinterpret_cast<int32_t *>(lds + L::FL)[threadIdx.x] = 0;
+    const uint32_t fl0 = lds0 + (uint32_t)K::FL * 4u;   // landed[p] at fl0 + 4 p, consumed at fl0 + 4 NP
+    if (threadIdx.x < 8) reinterpret_cast<int32_t *>(lds + K::FL)[threadIdx.x] = 0;
     __syncthreads();
 
     if (wv > 0) {
@@ -981,14 +1008,14 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         if (n_own_chunks > 0 && p + (n_own_chunks - 1) * NP == nchunk - 1) n_own -= 4 * nchunk - nsub;
         // DMA source of this lane: neighbour sub_e of the instruction, 4 features at foff (lanes past the row's width re-read the
         // slab's first piece; their LDS words are never stored)
-        const int sub_e = lane >> 4;
-        int32_t foff = f_slab + (lane & 15) * 4;
+        const int sub_e = lane / K::LPE;
+        int32_t foff = f_slab + (lane % K::LPE) * 4;
         if (foff + 4 > a.n_feat) foff = f_slab;
         const char *xsrc = reinterpret_cast<const char *>(a.X + foff);
         const uint32_t row_bytes = (uint32_t)(a.ldx * (int64_t)sizeof(float));
-        float *iring = lds + L::IR + p * NI * kHubChunk;
-        const uint32_t col_lane = lds0 + (uint32_t)(L::IR + p * NI * kHubChunk + sub_e) * 4u;
-        const uint32_t col16 = lds0 + (uint32_t)(L::IR + p * NI * kHubChunk + (lane & 15)) * 4u;
+        float *iring = lds + K::IR + p * NI * kHubChunk;
+        const uint32_t col_lane = lds0 + (uint32_t)(K::IR + p * NI * kHubChunk + sub_e) * 4u;
+        const uint32_t col64 = lds0 + (uint32_t)(K::IR + p * NI * kHubChunk + lane) * 4u;
 
         auto idx_dma = [&](int32_t j) {   // own index chunk j -> its ring slot: lane i brings neighbour chunk * 64 + i (clamped into the row)
             const int32_t c = p + j * NP;
@@ -996,33 +1023,37 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
             q = q < lo ? lo : q;
             __builtin_amdgcn_global_load_lds(a.colidx + q, (lds_void_t *)(iring + (j & (NI - 1)) * kHubChunk), 4, 0, 0);
         };
-        auto issue = [&](int32_t u) {     // own sub-chunk u: columns from the index ring, slices (+ values / column scales) into ring slot t % S
+        // own sub-chunk u: columns from the index ring, slices into ring slot t % S; in front of an index chunk's first sub-chunk the
+        // chunk's 64 per-entry values / gathered column scales (they land before it does: VMEM returns in order)
+        auto issue = [&](int32_t u) {
             const int32_t t = t_of(p, u);
             const int islot = (u >> 2) & (NI - 1), k0 = (u & 3) * kHubSub, slot = t & (S - 1);
-            int32_t c[IPS], c16 = 0;
+            int32_t c[IPS], c64 = 0;
             const uint32_t ca = col_lane + (uint32_t)(islot * kHubChunk + k0) * 4u;
-            hub_lds_read<0 * 16>(c[0], ca);
-            hub_lds_read<1 * 16>(c[1], ca);
-            hub_lds_read<2 * 16>(c[2], ca);
-            hub_lds_read<3 * 16>(c[3], ca);
-            if constexpr (has_sc(MODE)) hub_lds_read<0>(c16, col16 + (uint32_t)(islot * kHubChunk + k0) * 4u);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c16)::"memory");
+#define GNNX_PC_RC(i) if constexpr ((i) < IPS) hub_lds_read<(i) * K::EPI * 4>(c[(i) < IPS ? (i) : 0], ca)
+            GNNX_PC_RC(0); GNNX_PC_RC(1); GNNX_PC_RC(2); GNNX_PC_RC(3);
+#undef GNNX_PC_RC
+            if constexpr (has_sc(MODE)) {
+                if ((u & 3) == 0) hub_lds_read<0>(c64, col64 + (uint32_t)(islot * kHubChunk) * 4u);
+            }
+            if constexpr (IPS == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c64)::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c64)::"memory");
+            if constexpr (has_val(MODE) || has_sc(MODE)) {
+                if ((u & 3) == 0) {   // slots t .. t + 3 of the small rings: 64 words
+                    if constexpr (has_val(MODE)) {
+                        int32_t q = hi - 1 - (t * kHubSub + lane);
+                        q = q < lo ? lo : q;
+                        __builtin_amdgcn_global_load_lds(a.vals + q, (lds_void_t *)(lds + K::VR + slot * kHubSub), 4, 0, 0);
+                    }
+                    if constexpr (has_sc(MODE))
+                        __builtin_amdgcn_global_load_lds(a.colscale + c64, (lds_void_t *)(lds + K::SR + slot * kHubSub), 4, 0, 0);
+                }
+            }
             float *dst = lds + slot * SUBF;
 #pragma unroll
             for (int i = 0; i < IPS; i++) {
                 const char *srcp = xsrc + (uint64_t)(uint32_t)c[i] * row_bytes;
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(srcp), (lds_void_t *)(dst + i * 256), 16, 0, 0);
-            }
-            if constexpr (has_val(MODE) || has_sc(MODE)) {
-                if (lane < kHubSub) {   // 16 lanes: one word per neighbour of the sub-chunk
-                    if constexpr (has_val(MODE)) {
-                        int32_t q = hi - 1 - (t * kHubSub + lane);
-                        q = q < lo ? lo : q;
-                        __builtin_amdgcn_global_load_lds(a.vals + q, (lds_void_t *)(lds + L::VR + slot * kHubSub), 4, 0, 0);
-                    }
-                    if constexpr (has_sc(MODE))
-                        __builtin_amdgcn_global_load_lds(a.colscale + c16, (lds_void_t *)(lds + L::SR + slot * kHubSub), 4, 0, 0);
-                }
             }
         };
 
@@ -1031,9 +1062,10 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         hub_wait_vm<0>();
         int32_t issued = 0, landed = 0, consumed = 0, spins = 0;
         while (landed < n_own) {
-            // put in flight whatever the window (LAS) and the ring (a slot is free once the consumer has left sub-chunk t - S) allow
+            // put in flight whatever the window (LAS) and the ring allow: slot t % S is free once the consumer has left sub-chunk
+            // t - S (an index chunk's first sub-chunk also writes the small rings of the three behind it)
             while (issued < n_own && issued - landed < LAS) {
-                const int32_t need = t_of(p, issued) - S + 1;
+                const int32_t need = t_of(p, issued) + (((issued & 3) == 0 && K::XC > 1) ? 3 : 0) - S + 1;
                 if (need > consumed) {
                     consumed = flag_read(fl0 + 4u * NP);
                     if (need > consumed) break;
@@ -1041,7 +1073,7 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
                 issue(issued);
                 // the index chunk NCX ahead, behind the first sub-chunk of every own chunk: by the time its first sub-chunk is issued
                 // (LAS window: at least 2 sub-chunks issued after this DMA have landed, VMEM returns in order) it is in LDS, and
-                // the slot it overwrites (own chunk - 1) has been read to the end
+                // the slot it overwrites (an own chunk NI - NCX back) has been read to the end
                 if ((issued & 3) == 0) idx_dma((issued >> 2) + NCX);
                 issued++;
             }
@@ -1051,7 +1083,7 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
                 continue;
             }
             spins = 0;
-            wait_vm_sub<L::IPSX>(issued - landed - 1);   // own sub-chunk `landed` is in LDS (index DMAs in between only make the wait stricter)
+            wait_vm_sub<IPS, LAS>(issued - landed - 1);   // own sub-chunk `landed` is in LDS (chunk-level DMAs in between only make the wait stricter)
             landed++;
             flag_write(fl0 + 4u * (uint32_t)p, landed);
         }
@@ -1060,38 +1092,58 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
     }
 
     // ---------------------------------------------------------------------- consumer
-    const int32_t f = f_slab + lane;
-    const bool active = f < a.n_feat;
+    const int32_t f = f_slab + (lane & (SLAB - 1));
+    const bool active = lane < SLAB && f < a.n_feat;
     const ProConst<1> pc = pro_load<1, MODE>(a, active ? f : 0, active);
-    const uint32_t ring_lane = lds0 + (uint32_t)lane * 4u;
+    const uint32_t ring_lane = lds0 + (uint32_t)(lane & (SLAB - 1)) * 4u;
     struct Set {
         v2f d[8];
         v4f vv[4], sv[4];
         int32_t fl;
     };
     constexpr int NREADS = 8 + (has_val(MODE) ? 4 : 0) + (has_sc(MODE) ? 4 : 0) + 1;   // LDS operations of one issue_reads
-    constexpr bool PIPE = NREADS <= 15;                                                 // lgkmcnt is a 4-bit counter
     // what sub-chunk t needs: producer (t / 4) % NP has landed own sub-chunk 4 ((t / 4) / NP) + t % 4
     auto flag_of = [&](int32_t t) { return fl0 + 4u * (uint32_t)((t >> 2) % NP); };
     auto need_of = [&](int32_t t) { return 4 * ((t >> 2) / NP) + (t & 3) + 1; };
-    auto issue_reads = [&](Set &s, int32_t t) {   // slot t % S -> registers; with it the flag sub-chunk t + 2 will be checked against
-        const uint32_t ad = ring_lane + (uint32_t)(t & (S - 1)) * (uint32_t)(SUBF * 4);
-#define GNNX_PC_R2(i) asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(s.d[i]) : "v"(ad), "i"(2 * (i)), "i"(2 * (i) + 1) : "memory")
-        GNNX_PC_R2(0); GNNX_PC_R2(1); GNNX_PC_R2(2); GNNX_PC_R2(3); GNNX_PC_R2(4); GNNX_PC_R2(5); GNNX_PC_R2(6); GNNX_PC_R2(7);
-#undef GNNX_PC_R2
-        if constexpr (has_val(MODE)) {   // the 16 per-entry values: the same 64 bytes to every lane (broadcast reads)
-            const uint32_t va = lds0 + (uint32_t)(L::VR + (t & (S - 1)) * kHubSub) * 4u;
-#define GNNX_PC_R4(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.vv[i]) : "v"(va), "i"(16 * (i)) : "memory")
-            GNNX_PC_R4(0); GNNX_PC_R4(1); GNNX_PC_R4(2); GNNX_PC_R4(3);
-#undef GNNX_PC_R4
-        }
-        if constexpr (has_sc(MODE)) {
-            const uint32_t sa = lds0 + (uint32_t)(L::SR + (t & (S - 1)) * kHubSub) * 4u;
-#define GNNX_PC_R4(i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(s.sv[i]) : "v"(sa), "i"(16 * (i)) : "memory")
-            GNNX_PC_R4(0); GNNX_PC_R4(1); GNNX_PC_R4(2); GNNX_PC_R4(3);
-#undef GNNX_PC_R4
-        }
-        asm volatile("ds_read_b32 %0, %1" : "=v"(s.fl) : "v"(flag_of(t + 2)) : "memory");
+    // The LDS reads of slot t % S (with them the flag sub-chunk t + 2 will be checked against), one instruction at a time: step()
+    // places them BETWEEN the adds of an earlier sub-chunk -- a dependent v_add_f32 issues every ~13 cycles, the reads (and the
+    // scalar bookkeeping) ride in the gaps.  neighbours e, e + 1 of this lane's feature come in one instruction: slices are 256 bytes
+    // apart (read2st64) or 64 (read2, dword offsets).
+    struct Rd {
+        uint32_t ad, va, sa, fa;
+    };
+    auto rd_of = [&](int32_t t) {
+        Rd r;
+        r.ad = ring_lane + (uint32_t)(t & (S - 1)) * (uint32_t)(SUBF * 4);
+        r.va = lds0 + (uint32_t)(K::VR + (t & (S - 1)) * kHubSub) * 4u;
+        r.sa = lds0 + (uint32_t)(K::SR + (t & (S - 1)) * kHubSub) * 4u;
+        r.fa = flag_of(t + 2);
+        return r;
+    };
+#define GNNX_PC_R2(s, r, i)                                                                                                                  \
+    do {                                                                                                                                     \
+        if constexpr (SLAB == 64)                                                                                                            \
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"((s).d[i]) : "v"((r).ad), "i"(2 * (i)), "i"(2 * (i) + 1) : "memory"); \
+        else                                                                                                                                 \
+            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"((s).d[i]) : "v"((r).ad), "i"(32 * (i)), "i"(32 * (i) + 16) : "memory"); \
+    } while (0)
+#define GNNX_PC_RV(s, r, i)                                                                                                    \
+    do {                                                                                                                       \
+        if constexpr (has_val(MODE)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"((s).vv[i]) : "v"((r).va), "i"(16 * (i)) : "memory"); \
+    } while (0)
+#define GNNX_PC_RS(s, r, i)                                                                                                    \
+    do {                                                                                                                       \
+        if constexpr (has_sc(MODE)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"((s).sv[i]) : "v"((r).sa), "i"(16 * (i)) : "memory");  \
+    } while (0)
+#define GNNX_PC_RF(s, r) asm volatile("ds_read_b32 %0, %1" : "=v"((s).fl) : "v"((r).fa) : "memory")
+    auto issue_reads = [&](Set &s, int32_t t) {   // all of them at once (the first sub-chunk)
+        const Rd r = rd_of(t);
+        GNNX_PC_R2(s, r, 0); GNNX_PC_R2(s, r, 1); GNNX_PC_R2(s, r, 2); GNNX_PC_R2(s, r, 3);
+        GNNX_PC_R2(s, r, 4); GNNX_PC_R2(s, r, 5); GNNX_PC_R2(s, r, 6); GNNX_PC_R2(s, r, 7);
+        GNNX_PC_RF(s, r);
+        GNNX_PC_RV(s, r, 0); GNNX_PC_RV(s, r, 1); GNNX_PC_RV(s, r, 2); GNNX_PC_RV(s, r, 3);
+        if constexpr (NREADS > 14) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // never more than 15 LDS operations outstanding
+        GNNX_PC_RS(s, r, 0); GNNX_PC_RS(s, r, 1); GNNX_PC_RS(s, r, 2); GNNX_PC_RS(s, r, 3);
     };
     // this set's reads have returned; N: the LDS operations issued after them that stay in flight.  The set's registers are in-out
     // operands so that no use of them is scheduled in front of the wait (only the fields the MODE reads: an unused operand costs a copy)
@@ -1124,6 +1176,9 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
     auto wait_landed = [&](int32_t t, int32_t seen) {   // sub-chunk t is in LDS (`seen`: an earlier reading of its producer's flag)
         const int32_t need = need_of(t);
         if (seen >= need) return;
+#ifdef GNNX_EXPERIMENTS
+        if (a.pc_experiment == 1) return;
+#endif
         int32_t spins = 0;
         while (flag_read(flag_of(t)) < need) {
             __builtin_amdgcn_s_sleep(1);
@@ -1131,14 +1186,15 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         }
     };
     float acc = 0.f;
-    auto adds = [&](Set &s, auto full, int32_t cnt) {   // full: all 16 neighbours of the sub-chunk exist (every sub-chunk but the row's last)
-        float v[kHubSub];
+    // the 16 terms of a sub-chunk as they are added: the slice values through the prologue (straight-line code, as spmm_hub_kernel's
+    // pro_batch), the gathered column scale and the per-entry value -- separately rounded, in that order
+    auto terms = [&](Set &s, float(&v)[kHubSub]) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             v[2 * i] = s.d[i].x;
             v[2 * i + 1] = s.d[i].y;
         }
-        if constexpr (has_pro(MODE)) {   // the prologue of the sub-chunk in straight-line code (as spmm_hub_kernel's pro_batch)
+        if constexpr (has_pro(MODE)) {
             if constexpr (pro_bn(MODE)) {
                 float d[kHubSub];
                 bool bad = false;
@@ -1168,45 +1224,64 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
 #pragma unroll
             for (int j = 0; j < kHubSub; j++) v[j] = mul_rn(v[j], s.vv[j >> 2][j & 3]);
         }
-        if constexpr (decltype(full)::value) {
-#pragma unroll
-            for (int j = 0; j < kHubSub; j++) acc = add_rn(acc, v[j]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < kHubSub; j++)
-                if (j < cnt) acc = add_rn(acc, v[j]);
-        }
     };
-    using Keep = std::integral_constant<int, PIPE ? NREADS : 0>;
+    // acc = RN(acc + x), pinned in program order between the LDS reads (a volatile asm is not moved across another one)
+#define GNNX_PC_ADD(x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x))
     using None = std::integral_constant<int, 0>;
-    // a step with a successor: sub-chunk t (its reads issued one step earlier into `cur`) is added while the reads of t + 1 go out
-    // into `nxt`; nxt.fl still holds the flag that travelled with sub-chunk t - 1: the reading sub-chunk t + 1 is checked against
+    // One step, t + 1 < nsub: `cur` holds sub-chunk t (complete); its 16 adds run with the reads of sub-chunk t + 1 (into `nxt`)
+    // between the first of them -- the last adds cover the reads' latency -- then nxt is waited for.  Never more than 15 LDS operations
+    // outstanding (lgkmcnt is a 4-bit counter).  nxt.fl, which travelled with sub-chunk t - 1's reads, is the reading of the flag
+    // sub-chunk t + 1 is checked against.
     auto step = [&](Set &cur, Set &nxt, int32_t t) {
-        wait_landed(t + 1, __builtin_amdgcn_readfirstlane(nxt.fl));
-        issue_reads(nxt, t + 1);
-        wait_set(cur, Keep{});
         flag_write(fl0 + 4u * NP, t + 1);   // the slot of sub-chunk t is free (its words are in registers)
-        adds(cur, std::true_type{}, kHubSub);
+        wait_landed(t + 1, __builtin_amdgcn_readfirstlane(nxt.fl));
+        float v[kHubSub];
+        terms(cur, v);
+        const Rd r = rd_of(t + 1);
+        GNNX_PC_ADD(v[0]); GNNX_PC_R2(nxt, r, 0);
+        GNNX_PC_ADD(v[1]); GNNX_PC_R2(nxt, r, 1);
+        GNNX_PC_ADD(v[2]); GNNX_PC_R2(nxt, r, 2);
+        GNNX_PC_ADD(v[3]); GNNX_PC_R2(nxt, r, 3);
+        GNNX_PC_ADD(v[4]); GNNX_PC_R2(nxt, r, 4);
+        GNNX_PC_ADD(v[5]); GNNX_PC_R2(nxt, r, 5);
+        GNNX_PC_ADD(v[6]); GNNX_PC_R2(nxt, r, 6);
+        GNNX_PC_ADD(v[7]); GNNX_PC_R2(nxt, r, 7);
+        GNNX_PC_ADD(v[8]); GNNX_PC_RF(nxt, r); GNNX_PC_RV(nxt, r, 0); GNNX_PC_RV(nxt, r, 1);
+        GNNX_PC_ADD(v[9]); GNNX_PC_RV(nxt, r, 2); GNNX_PC_RV(nxt, r, 3);
+        if constexpr (NREADS > 14) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // (values + column scales: 17 reads and the flag write)
+        GNNX_PC_ADD(v[10]); GNNX_PC_RS(nxt, r, 0); GNNX_PC_RS(nxt, r, 1);
+        GNNX_PC_ADD(v[11]); GNNX_PC_RS(nxt, r, 2); GNNX_PC_RS(nxt, r, 3);
+        GNNX_PC_ADD(v[12]);
+        GNNX_PC_ADD(v[13]);
+        GNNX_PC_ADD(v[14]);
+        GNNX_PC_ADD(v[15]);
+        wait_set(nxt, None{});
     };
-    auto last = [&](Set &cur, int32_t t) {   // the row's last sub-chunk (possibly short)
-        wait_set(cur, None{});
-        adds(cur, std::false_type{}, total - t * kHubSub);
+    // the row's last sub-chunk (possibly short), complete in `cur`
+    auto last = [&](Set &cur, int32_t t) {
+        float v[kHubSub];
+        terms(cur, v);
+        const int32_t cnt = total - t * kHubSub;
+#pragma unroll
+        for (int j = 0; j < kHubSub; j++)
+            if (j < cnt) acc = add_rn(acc, v[j]);
     };
     Set A, B;
     B.fl = 0;
     wait_landed(0, 0);
     issue_reads(A, 0);
-    int32_t t = 0;
-    for (; t + 2 < nsub; t += 2) {
-        step(A, B, t);
-        step(B, A, t + 1);
+    wait_set(A, None{});
+    for (int32_t t = 0;;) {
+        if (t + 1 >= nsub) { last(A, t); break; }
+        step(A, B, t++);
+        if (t + 1 >= nsub) { last(B, t); break; }
+        step(B, A, t++);
     }
-    if (t + 1 < nsub) {   // A holds the reads of sub-chunk t: one or two sub-chunks are left
-        step(A, B, t);
-        last(B, t + 1);
-    } else {
-        last(A, t);
-    }
+#undef GNNX_PC_ADD
+#undef GNNX_PC_R2
+#undef GNNX_PC_RV
+#undef GNNX_PC_RS
+#undef GNNX_PC_RF
     if (active) {  // the epilogue of epilogue_store<1>, same op order
         float v = acc;
         if (a.rowscale) v = mul_rn(v, a.rowscale[row]);
@@ -1354,26 +1429,37 @@ int launch_hub(int mode, hipStream_t st, const SpmmArgs &a)
     }
 }
 
-template <int MODE, bool SUMS>
-int launch_hubpc_kernel(hipStream_t st, const SpmmArgs &a)
+template <int MODE, bool SUMS, int SLAB>
+int launch_hubpc_slab(hipStream_t st, const SpmmArgs &a)
 {
-    using L = hubpc::Lay<MODE>;
+    using L = hubpc::Cfg<MODE, SLAB>;
     static std::atomic<uint64_t> done{0};
     constexpr size_t lds_bytes = sizeof(float) * L::LDS_FLOATS;
     static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
     int dev = 0;
     GNNX_HIP_CHECK(hipGetDevice(&dev));
     if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {  // dynamic-LDS opt-in, once per kernel and device
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hubpc_kernel<MODE, SUMS>),
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hubpc_kernel<MODE, SUMS, SLAB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
     }
-    const int32_t n_slabs = (int32_t)ceil_div(a.n_feat, kHubSlab);
+    const int32_t n_slabs = (int32_t)ceil_div(a.n_feat, SLAB);
     const dim3 grid((uint32_t)((int64_t)a.n_big_rows * n_slabs));
-    hipLaunchKernelGGL((spmm_hubpc_kernel<MODE, SUMS>), grid, dim3(64 * (1 + hubpc::NP)), lds_bytes, st, a, a.hub_rows, n_slabs);
+    hipLaunchKernelGGL((spmm_hubpc_kernel<MODE, SUMS, SLAB>), grid, dim3(64 * (1 + hubpc::NP)), lds_bytes, st, a, a.hub_rows, n_slabs);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
 }
+
+template <int MODE, bool SUMS>
+int launch_hubpc_kernel(hipStream_t st, const SpmmArgs &a)
+{
+#ifdef GNNX_EXPERIMENTS
+    static const int slab_env = [] { const char *e = experiment_env("GNNX_PC_SLAB"); return e ? atoi(e) : 0; }();   // A/B: 64-feature slabs
+    if (slab_env == 64) return launch_hubpc_slab<MODE, SUMS, 64>(st, a);
+#endif
+    return launch_hubpc_slab<MODE, SUMS, hubpc::kBigSlab>(st, a);
+}
+
 
 // the first n_big_rows hub rows (f32 rows of 16-byte pieces) on the producer / consumer kernel
 int launch_hubpc(int mode, hipStream_t st, const SpmmArgs &a)
@@ -1446,29 +1532,35 @@ void launch_rows(int mode, dim3 grid, hipStream_t st, const SpmmArgs &a)
 #undef GNNX_ROWS
 }
 
-// Side stream of the aggregation (hub kernel beside the row kernel): one per host thread and device, created on first use, with
-// the two events of the fork / join.  Per thread because a rank = one host thread = one stream (gnnx.h): two threads never share
-// the events.  Released when the thread ends (a rank thread of an in-process group that exits leaves nothing behind).
+// Side streams of the aggregation (the hub kernels beside the row kernel): one pair per host thread and device, created on first
+// use, with the events of the fork / join.  `stream` carries spmm_hub_kernel when it runs beside the row kernel, `stream2` the
+// producer / consumer kernel of the longest rows (always beside: the two hub kernels overlap, each fills the CUs the other leaves).
+// Per thread because a rank = one host thread = one stream (gnnx.h): two threads never share the events.  Released when the thread
+// ends (a rank thread of an in-process group that exits leaves nothing behind).
 struct SideStream {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, join2 = nullptr;
+    void destroy()
+    {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (stream2) (void)hipStreamSynchronize(stream2);
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        if (join2) (void)hipEventDestroy(join2);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (stream2) (void)hipStreamDestroy(stream2);
+        *this = SideStream{};
+    }
 };
 constexpr int kSideMaxDev = 64;
 struct SideStreamTable {
     SideStream t[kSideMaxDev];
     ~SideStreamTable()
     {
-        for (SideStream &s : t) {
-            if (!s.stream) continue;
-            (void)hipStreamSynchronize(s.stream);
-            if (s.fork) (void)hipEventDestroy(s.fork);
-            if (s.join) (void)hipEventDestroy(s.join);
-            (void)hipStreamDestroy(s.stream);
-            s = SideStream{};
-        }
+        for (SideStream &s : t) s.destroy();
     }
 };
-// the side stream lives on the device that owns the CALLER's stream (the current device for the null stream)
+// the side streams live on the device that owns the CALLER's stream (the current device for the null stream)
 SideStream *side_stream(hipStream_t caller)
 {
     static thread_local SideStreamTable table;
@@ -1483,14 +1575,13 @@ SideStream *side_stream(hipStream_t caller)
         if (hipGetDevice(&cur) != hipSuccess) return nullptr;
         if (cur != dev && hipSetDevice(dev) != hipSuccess) return nullptr;
         const bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
+                        hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) == hipSuccess &&
                         hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess;
+                        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) == hipSuccess;
         if (cur != dev) (void)hipSetDevice(cur);
         if (!ok) {
-            if (s.fork) (void)hipEventDestroy(s.fork);
-            if (s.join) (void)hipEventDestroy(s.join);
-            if (s.stream) (void)hipStreamDestroy(s.stream);
-            s = SideStream{};
+            s.destroy();
             return nullptr;
         }
     }
@@ -1516,15 +1607,21 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     // and joined back into the caller's stream with events -- and hides under the row kernel (RMAT 1M / 10M, F = 128: a 0.49 ms hub
     // kernel beside a 0.45 ms streaming kernel); when it is bandwidth-bound the two would only share the same bytes per second.
     SideStream *side = nullptr;
-    struct JoinGuard {
+    struct JoinGuard {   // every exit path orders the caller's stream behind whatever this call put on the side streams
         SideStream *s = nullptr;
         hipStream_t to = nullptr;
-        void arm(SideStream *s_, hipStream_t to_) { s = s_; to = to_; }
+        bool used1 = false, used2 = false;
         ~JoinGuard()
         {
             if (!s) return;
-            if (hipEventRecord(s->join, s->stream) == hipSuccess) (void)hipStreamWaitEvent(to, s->join, 0);
-            else (void)hipStreamSynchronize(s->stream);
+            if (used1) {
+                if (hipEventRecord(s->join, s->stream) == hipSuccess) (void)hipStreamWaitEvent(to, s->join, 0);
+                else (void)hipStreamSynchronize(s->stream);
+            }
+            if (used2) {
+                if (hipEventRecord(s->join2, s->stream2) == hipSuccess) (void)hipStreamWaitEvent(to, s->join2, 0);
+                else (void)hipStreamSynchronize(s->stream2);
+            }
         }
     } joiner;
     static const int side_env = [] { const char *e = experiment_env("GNNX_SPMM_SIDE"); return e ? atoi(e) : -1; }();   // A/B: 0 never, 1 always
@@ -1532,20 +1629,23 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
     const int32_t n_rest = a.n_hub_rows - a.n_big_rows;   // hub rows of spmm_hub_kernel
     if (a.n_big_rows > 0 || (n_rest > 0 && beside)) {
         side = side_stream(st);
-        GNNX_REQUIRE(side, GNNX_ERR_HIP, "could not create the aggregation's side stream");
+        GNNX_REQUIRE(side, GNNX_ERR_HIP, "could not create the aggregation's side streams");
         GNNX_HIP_CHECK(hipEventRecord(side->fork, st));
-        GNNX_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
-        // from here on every exit path joins the side stream back into the caller's (JoinGuard): an error return must not leave
-        // work of this call running beside whatever the caller enqueues next
-        joiner.arm(side, st);
+        joiner.s = side;
+        joiner.to = st;
     }
     if (a.n_big_rows > 0) {
-        // the longest rows -- each a chain of dependent adds, a CU of its own per (row, slab) -- always beside everything else, first:
-        // their workgroups take a whole CU's LDS, the other hub rows' workgroups fill the CUs they leave
-        const int rc = launch_hubpc(mode, side->stream, a);
+        // the longest rows -- each a chain of dependent adds, a CU of its own per (row, slab) -- always beside everything else
+        GNNX_HIP_CHECK(hipStreamWaitEvent(side->stream2, side->fork, 0));
+        joiner.used2 = true;   // from here on every exit path joins the stream back into the caller's (an error return included)
+        const int rc = launch_hubpc(mode, side->stream2, a);
         if (rc != GNNX_OK) return rc;
     }
     if (n_rest > 0) {
+        if (beside) {
+            GNNX_HIP_CHECK(hipStreamWaitEvent(side->stream, side->fork, 0));
+            joiner.used1 = true;
+        }
         const int rc = launch_hub<VEC>(mode, beside ? side->stream : st, a);
         if (rc != GNNX_OK) return rc;
     }
@@ -1583,8 +1683,11 @@ int plan_build(gnnx_spmm_plan *plan, const int32_t *d_rowptr, int32_t n_rows, in
     hipLaunchKernelGGL(plan_count_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, chunk, plan->d_counters);
     GNNX_LAUNCH_CHECK();
     unsigned long long h[2];
+    int32_t h_nnz = 0;
     GNNX_HIP_CHECK(hipMemcpyAsync(h, plan->d_counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    GNNX_HIP_CHECK(hipMemcpyAsync(&h_nnz, d_rowptr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    plan->nnz = h_nnz;
     plan->n_split_rows = (int32_t)h[0];
     plan->n_hub_nnz = (int64_t)h[1];
     if (plan->n_split_rows > 0) {
@@ -1603,7 +1706,11 @@ int plan_build(gnnx_spmm_plan *plan, const int32_t *d_rowptr, int32_t n_rows, in
         for (size_t i = 0; i < h_rows.size(); i++) h_hub[i] = h_rows[i].x;
         plan->max_hub_degree = h_rows.empty() ? 0 : h_rows[0].y;
         plan->h_hub_degrees.resize(h_rows.size());
-        for (size_t i = 0; i < h_rows.size(); i++) plan->h_hub_degrees[i] = h_rows[i].y;
+        plan->h_hub_prefix.assign(h_rows.size() + 1, 0);
+        for (size_t i = 0; i < h_rows.size(); i++) {
+            plan->h_hub_degrees[i] = h_rows[i].y;
+            plan->h_hub_prefix[i + 1] = plan->h_hub_prefix[i] + h_rows[i].y;
+        }
         GNNX_HIP_CHECK(hipMalloc(&plan->d_hub_rows, sizeof(int32_t) * h_hub.size()));
         GNNX_HIP_CHECK(hipMemcpyAsync(plan->d_hub_rows, h_hub.data(), sizeof(int32_t) * h_hub.size(), hipMemcpyHostToDevice, st));
         GNNX_HIP_CHECK(hipStreamSynchronize(st));
@@ -1654,22 +1761,14 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
         (void)gnnx_spmm_plan_destroy(plan);
         return rc;
     }
-    (void)gnnx_spmm_plan_set_big_row_threshold(plan, kHubBigRow);
     *plan_out = plan;
     return GNNX_OK;
 }
 
 GNNX_API int gnnx_spmm_plan_set_big_row_threshold(gnnx_spmm_plan *plan, int32_t threshold)
 {
-    GNNX_REQUIRE(plan && threshold >= 0, GNNX_ERR_INVALID_ARG, "plan / threshold");
-    plan->big_row_threshold = threshold;
-    plan->n_big_rows = 0;
-    plan->n_big_nnz = 0;
-    for (int32_t d : plan->h_hub_degrees) {   // sorted, longest first
-        if (d <= threshold) break;
-        plan->n_big_rows++;
-        plan->n_big_nnz += d;
-    }
+    GNNX_REQUIRE(plan, GNNX_ERR_INVALID_ARG, "plan is null");
+    plan->big_row_threshold = threshold < 0 ? -1 : threshold;
     return GNNX_OK;
 }
 
@@ -1725,6 +1824,27 @@ bool hub_is_chain_bound(int32_t max_hub_degree, int64_t n_hub_nnz, int32_t n_fea
     const double chain_ns = (double)max_hub_degree * kHubNsPerNeighbour;
     const double bytes_ns = (double)n_hub_nnz * (double)n_feat * bytes_per_feature / kHubBytesPerNs;
     return chain_ns > bytes_ns;
+}
+
+// How many of the plan's hub rows (longest first) take the producer / consumer kernel for an aggregation of `n_feat` f32 features:
+// those whose chain in spmm_hub_kernel (kHubNsPerNeighbour per non-zero) would stick out of what runs beside it -- longer than HALF
+// of the larger of the hub rows' bytes and the other rows' bytes at kHubBytesPerNs.  Whole 10 M / 100 M graph: none or a handful
+// (everything hides behind 80 GB of other rows); one rank's eighth of it: the rows beyond ~50 k non-zeros (a rank keeps the longest
+// rows whole but only an eighth of the bytes); RMAT 1M / 10M, F = 128: the three rows beyond 26 k.  Few rows on purpose: every
+// (row, 16-feature slab) takes a whole CU's LDS, and spmm_hub_kernel's workgroups need the CUs these leave.  A threshold fixed by
+// the caller (tests) wins.
+int32_t big_rows_for(const gnnx_spmm_plan *plan, int32_t n_feat)
+{
+    const auto &deg = plan->h_hub_degrees;
+    int32_t thr = plan->big_row_threshold;
+    if (thr < 0) {
+        const int64_t rest = plan->nnz > plan->n_hub_nnz ? plan->nnz - plan->n_hub_nnz : 0;
+        const double bytes_ns = (double)(plan->n_hub_nnz > rest ? plan->n_hub_nnz : rest) * (double)n_feat * 4.0 / kHubBytesPerNs;
+        const double t = 0.5 * bytes_ns / kHubNsPerNeighbour;
+        thr = t > 2.0e9 ? 2000000000 : (int32_t)t;
+        if (thr < kHubBigRowMin) thr = kHubBigRowMin;
+    }
+    return (int32_t)(std::partition_point(deg.begin(), deg.end(), [thr](int32_t d) { return d > thr; }) - deg.begin());
 }
 
 int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr, const int32_t *d_colidx, const float *d_vals,
@@ -1796,7 +1916,6 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         // Hub kernel beside the row kernel (side stream) or in front of it (same stream)?  Beside, when its time is the dependent-add
         // chain of its longest row (~12 ns per neighbour) rather than its bytes (hub non-zeros x row bytes at ~7 TB/s):
         // RMAT 1M / 10M, F = 128: 0.92 -> 0.79 ms; RMAT 10M / 100M, F = 256 (28 GB of hub rows): in front, 13.59 vs 13.76 ms beside.
-        a.n_big_rows = plan->n_big_rows;
         a.hub_beside = hub_is_chain_bound(plan->max_hub_degree, plan->n_hub_nnz, n_feat, x_bf16 ? 2 : 4);
     }
     hipStream_t st = as_stream(stream);
@@ -1804,10 +1923,17 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
     const bool vec4 = (n_feat % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && (x_bf16 ? (reinterpret_cast<uintptr_t>(d_X) & 7u) == 0 : aligned16(d_X)) && aligned16(d_Y) &&
                       aligned16(d_bias) && aligned16(a.pro_mean) && aligned16(a.pro_var) && aligned16(a.pro_gamma) &&
                       aligned16(a.pro_beta);
-    if (x_bf16 || !vec4) a.n_big_rows = 0;   // the producer / consumer kernel reads f32 rows in 16-byte pieces; other rows: spmm_hub_kernel
-    else if (a.n_big_rows > 0)            // what is left for spmm_hub_kernel: is IT bound by its longest row's chain?
-        a.hub_beside = hub_is_chain_bound(plan->h_hub_degrees[(size_t)a.n_big_rows < plan->h_hub_degrees.size() ? a.n_big_rows : 0],
-                                          plan->n_hub_nnz - plan->n_big_nnz, n_feat, 4) || a.n_big_rows == plan->n_split_rows;
+    // the producer / consumer kernel reads f32 rows in 16-byte pieces; other rows: spmm_hub_kernel for every hub row
+    if (a.n_hub_rows > 0 && !x_bf16 && vec4) {
+#ifdef GNNX_EXPERIMENTS
+        static const int pc_exp = [] { const char *e = experiment_env("GNNX_PC_EXP"); return e ? atoi(e) : 0; }();
+        a.pc_experiment = pc_exp;
+#endif
+        a.n_big_rows = big_rows_for(plan, n_feat);
+        if (a.n_big_rows > 0 && a.n_big_rows < a.n_hub_rows)   // what is left for spmm_hub_kernel: is IT bound by its longest row's chain?
+            a.hub_beside = hub_is_chain_bound(plan->h_hub_degrees[(size_t)a.n_big_rows], plan->n_hub_nnz - plan->h_hub_prefix[(size_t)a.n_big_rows],
+                                              n_feat, 4);
+    }
     if (x_bf16 && !vec4) {
         // bf16 rows that are not 8-byte pieces (n_feat % 4 != 0 or an unaligned X): LDS-DMA moves one DWORD per lane whatever the
         // load size, so a 2-byte-per-lane ring layout does not exist -- the hub rows stay with the row / streaming kernel (same bits)

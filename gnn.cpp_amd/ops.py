@@ -66,7 +66,8 @@ class SpmmPlan:
         self.n_split_rows, self.n_hub_nnz = a.value, b.value   # hub rows (degree > chunk) and their non-zeros
 
     def set_big_row_threshold(self, threshold):
-        """Hub rows longer than `threshold` take the producer / consumer hub kernel (default 8192; same bits for every value)."""
+        """Hub rows longer than `threshold` take the producer / consumer hub kernel (< 0: the library picks them per call, the
+        default; same bits for every value)."""
         capi.call("gnnx_spmm_plan_set_big_row_threshold", self.h, int(threshold))
         return self
 

@@ -168,9 +168,12 @@ int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int32_t chunk
                           gnnx_spmm_plan **plan, void *stream);
 int gnnx_spmm_plan_destroy(gnnx_spmm_plan *plan);
 int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_hub_rows, int64_t *n_hub_nnz);
-/* Hub rows longer than `threshold` non-zeros (default 8192, set by gnnx_spmm_plan_create) are summed by the producer / consumer hub
- * kernel -- a CU per (row, 64-feature slab): one wavefront adds, three keep the row's slices coming -- for rows whose time is their
- * own chain of dependent adds.  Same bits for every threshold (tests pass 0: every hub row). */
+/* The longest hub rows are summed by the producer / consumer hub kernel -- a CU per (row, 64-feature slab): one wavefront adds in
+ * the reference's order, three keep the row's slices coming through a 128 KiB LDS ring -- because their time is their own chain of
+ * dependent adds, not their bytes.  By default the library picks them per call (rows whose chain in the plain hub kernel would
+ * exceed half of what all hub rows' bytes take: a handful on a whole 10 M / 100 M graph, the rows beyond ~18 k non-zeros on an
+ * eighth of it).  threshold >= 0 fixes the cut (rows longer than it; tests pass 0: every hub row), < 0 restores the default.  Same
+ * bits for every choice. */
 int gnnx_spmm_plan_set_big_row_threshold(gnnx_spmm_plan *plan, int32_t threshold);
 
 int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
