@@ -930,11 +930,12 @@ template <int MODE, int SLAB> struct Cfg {
     // that layout reaches 156 KiB, and workgroup LDS addresses above ~152 KB misbehaved on the MI355X boxes of this pool (wrong words
     // from producers 1 and 2, whose index rings sat there; every layout up to 151 584 bytes is exact) -- kMaxLdsBytes keeps all of them below
     static constexpr bool kBoth = has_val(MODE) && has_sc(MODE);
-    static constexpr int S = (kBoth ? 16384 : 32768) / SUBF;
-    static constexpr int LAS = SLAB == 64 ? (kBoth ? 5 : 10) : (kBoth ? 16 : 32);     // sub-chunks in flight per producer
-    static constexpr int NCX = (LAS + 2 + 3) / 4;        // index chunks fetched ahead per producer (4 NCX >= LAS + 2)
-    static constexpr int NI = NCX < 4 ? 4 : 16;          // index ring slots per producer (a power of two > NCX)
+    static constexpr int S = (kBoth && SLAB == 16 ? 16384 : 32768) / SUBF;
+    static constexpr int LASC = SLAB == 64 ? (kBoth ? 1 : 2) : (kBoth ? 4 : 8);   // index chunks (4 ring slots each) in flight per producer
+    static constexpr int NCX = LASC + 1;                 // index chunks fetched ahead per producer
+    static constexpr int NI = NCX < 4 ? 4 : (NCX < 8 ? 8 : 16);   // index ring slots per producer (a power of two > NCX)
     static constexpr int XC = 1 + (has_val(MODE) ? 1 : 0) + (has_sc(MODE) ? 1 : 0);   // VMEM operations per index chunk besides the slices
+    static constexpr int OPS = 4 * IPS + XC;             // VMEM operations per index chunk
     static constexpr int VR = S * SUBF;                                // [S][16] per-entry values (written 64 at a time, by index chunk)
     static constexpr int SR = VR + (has_val(MODE) ? S * kHubSub : 0);  // [S][16] gathered column scales
     static constexpr int IR = SR + (has_sc(MODE) ? S * kHubSub : 0);   // [NP][NI][64] column indices
@@ -942,10 +943,10 @@ template <int MODE, int SLAB> struct Cfg {
     static constexpr int LDS_FLOATS = FL + 8;
     static_assert(SLAB == 64 || SLAB == 16, "slice = 256 or 64 bytes");
     static_assert(LDS_FLOATS * 4 <= kMaxLdsBytes, "stay inside the validated LDS range");
-    static_assert((S & (S - 1)) == 0 && S % 4 == 0 && S > NP * LAS, "ring: a power of two, and room for everything in flight plus the slot being added");
-    static_assert(4 * NCX >= LAS + 2 && NI > NCX, "an index chunk has landed when its first sub-chunk is issued (see the producer loop)");
-    static_assert((LAS - 1) * IPS + (LAS / 4 + 2) * XC <= 63, "vmcnt is a 6-bit counter");
-    static_assert(LAS <= 32, "wait_vm_sub");
+    static_assert((S & (S - 1)) == 0 && S >= 4 * (NP * LASC + 2), "ring: a power of two, room for everything in flight plus the chunk being added");
+    static_assert(NCX >= LASC + 1 && NI > NCX, "an index chunk has landed when it is read: a chunk issued behind its DMA has landed by then");
+    static_assert(LASC * OPS <= 63, "vmcnt is a 6-bit counter");
+    static_assert(LASC <= 32, "wait_vm_sub");
 };
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -979,7 +980,7 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
 {
     using namespace hubpc;
     using K = Cfg<MODE, SLAB>;
-    constexpr int S = K::S, LAS = K::LAS, IPS = K::IPS, NI = K::NI, NCX = K::NCX, SUBF = K::SUBF;
+    constexpr int S = K::S, IPS = K::IPS, NI = K::NI, NCX = K::NCX, SUBF = K::SUBF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1001,11 +1002,15 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
 
     if (wv > 0) {
         // ------------------------------------------------------------------ producer p
+        // Everything at the granularity of an index chunk (64 neighbours = 4 ring slots): a lone wavefront pays ~4 cycles per instruction
+        // and tens per taken branch, so the loop is long straight-line stretches -- one flag check, one LDS wait, the chunk's DMAs back
+        // to back, one counted vmcnt wait, one publish per 64 neighbours.
+#ifdef GNNX_EXPERIMENTS
+        if (a.pc_experiment == 3) return;   // timing only: the consumer alone
+#endif
         const int32_t p = wv - 1;
         const int32_t nchunk = (nsub + 3) >> 2;
-        const int32_t n_own_chunks = nchunk > p ? (nchunk - p + NP - 1) / NP : 0;
-        int32_t n_own = 4 * n_own_chunks;                              // own sub-chunks: the row's last index chunk may be short
-        if (n_own_chunks > 0 && p + (n_own_chunks - 1) * NP == nchunk - 1) n_own -= 4 * nchunk - nsub;
+        const int32_t n_own = nchunk > p ? (nchunk - p + NP - 1) / NP : 0;   // own index chunks: own chunk j is the row's chunk p + j NP
         // DMA source of this lane: neighbour sub_e of the instruction, 4 features at foff (lanes past the row's width re-read the
         // slab's first piece; their LDS words are never stored)
         const int sub_e = lane / K::LPE;
@@ -1023,59 +1028,82 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
             q = q < lo ? lo : q;
             __builtin_amdgcn_global_load_lds(a.colidx + q, (lds_void_t *)(iring + (j & (NI - 1)) * kHubChunk), 4, 0, 0);
         };
-        // own sub-chunk u: columns from the index ring, slices into ring slot t % S; in front of an index chunk's first sub-chunk the
-        // chunk's 64 per-entry values / gathered column scales (they land before it does: VMEM returns in order)
-        auto issue = [&](int32_t u) {
-            const int32_t t = t_of(p, u);
-            const int islot = (u >> 2) & (NI - 1), k0 = (u & 3) * kHubSub, slot = t & (S - 1);
-            int32_t c[IPS], c64 = 0;
-            const uint32_t ca = col_lane + (uint32_t)(islot * kHubChunk + k0) * 4u;
-#define GNNX_PC_RC(i) if constexpr ((i) < IPS) hub_lds_read<(i) * K::EPI * 4>(c[(i) < IPS ? (i) : 0], ca)
+        // own chunk j: columns from the index ring; the chunk's 64 per-entry values / gathered column scales, then the slices of its
+        // 64 neighbours into ring slots 4 c .. 4 c + 3 (mod S), then the index chunk NCX ahead: always K::OPS VMEM operations, in this
+        // order (the row's last chunk too: neighbours past the row's end are clamped into it -- valid addresses, words nobody adds)
+        auto issue_chunk = [&](int32_t j) {
+            const int32_t c = p + j * NP;
+            const int islot = j & (NI - 1), slot0 = (4 * c) & (S - 1);
+            int32_t col[4 * IPS], c64 = 0;
+            const uint32_t ca = col_lane + (uint32_t)(islot * kHubChunk) * 4u;
+#define GNNX_PC_RC(i) hub_lds_read<(i) * K::EPI * 4>(col[i], ca)
             GNNX_PC_RC(0); GNNX_PC_RC(1); GNNX_PC_RC(2); GNNX_PC_RC(3);
+            if constexpr (IPS == 4) {
+                GNNX_PC_RC(4); GNNX_PC_RC(5); GNNX_PC_RC(6); GNNX_PC_RC(7); GNNX_PC_RC(8); GNNX_PC_RC(9); GNNX_PC_RC(10); GNNX_PC_RC(11);
+                GNNX_PC_RC(12); GNNX_PC_RC(13); GNNX_PC_RC(14); GNNX_PC_RC(15);
+            }
 #undef GNNX_PC_RC
-            if constexpr (has_sc(MODE)) {
-                if ((u & 3) == 0) hub_lds_read<0>(c64, col64 + (uint32_t)(islot * kHubChunk) * 4u);
+            if constexpr (has_sc(MODE)) hub_lds_read<0>(c64, col64 + (uint32_t)(islot * kHubChunk) * 4u);
+            if constexpr (IPS == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(col[4]), "+v"(col[5]), "+v"(col[6]), "+v"(col[7]), "+v"(col[8]),
+                               "+v"(col[9]), "+v"(col[10]), "+v"(col[11]), "+v"(col[12]), "+v"(col[13]), "+v"(col[14]), "+v"(col[15]), "+v"(c64)::"memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(col[0]), "+v"(col[1]), "+v"(col[2]), "+v"(col[3]), "+v"(c64)::"memory");
+            if constexpr (has_val(MODE)) {
+                int32_t q = hi - 1 - (c * kHubChunk + lane);
+                q = q < lo ? lo : q;
+                __builtin_amdgcn_global_load_lds(a.vals + q, (lds_void_t *)(lds + K::VR + slot0 * kHubSub), 4, 0, 0);
             }
-            if constexpr (IPS == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c64)::"memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c[0]), "+v"(c64)::"memory");
-            if constexpr (has_val(MODE) || has_sc(MODE)) {
-                if ((u & 3) == 0) {   // slots t .. t + 3 of the small rings: 64 words
-                    if constexpr (has_val(MODE)) {
-                        int32_t q = hi - 1 - (t * kHubSub + lane);
-                        q = q < lo ? lo : q;
-                        __builtin_amdgcn_global_load_lds(a.vals + q, (lds_void_t *)(lds + K::VR + slot * kHubSub), 4, 0, 0);
-                    }
-                    if constexpr (has_sc(MODE))
-                        __builtin_amdgcn_global_load_lds(a.colscale + c64, (lds_void_t *)(lds + K::SR + slot * kHubSub), 4, 0, 0);
-                }
-            }
-            float *dst = lds + slot * SUBF;
+            if constexpr (has_sc(MODE)) __builtin_amdgcn_global_load_lds(a.colscale + c64, (lds_void_t *)(lds + K::SR + slot0 * kHubSub), 4, 0, 0);
+            float *dst = lds + slot0 * SUBF;
 #pragma unroll
-            for (int i = 0; i < IPS; i++) {
-                const char *srcp = xsrc + (uint64_t)(uint32_t)c[i] * row_bytes;
+            for (int i = 0; i < 4 * IPS; i++) {
+                const char *srcp = xsrc + (uint64_t)(uint32_t)col[i] * row_bytes;
                 __builtin_amdgcn_global_load_lds(reinterpret_cast<const float *>(srcp), (lds_void_t *)(dst + i * 256), 16, 0, 0);
+            }
+            idx_dma(j + NCX);
+        };
+        // A landed chunk is FINISHED by its producer, in place: the BatchNorm / ReLU prologue, the gathered column scale and the
+        // per-entry value are applied to this lane's 16-byte piece of every neighbour's slice -- the same separately rounded operations
+        // in the same order as every other path (pro_apply, then x sc, then x val) -- so that the consumer's loop is "read, add" in
+        // every MODE (its instruction count is the row's time; the producers have the issue slots to spare).
+        const ProConst<4> pc4 = pro_load<4, MODE>(a, foff, true);
+        auto finish_chunk = [&](int32_t j) {
+            const int32_t slot0 = (4 * (p + j * NP)) & (S - 1);
+#pragma unroll
+            for (int i = 0; i < 4 * IPS; i++) {
+                const uint32_t xa = lds0 + (uint32_t)(slot0 * SUBF + i * 256) * 4u + (uint32_t)lane * 16u;
+                const uint32_t e = (uint32_t)(slot0 * kHubSub + i * K::EPI + sub_e) * 4u;   // this lane's neighbour in the small rings
+                v4f x;
+                float vv = 1.f, sv = 1.f;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(x) : "v"(xa) : "memory");
+                if constexpr (has_val(MODE)) hub_lds_read<0>(vv, lds0 + (uint32_t)K::VR * 4u + e);
+                if constexpr (has_sc(MODE)) hub_lds_read<0>(sv, lds0 + (uint32_t)K::SR * 4u + e);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x), "+v"(vv), "+v"(sv)::"memory");
+                float4 y = make_float4(x.x, x.y, x.z, x.w);
+                if constexpr (has_pro(MODE)) y = pro_apply<MODE>(y, pc4);
+                if constexpr (has_sc(MODE)) y = mul_rn(y, sv);
+                if constexpr (has_val(MODE)) y = mul_rn(y, vv);
+                x = (v4f){y.x, y.y, y.z, y.w};
+                asm volatile("ds_write_b128 %0, %1" ::"v"(xa), "v"(x) : "memory");
             }
         };
 
 #pragma unroll
         for (int j = 0; j < NCX; j++) idx_dma(j);
         hub_wait_vm<0>();
-        int32_t issued = 0, landed = 0, consumed = 0, spins = 0;
+        int32_t issued = 0, landed = 0, consumed = 0, spins = 0;   // own chunks
         while (landed < n_own) {
-            // put in flight whatever the window (LAS) and the ring allow: slot t % S is free once the consumer has left sub-chunk
-            // t - S (an index chunk's first sub-chunk also writes the small rings of the three behind it)
-            while (issued < n_own && issued - landed < LAS) {
-                const int32_t need = t_of(p, issued) + (((issued & 3) == 0 && K::XC > 1) ? 3 : 0) - S + 1;
+            // put in flight whatever the window (LASC chunks) and the ring allow: slots 4 c .. 4 c + 3 (mod S) are free once the consumer
+            // has left sub-chunk 4 c + 3 - S
+            while (issued < n_own && issued - landed < K::LASC) {
+                const int32_t need = 4 * (p + issued * NP) + 3 - S + 1;
                 if (need > consumed) {
                     consumed = flag_read(fl0 + 4u * NP);
                     if (need > consumed) break;
                 }
-                issue(issued);
-                // the index chunk NCX ahead, behind the first sub-chunk of every own chunk: by the time its first sub-chunk is issued
-                // (LAS window: at least 2 sub-chunks issued after this DMA have landed, VMEM returns in order) it is in LDS, and
-                // the slot it overwrites (an own chunk NI - NCX back) has been read to the end
-                if ((issued & 3) == 0) idx_dma((issued >> 2) + NCX);
-                issued++;
+                issue_chunk(issued++);
             }
             if (issued == landed) {   // ring full and nothing of ours in flight: the consumer is behind
                 __builtin_amdgcn_s_sleep(2);
@@ -1083,205 +1111,133 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
                 continue;
             }
             spins = 0;
-            wait_vm_sub<IPS, LAS>(issued - landed - 1);   // own sub-chunk `landed` is in LDS (chunk-level DMAs in between only make the wait stricter)
+            wait_vm_sub<K::OPS, K::LASC>(issued - landed - 1);   // own chunk `landed` is in LDS: exactly K::OPS operations per younger chunk
+            if constexpr (has_pro(MODE) || has_val(MODE) || has_sc(MODE)) finish_chunk(landed);
             landed++;
-            flag_write(fl0 + 4u * (uint32_t)p, landed);
+            flag_write(fl0 + 4u * (uint32_t)p, 4 * landed);   // (behind finish_chunk's LDS writes: one wavefront's LDS operations are processed in order)
         }
         hub_wait_vm<0>();   // index DMAs past the end of the row
         return;
     }
 
     // ---------------------------------------------------------------------- consumer
+    // A lone wavefront issues one instruction every ~4 cycles, whatever its kind: the consumer's time is its instruction COUNT.  So
+    // everything but "read, add" is somewhere else -- the per-entry value, the column scale and the BatchNorm / ReLU prologue are
+    // applied to a landed slot by its producer (in place, the same separately rounded operations in the same order), the bookkeeping
+    // (flags, slot addresses) is per index chunk of 64 neighbours -- and the loop is the same for every MODE: per neighbour half a
+    // two-address LDS read and one add.
     const int32_t f = f_slab + (lane & (SLAB - 1));
     const bool active = lane < SLAB && f < a.n_feat;
-    const ProConst<1> pc = pro_load<1, MODE>(a, active ? f : 0, active);
     const uint32_t ring_lane = lds0 + (uint32_t)(lane & (SLAB - 1)) * 4u;
+#ifdef GNNX_EXPERIMENTS
+    if (a.pc_experiment == 2) {   // timing only: the producers alone (no back-pressure)
+        flag_write(fl0 + 4u * NP, 0x7fffffff);
+        return;
+    }
+#endif
     struct Set {
         v2f d[8];
-        v4f vv[4], sv[4];
-        int32_t fl;
     };
-    constexpr int NREADS = 8 + (has_val(MODE) ? 4 : 0) + (has_sc(MODE) ? 4 : 0) + 1;   // LDS operations of one issue_reads
-    // what sub-chunk t needs: producer (t / 4) % NP has landed own sub-chunk 4 ((t / 4) / NP) + t % 4
-    auto flag_of = [&](int32_t t) { return fl0 + 4u * (uint32_t)((t >> 2) % NP); };
-    auto need_of = [&](int32_t t) { return 4 * ((t >> 2) / NP) + (t & 3) + 1; };
-    // The LDS reads of slot t % S (with them the flag sub-chunk t + 2 will be checked against), one instruction at a time: step()
-    // places them BETWEEN the adds of an earlier sub-chunk -- a dependent v_add_f32 issues every ~13 cycles, the reads (and the
-    // scalar bookkeeping) ride in the gaps.  neighbours e, e + 1 of this lane's feature come in one instruction: slices are 256 bytes
-    // apart (read2st64) or 64 (read2, dword offsets).
-    struct Rd {
-        uint32_t ad, va, sa, fa;
-    };
-    auto rd_of = [&](int32_t t) {
-        Rd r;
-        r.ad = ring_lane + (uint32_t)(t & (S - 1)) * (uint32_t)(SUBF * 4);
-        r.va = lds0 + (uint32_t)(K::VR + (t & (S - 1)) * kHubSub) * 4u;
-        r.sa = lds0 + (uint32_t)(K::SR + (t & (S - 1)) * kHubSub) * 4u;
-        r.fa = flag_of(t + 2);
-        return r;
-    };
-#define GNNX_PC_R2(s, r, i)                                                                                                                  \
-    do {                                                                                                                                     \
-        if constexpr (SLAB == 64)                                                                                                            \
-            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"((s).d[i]) : "v"((r).ad), "i"(2 * (i)), "i"(2 * (i) + 1) : "memory"); \
-        else                                                                                                                                 \
-            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"((s).d[i]) : "v"((r).ad), "i"(32 * (i)), "i"(32 * (i) + 16) : "memory"); \
+    constexpr uint32_t SLOT_BYTES = (uint32_t)SUBF * 4u;
+    // neighbours e, e + 1 of this lane's feature in one instruction: slices are 256 bytes apart (read2st64) or 64 (read2, dword offsets)
+#define GNNX_PC_R2(s, ad, i)                                                                                                           \
+    do {                                                                                                                               \
+        if constexpr (SLAB == 64)                                                                                                      \
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"((s).d[i]) : "v"(ad), "i"(2 * (i)), "i"(2 * (i) + 1) : "memory"); \
+        else                                                                                                                           \
+            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"((s).d[i]) : "v"(ad), "i"(32 * (i)), "i"(32 * (i) + 16) : "memory"); \
     } while (0)
-#define GNNX_PC_RV(s, r, i)                                                                                                    \
-    do {                                                                                                                       \
-        if constexpr (has_val(MODE)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"((s).vv[i]) : "v"((r).va), "i"(16 * (i)) : "memory"); \
-    } while (0)
-#define GNNX_PC_RS(s, r, i)                                                                                                    \
-    do {                                                                                                                       \
-        if constexpr (has_sc(MODE)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"((s).sv[i]) : "v"((r).sa), "i"(16 * (i)) : "memory");  \
-    } while (0)
-#define GNNX_PC_RF(s, r) asm volatile("ds_read_b32 %0, %1" : "=v"((s).fl) : "v"((r).fa) : "memory")
-    auto issue_reads = [&](Set &s, int32_t t) {   // all of them at once (the first sub-chunk)
-        const Rd r = rd_of(t);
-        GNNX_PC_R2(s, r, 0); GNNX_PC_R2(s, r, 1); GNNX_PC_R2(s, r, 2); GNNX_PC_R2(s, r, 3);
-        GNNX_PC_R2(s, r, 4); GNNX_PC_R2(s, r, 5); GNNX_PC_R2(s, r, 6); GNNX_PC_R2(s, r, 7);
-        GNNX_PC_RF(s, r);
-        GNNX_PC_RV(s, r, 0); GNNX_PC_RV(s, r, 1); GNNX_PC_RV(s, r, 2); GNNX_PC_RV(s, r, 3);
-        if constexpr (NREADS > 14) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // never more than 15 LDS operations outstanding
-        GNNX_PC_RS(s, r, 0); GNNX_PC_RS(s, r, 1); GNNX_PC_RS(s, r, 2); GNNX_PC_RS(s, r, 3);
+    auto issue_reads = [&](Set &s, uint32_t ad) {   // one ring slot -> 16 registers
+        GNNX_PC_R2(s, ad, 0); GNNX_PC_R2(s, ad, 1); GNNX_PC_R2(s, ad, 2); GNNX_PC_R2(s, ad, 3);
+        GNNX_PC_R2(s, ad, 4); GNNX_PC_R2(s, ad, 5); GNNX_PC_R2(s, ad, 6); GNNX_PC_R2(s, ad, 7);
     };
-    // this set's reads have returned; N: the LDS operations issued after them that stay in flight.  The set's registers are in-out
-    // operands so that no use of them is scheduled in front of the wait (only the fields the MODE reads: an unused operand costs a copy)
+#undef GNNX_PC_R2
+    // this set's reads have returned; N: the LDS operations issued after them that may stay in flight.  The registers are in-out
+    // operands so that no use of them is scheduled in front of the wait
     auto wait_set = [&](Set &s, auto keep) {
         constexpr int N = decltype(keep)::value;
-        if constexpr (has_val(MODE) && has_sc(MODE))
-            asm volatile("s_waitcnt lgkmcnt(%17)"
-                         : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7]), "+v"(s.vv[0]),
-                           "+v"(s.vv[1]), "+v"(s.vv[2]), "+v"(s.vv[3]), "+v"(s.sv[0]), "+v"(s.sv[1]), "+v"(s.sv[2]), "+v"(s.sv[3]), "+v"(s.fl)
-                         : "i"(N)
-                         : "memory");
-        else if constexpr (has_val(MODE))
-            asm volatile("s_waitcnt lgkmcnt(%13)"
-                         : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7]), "+v"(s.vv[0]),
-                           "+v"(s.vv[1]), "+v"(s.vv[2]), "+v"(s.vv[3]), "+v"(s.fl)
-                         : "i"(N)
-                         : "memory");
-        else if constexpr (has_sc(MODE))
-            asm volatile("s_waitcnt lgkmcnt(%13)"
-                         : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7]), "+v"(s.sv[0]),
-                           "+v"(s.sv[1]), "+v"(s.sv[2]), "+v"(s.sv[3]), "+v"(s.fl)
-                         : "i"(N)
-                         : "memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(%9)"
-                         : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7]), "+v"(s.fl)
-                         : "i"(N)
-                         : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%8)"
+                     : "+v"(s.d[0]), "+v"(s.d[1]), "+v"(s.d[2]), "+v"(s.d[3]), "+v"(s.d[4]), "+v"(s.d[5]), "+v"(s.d[6]), "+v"(s.d[7])
+                     : "i"(N)
+                     : "memory");
     };
-    auto wait_landed = [&](int32_t t, int32_t seen) {   // sub-chunk t is in LDS (`seen`: an earlier reading of its producer's flag)
-        const int32_t need = need_of(t);
+    using Keep8 = std::integral_constant<int, 8>;
+    using None = std::integral_constant<int, 0>;
+    float acc = 0.f;
+    // acc = RN(acc + x), sixteen times.  (Plain adds: the compiler issues a chunk's four blocks of reads first and its 64 adds last.
+    // Pinning the adds between the read blocks with volatile asm -- which covers the reads' latency on paper -- measured SLOWER,
+    // 6.1 vs 4.8 ns per neighbour for the consumer alone, as did one read after every add: 10.6.)
+    auto adds = [&](const Set &s) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            acc = add_rn(acc, s.d[i].x);
+            acc = add_rn(acc, s.d[i].y);
+        }
+    };
+    auto adds_n = [&](const Set &s, int32_t cnt) {   // the row's last sub-chunk: cnt of 16
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (2 * i < cnt) acc = add_rn(acc, s.d[i].x);
+            if (2 * i + 1 < cnt) acc = add_rn(acc, s.d[i].y);
+        }
+    };
+    // index chunk c belongs to producer c % NP, its sub-chunks are that producer's own 4 (c / NP) ..: (p, own0) walk along with c
+    auto wait_chunk = [&](int32_t p, int32_t need, int32_t seen) {   // producer p has landed (and finished) `need` own sub-chunks
         if (seen >= need) return;
 #ifdef GNNX_EXPERIMENTS
-        if (a.pc_experiment == 1) return;
+        if (a.pc_experiment == 1 || a.pc_experiment == 3) return;
 #endif
         int32_t spins = 0;
-        while (flag_read(flag_of(t)) < need) {
+        while (flag_read(fl0 + 4u * (uint32_t)p) < need) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > kSpinCap) break;   // bounded exit (never reached: the producers do not wait for anything but this wavefront)
         }
     };
-    float acc = 0.f;
-    // the 16 terms of a sub-chunk as they are added: the slice values through the prologue (straight-line code, as spmm_hub_kernel's
-    // pro_batch), the gathered column scale and the per-entry value -- separately rounded, in that order
-    auto terms = [&](Set &s, float(&v)[kHubSub]) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            v[2 * i] = s.d[i].x;
-            v[2 * i + 1] = s.d[i].y;
-        }
-        if constexpr (has_pro(MODE)) {
-            if constexpr (pro_bn(MODE)) {
-                float d[kHubSub];
-                bool bad = false;
-#pragma unroll
-                for (int j = 0; j < kHubSub; j++) {
-                    d[j] = __fsub_rn(v[j], pc.mean);
-                    v[j] = (float)((double)d[j] * pc.rsd[0]);
-                    bad |= !(fabsf(v[j]) >= 1.17549435e-38f) && d[j] != 0.f;
-                }
-                if (__builtin_expect(bad, 0)) {
-#pragma unroll
-                    for (int j = 0; j < kHubSub; j++) v[j] = __fdiv_rn(d[j], pc.sd);
-                }
-#pragma unroll
-                for (int j = 0; j < kHubSub; j++) v[j] = __fadd_rn(__fmul_rn(v[j], pc.gamma), pc.beta);
-            }
-            if constexpr (pro_relu(MODE)) {
-#pragma unroll
-                for (int j = 0; j < kHubSub; j++) v[j] = relu1(v[j]);
-            }
-        }
-        if constexpr (has_sc(MODE)) {
-#pragma unroll
-            for (int j = 0; j < kHubSub; j++) v[j] = mul_rn(v[j], s.sv[j >> 2][j & 3]);
-        }
-        if constexpr (has_val(MODE)) {
-#pragma unroll
-            for (int j = 0; j < kHubSub; j++) v[j] = mul_rn(v[j], s.vv[j >> 2][j & 3]);
-        }
-    };
-    // acc = RN(acc + x), pinned in program order between the LDS reads (a volatile asm is not moved across another one)
-#define GNNX_PC_ADD(x) asm volatile("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(x))
-    using None = std::integral_constant<int, 0>;
-    // One step, t + 1 < nsub: `cur` holds sub-chunk t (complete); its 16 adds run with the reads of sub-chunk t + 1 (into `nxt`)
-    // between the first of them -- the last adds cover the reads' latency -- then nxt is waited for.  Never more than 15 LDS operations
-    // outstanding (lgkmcnt is a 4-bit counter).  nxt.fl, which travelled with sub-chunk t - 1's reads, is the reading of the flag
-    // sub-chunk t + 1 is checked against.
-    auto step = [&](Set &cur, Set &nxt, int32_t t) {
-        flag_write(fl0 + 4u * NP, t + 1);   // the slot of sub-chunk t is free (its words are in registers)
-        wait_landed(t + 1, __builtin_amdgcn_readfirstlane(nxt.fl));
-        float v[kHubSub];
-        terms(cur, v);
-        const Rd r = rd_of(t + 1);
-        GNNX_PC_ADD(v[0]); GNNX_PC_R2(nxt, r, 0);
-        GNNX_PC_ADD(v[1]); GNNX_PC_R2(nxt, r, 1);
-        GNNX_PC_ADD(v[2]); GNNX_PC_R2(nxt, r, 2);
-        GNNX_PC_ADD(v[3]); GNNX_PC_R2(nxt, r, 3);
-        GNNX_PC_ADD(v[4]); GNNX_PC_R2(nxt, r, 4);
-        GNNX_PC_ADD(v[5]); GNNX_PC_R2(nxt, r, 5);
-        GNNX_PC_ADD(v[6]); GNNX_PC_R2(nxt, r, 6);
-        GNNX_PC_ADD(v[7]); GNNX_PC_R2(nxt, r, 7);
-        GNNX_PC_ADD(v[8]); GNNX_PC_RF(nxt, r); GNNX_PC_RV(nxt, r, 0); GNNX_PC_RV(nxt, r, 1);
-        GNNX_PC_ADD(v[9]); GNNX_PC_RV(nxt, r, 2); GNNX_PC_RV(nxt, r, 3);
-        if constexpr (NREADS > 14) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");   // (values + column scales: 17 reads and the flag write)
-        GNNX_PC_ADD(v[10]); GNNX_PC_RS(nxt, r, 0); GNNX_PC_RS(nxt, r, 1);
-        GNNX_PC_ADD(v[11]); GNNX_PC_RS(nxt, r, 2); GNNX_PC_RS(nxt, r, 3);
-        GNNX_PC_ADD(v[12]);
-        GNNX_PC_ADD(v[13]);
-        GNNX_PC_ADD(v[14]);
-        GNNX_PC_ADD(v[15]);
-        wait_set(nxt, None{});
-    };
-    // the row's last sub-chunk (possibly short), complete in `cur`
-    auto last = [&](Set &cur, int32_t t) {
-        float v[kHubSub];
-        terms(cur, v);
-        const int32_t cnt = total - t * kHubSub;
-#pragma unroll
-        for (int j = 0; j < kHubSub; j++)
-            if (j < cnt) acc = add_rn(acc, v[j]);
-    };
+    const int32_t nchunk = (nsub + 3) >> 2;
+    int32_t p = 0, own0 = 0;   // of the chunk being added
     Set A, B;
-    B.fl = 0;
-    wait_landed(0, 0);
-    issue_reads(A, 0);
-    wait_set(A, None{});
-    for (int32_t t = 0;;) {
-        if (t + 1 >= nsub) { last(A, t); break; }
-        step(A, B, t++);
-        if (t + 1 >= nsub) { last(B, t); break; }
-        step(B, A, t++);
+    wait_chunk(0, nchunk > 1 ? 4 : nsub, 0);
+    issue_reads(A, ring_lane);
+    int32_t c = 0;
+    for (; c + 1 < nchunk; c++) {
+        // precondition: chunk c is complete in LDS, the reads of its first sub-chunk are in flight into A
+        const int32_t pn = p + 1 == NP ? 0 : p + 1, own0n = p + 1 == NP ? own0 + 4 : own0;   // the next chunk's producer / first own sub-chunk
+        const int32_t need_n = own0n + (c + 2 < nchunk ? 4 : nsub - 4 * (c + 1));            // (the row's last chunk may be short)
+        int32_t fl;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(fl) : "v"(fl0 + 4u * (uint32_t)pn) : "memory");   // early: it has returned long before it is looked at
+        const uint32_t ad = ring_lane + (uint32_t)((4 * c) & (S - 1)) * SLOT_BYTES;
+        issue_reads(B, ad + SLOT_BYTES);
+        wait_set(A, Keep8{});
+        adds(A);
+        issue_reads(A, ad + 2 * SLOT_BYTES);
+        wait_set(B, Keep8{});
+        adds(B);
+        issue_reads(B, ad + 3 * SLOT_BYTES);
+        wait_set(A, Keep8{});
+        adds(A);
+        wait_chunk(pn, need_n, __builtin_amdgcn_readfirstlane(fl));
+        issue_reads(A, ring_lane + (uint32_t)((4 * c + 4) & (S - 1)) * SLOT_BYTES);
+        wait_set(B, Keep8{});
+        flag_write(fl0 + 4u * NP, 4 * c + 4);   // the four slots of chunk c are free (their words are in registers)
+        adds(B);
+        p = pn;
+        own0 = own0n;
     }
-#undef GNNX_PC_ADD
-#undef GNNX_PC_R2
-#undef GNNX_PC_RV
-#undef GNNX_PC_RS
-#undef GNNX_PC_RF
+    {   // the row's last index chunk: 1 .. 4 sub-chunks, the last one possibly short; the reads of its first are in flight into A
+        const uint32_t ad = ring_lane + (uint32_t)((4 * c) & (S - 1)) * SLOT_BYTES;
+        const int32_t r = nsub - 4 * c;
+        const int32_t cnt_last = total - (nsub - 1) * kHubSub;
+        wait_set(A, None{});
+        for (int32_t k = 0; k < r; k++) {
+            if (k + 1 < r) {
+                adds(A);
+                issue_reads(A, ad + (uint32_t)(k + 1) * SLOT_BYTES);
+                wait_set(A, None{});
+            } else {
+                adds_n(A, cnt_last);
+            }
+        }
+    }
     if (active) {  // the epilogue of epilogue_store<1>, same op order
         float v = acc;
         if (a.rowscale) v = mul_rn(v, a.rowscale[row]);
@@ -1817,29 +1773,32 @@ int64_t bn_sums_stream_waves(int32_t n_rows, int32_t n_feat, const gnnx_spmm_pla
 //   chain: kHubNsPerNeighbour per non-zero of the longest row (one accumulator per feature, the reference's order);
 //   bytes: hub non-zeros x row bytes at kHubBytesPerNs.
 // RMAT 1M / 10M, F = 128: beside (0.92 -> 0.79 ms); RMAT 10M / 100M, F = 256 (28 GB of hub rows): in front (13.59 vs 13.76 ms beside).
-constexpr double kHubNsPerNeighbour = 12.0;   // spmm_hub_kernel (the rows up to kHubBigRow)   // profiles/r03: 0.75 ms for the 62 k-entry longest row of RMAT 1M / 10M
+constexpr double kHubNsPerNeighbour = 17.0;   // spmm_hub_kernel, one row alone: 4.29 ms for 250 k neighbours (scripts/exp_hub_row.py; the pc kernel: 4.5)   // profiles/r03: 0.75 ms for the 62 k-entry longest row of RMAT 1M / 10M
 constexpr double kHubBytesPerNs = 7000.0;     // ~7 TB/s on the hub rows of the headline graph
+constexpr double kHubBesideBytes = 8.0e9;     // hub rows of fewer bytes run beside the row kernel (28 GB on the whole headline graph: in front)
 bool hub_is_chain_bound(int32_t max_hub_degree, int64_t n_hub_nnz, int32_t n_feat, int bytes_per_feature)
 {
     const double chain_ns = (double)max_hub_degree * kHubNsPerNeighbour;
-    const double bytes_ns = (double)n_hub_nnz * (double)n_feat * bytes_per_feature / kHubBytesPerNs;
-    return chain_ns > bytes_ns;
+    const double bytes = (double)n_hub_nnz * (double)n_feat * bytes_per_feature;
+    // ... or when its bytes are few: a small hub kernel does not fill the memory system by itself (one rank of 8 of the 10 M / 100 M
+    // graph: 2.5 GB in 0.45 ms = 5.5 TB/s, in FRONT of a 1.33 ms streaming kernel -- kernel trace, profiles/r04_shard_rank0_trace.txt);
+    // beside the streaming kernel the two share what the memory system delivers
+    return chain_ns > bytes / kHubBytesPerNs || bytes < kHubBesideBytes;
 }
 
 // How many of the plan's hub rows (longest first) take the producer / consumer kernel for an aggregation of `n_feat` f32 features:
-// those whose chain in spmm_hub_kernel (kHubNsPerNeighbour per non-zero) would stick out of what runs beside it -- longer than HALF
-// of the larger of the hub rows' bytes and the other rows' bytes at kHubBytesPerNs.  Whole 10 M / 100 M graph: none or a handful
-// (everything hides behind 80 GB of other rows); one rank's eighth of it: the rows beyond ~50 k non-zeros (a rank keeps the longest
-// rows whole but only an eighth of the bytes); RMAT 1M / 10M, F = 128: the three rows beyond 26 k.  Few rows on purpose: every
-// (row, 16-feature slab) takes a whole CU's LDS, and spmm_hub_kernel's workgroups need the CUs these leave.  A threshold fixed by
-// the caller (tests) wins.
+// those whose chain in spmm_hub_kernel (kHubNsPerNeighbour per non-zero) would be longer than HALF of what all the hub rows' bytes
+// take at kHubBytesPerNs -- on the whole 10 M / 100 M graph a handful of rows beyond ~100 k non-zeros (everything else hides behind
+// 28 GB of hub rows), on one rank's eighth of it the rows beyond ~15 k (a rank keeps the longest rows whole but only an eighth of the
+// bytes), on RMAT 1M / 10M everything beyond kHubBigRowMin.  (Measured against a rule that also let the OTHER rows' bytes hide a
+// chain -- fewer rows here, more on spmm_hub_kernel: one rank of 8, aggregation 1.78 -> 2.15 ms; RMAT 1M / 10M 0.59 -> 0.65.)  A
+// threshold fixed by the caller (tests) wins.
 int32_t big_rows_for(const gnnx_spmm_plan *plan, int32_t n_feat)
 {
     const auto &deg = plan->h_hub_degrees;
     int32_t thr = plan->big_row_threshold;
     if (thr < 0) {
-        const int64_t rest = plan->nnz > plan->n_hub_nnz ? plan->nnz - plan->n_hub_nnz : 0;
-        const double bytes_ns = (double)(plan->n_hub_nnz > rest ? plan->n_hub_nnz : rest) * (double)n_feat * 4.0 / kHubBytesPerNs;
+        const double bytes_ns = (double)plan->n_hub_nnz * (double)n_feat * 4.0 / kHubBytesPerNs;
         const double t = 0.5 * bytes_ns / kHubNsPerNeighbour;
         thr = t > 2.0e9 ? 2000000000 : (int32_t)t;
         if (thr < kHubBigRowMin) thr = kHubBigRowMin;

@@ -37,7 +37,7 @@ def main():
     n = int(os.environ.get("N", 4_000_000))
     for F in Fs:
         X = ops.uniform_pm1(1, (n, F), device=dev)
-        for L in (20_000, 250_000):
+        for L in (20_000, 250_000) if n > 250_000 else (n // 50, n // 2):
             # row 0 has L random neighbours, every other row is empty
             cols = torch.randperm(n - 1, device=dev)[:L].to(torch.int32) + 1
             src = torch.zeros(L, dtype=torch.int32, device=dev)
