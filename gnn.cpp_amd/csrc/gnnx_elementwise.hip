@@ -586,26 +586,26 @@ GNNX_API int gnnx_pow_f32(const float *d_x, int64_t n, float exponent, float *d_
     // [0, 2^24]) the result is looked up in a table of that very libm call, table[k] = powf((float)k, e) -- the reference's bits, where a
     // device pow would be 1 ulp off for some k.  One reduction, one host synchronisation and max + 1 libm calls: a graph-build call,
     // not a per-step one.  Any other argument vector is evaluated on the device (tolerance-level against the host libm).
-    int32_t *d_info = nullptr;
-    GNNX_HIP_CHECK(hipMallocAsync((void **)&d_info, 2 * sizeof(int32_t), st));
-    DeviceFree free_info{d_info, st};
+    // (temporaries with the synchronous allocator and synchronous copies, as in gnnx_degree_norm_f32: see the note there)
+    DeviceFreeSync info_g, table_g;
+    GNNX_HIP_CHECK(hipMalloc(&info_g.p, 2 * sizeof(int32_t)));
+    int32_t *d_info = static_cast<int32_t *>(info_g.p);
     GNNX_HIP_CHECK(hipMemsetAsync(d_info, 0, 2 * sizeof(int32_t), st));
     hipLaunchKernelGGL(pow_scan_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, d_info);
     GNNX_LAUNCH_CHECK();
-    int32_t info[2] = {0, 1};
-    GNNX_HIP_CHECK(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
     GNNX_HIP_CHECK(hipStreamSynchronize(st));
+    int32_t info[2] = {0, 1};
+    GNNX_HIP_CHECK(hipMemcpy(info, d_info, sizeof(info), hipMemcpyDeviceToHost));
     if (!info[1]) {
         std::vector<float> table((size_t)info[0] + 1);
         volatile float e = exponent;   // a run-time exponent: the call stays the libm's powf whatever the optimiser knows about it
         for (int64_t k = 0; k <= info[0]; k++) table[(size_t)k] = powf((float)k, e);
-        float *d_table = nullptr;
-        GNNX_HIP_CHECK(hipMallocAsync((void **)&d_table, sizeof(float) * table.size(), st));
-        DeviceFree free_table{d_table, st};
-        GNNX_HIP_CHECK(hipMemcpyAsync(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, st));
+        GNNX_HIP_CHECK(hipMalloc(&table_g.p, sizeof(float) * table.size()));
+        float *d_table = static_cast<float *>(table_g.p);
+        GNNX_HIP_CHECK(hipMemcpy(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice));   // complete on return
         hipLaunchKernelGGL(pow_table_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, d_table, d_y);
         GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // `table` is pageable host memory: read by the copy until here
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // the table is freed behind the kernel
         return GNNX_OK;
     }
     hipLaunchKernelGGL(pow_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, exponent, d_y);

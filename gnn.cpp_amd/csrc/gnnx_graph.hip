@@ -99,6 +99,15 @@ __global__ void max_degree_kernel(const int32_t *rowptr, int32_t n_rows, int32_t
     if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(out, d);
 }
 
+#ifdef GNNX_EXPERIMENTS
+__global__ void deg_rsqrt_exp_kernel(const int32_t *rowptr, int32_t n_rows, float *s)   // A/B only: the correctly rounded value, no table
+{
+    int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    s[i] = (float)(1.0 / sqrt((double)((float)(rowptr[i + 1] - rowptr[i]) + 1.0f)));
+}
+#endif
+
 __global__ void deg_pow_table_kernel(const int32_t *rowptr, int32_t n_rows, const float *table, float *s)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -485,30 +494,41 @@ GNNX_API int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_coli
     hipStream_t st = as_stream(stream);
     const int T = 256;
     dim3 grid((uint32_t)ceil_div(n_rows, T));
+#ifdef GNNX_EXPERIMENTS
+    static const int deg_exp = [] { const char *e = experiment_env("GNNX_DEG_RSQRT"); return e ? atoi(e) : 0; }();
+    if (d_s && deg_exp) {
+        hipLaunchKernelGGL(deg_rsqrt_exp_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_s);
+        GNNX_LAUNCH_CHECK();
+    } else
+#endif
     if (d_s) {
         // table[k] = the host libm's powf((float)k, -0.5f) for k = 1 .. 1 + max degree: what the reference evaluates per vertex
         // (functional.h:253).  One reduction + one host synchronisation + (1 + max degree) libm calls, once per graph.
-        int32_t *d_max = nullptr;
-        GNNX_HIP_CHECK(hipMallocAsync((void **)&d_max, sizeof(int32_t), st));
-        DeviceFree free_max{d_max, st};
+        // Every temporary with the SYNCHRONOUS allocator and synchronous copies.  This is a once-per-graph call, and rank threads of an
+        // in-process group build their shards concurrently, each on a stream of its own: with stream-ordered temporaries
+        // (hipMallocAsync / hipFreeAsync) and asynchronous copies from / to pageable host memory the table path gave a wrong s now and
+        // then (tests/cpp/test_host_sharded_gpu with 4 ranks: 1-4 of 10 runs exact, whether or not the copy was waited for before the
+        // kernel that reads the table; the device-side rsqrt: 6 of 6; this form: 21 of 22, the odd one not reproduced in 12 more).
+        DeviceFreeSync max_g, table_g;
+        GNNX_HIP_CHECK(hipMalloc(&max_g.p, sizeof(int32_t)));
+        int32_t *d_max = static_cast<int32_t *>(max_g.p);
         GNNX_HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(max_degree_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_max);
         GNNX_LAUNCH_CHECK();
-        int32_t h_max = 0;
-        GNNX_HIP_CHECK(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         GNNX_HIP_CHECK(hipStreamSynchronize(st));
+        int32_t h_max = 0;
+        GNNX_HIP_CHECK(hipMemcpy(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost));
         GNNX_REQUIRE(h_max >= 0, GNNX_ERR_INVALID_ARG, "rowptr is not monotone");
         std::vector<float> table((size_t)h_max + 2);
         table[0] = 0.f;
         volatile float expo = -0.5f;   // a run-time exponent: the call stays a libm powf call whatever the optimiser knows about -0.5
         for (int64_t k = 1; k <= (int64_t)h_max + 1; k++) table[(size_t)k] = powf((float)k, expo);
-        float *d_table = nullptr;
-        GNNX_HIP_CHECK(hipMallocAsync((void **)&d_table, sizeof(float) * table.size(), st));
-        DeviceFree free_table{d_table, st};
-        GNNX_HIP_CHECK(hipMemcpyAsync(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice, st));
+        GNNX_HIP_CHECK(hipMalloc(&table_g.p, sizeof(float) * table.size()));
+        float *d_table = static_cast<float *>(table_g.p);
+        GNNX_HIP_CHECK(hipMemcpy(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice));   // complete on return
         hipLaunchKernelGGL(deg_pow_table_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_table, d_s);
         GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // `table` (pageable host memory) is read by the copy until here
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // the table is freed behind the kernel
     }
     if (d_norm) {
         if (!d_colidx) {  // only a graph without entries may come without colidx (once-per-graph call: the sync is fine)

@@ -1889,6 +1889,10 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         a.pc_experiment = pc_exp;
 #endif
         a.n_big_rows = big_rows_for(plan, n_feat);
+#ifdef GNNX_EXPERIMENTS
+        static const int pc_off = [] { const char *e = experiment_env("GNNX_PC_OFF"); return e ? atoi(e) : 0; }();
+        if (pc_off) a.n_big_rows = 0;
+#endif
         if (a.n_big_rows > 0 && a.n_big_rows < a.n_hub_rows)   // what is left for spmm_hub_kernel: is IT bound by its longest row's chain?
             a.hub_beside = hub_is_chain_bound(plan->h_hub_degrees[(size_t)a.n_big_rows], plan->n_hub_nnz - plan->h_hub_prefix[(size_t)a.n_big_rows],
                                               n_feat, 4);
