@@ -534,8 +534,15 @@ class SingleGpu:
         # consecutive: measured (scripts/exp_gemm_in_step.py), the f32 MFMA product takes 9.4 ms behind another product but 10.6 ms
         # behind an aggregation and 11.6 ms after 50 ms of idle -- the core clock has to come back up after a memory-bound
         # kernel -- so one such transition per step instead of two.
-        run(lambda: ops.colsum(self.G, out=self.dbias))
-        run(lambda: ops.aggregate_bwd_sym(g, self.G, out=self.dH) if sym else ops.aggregate_bwd(g, self.G, out=self.dH))
+        if getattr(self, "gather_pitch", False):
+            # vertices as the data set numbers them (no relabelling): the two matrices the aggregations GATHER from sit on the padded
+            # row pitch (gnnx_gather_row_stride) -- H is the layer's own intermediate (the product writes it there), the caller's
+            # upstream gradient G is copied there by the pass that sums its columns anyway (gnnx_colsum_copy_f32)
+            run(lambda: ops.colsum_copy(self.G, self.Gpad, out=self.dbias))
+            run(lambda: ops.aggregate_bwd(g, self.Gpad, out=self.dH))
+        else:
+            run(lambda: ops.colsum(self.G, out=self.dbias))
+            run(lambda: ops.aggregate_bwd_sym(g, self.G, out=self.dH) if sym else ops.aggregate_bwd(g, self.G, out=self.dH))
         run(lambda: ops.gemm_split(self.dH, self.W, transB=False, out=self.dX) if split else ops.gemm(self.dHp, self.Wp, out=self.dXp))
         run(lambda: ops.gemm(self.dHp, self.Xp, transA=True, out=self.dWp))
         run(lambda: ops.gemm_split(self.X, self.W, transB=True, out=self.H) if split else ops.linear_fwd(self.Xp, self.Wp[:self.F], out=self.H))
@@ -556,23 +563,40 @@ class SingleGpu:
         del src, dst
         if chunk > 0:
             g2.make_plans(chunk, self.F)
-        keep_g, keep_ev = self.g, self.ev
-        self.g, self.ev = g2, []
-        for _ in range(warmup):
-            self.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step(timed=True)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        kt = self.kernel_times()
-        self.g, self.ev = keep_g, keep_ev
+        keep_g, keep_ev, keep_H = self.g, self.ev, self.H
+        self.g = g2
+
+        def run_steps():
+            self.ev = []
+            for _ in range(warmup):
+                self.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(timed=True)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3, self.kernel_times()
+
+        ms, kt = run_steps()   # (1) nothing but the labels changed: gathered rows on their own width
+        out = {"order": "as-generated", "steps": steps, "ms_per_step": ms, "spmm_fwd_ms": kt.get("spmm_fwd"), "spmm_bwd_ms": kt.get("spmm_bwd"),
+               "note": "same per-vertex bits as the default order (tests/test_gpu_parity.py::test_headline_config_whole_graph_vs_oracle)"}
+        if ops.gather_row_stride(n, self.F) != self.F and self.Fp == self.F:
+            # (2) what the library does for a caller who did not relabel the data set: the gathered matrices on the padded row pitch
+            self.H = ops.empty_gathered(n, self.F, device=self.X.device)
+            self.Gpad = ops.empty_gathered(n, self.F, device=self.X.device)
+            self.gather_pitch = True
+            ms2, kt2 = run_steps()
+            self.gather_pitch = False
+            del self.Gpad
+            out["padded_gather_pitch"] = {"ms_per_step": ms2, "spmm_fwd_ms": kt2.get("spmm_fwd"), "spmm_bwd_ms": kt2.get("spmm_bwd"),
+                                          "colsum_and_copy_ms": kt2.get("colsum"), "gathered_row_pitch_floats": ops.gather_row_stride(n, self.F),
+                                          "what": "vertices as generated; H (the layer's intermediate) and a copy of the upstream gradient made "
+                                                  "by the column-sum pass sit on the padded row pitch (gnnx_gather_row_stride)"}
+        self.g, self.ev, self.H = keep_g, keep_ev, keep_H
         del g2
         ops._ws_cache.clear()
         torch.cuda.empty_cache()
-        return {"order": "as-generated", "steps": steps, "ms_per_step": ms, "spmm_fwd_ms": kt.get("spmm_fwd"), "spmm_bwd_ms": kt.get("spmm_bwd"),
-                "note": "same per-vertex bits as the default order (tests/test_gpu_parity.py::test_headline_config_whole_graph_vs_oracle)"}
+        return out
 
     def kernel_times(self):
         out = {}

@@ -63,6 +63,7 @@ _SIGS = {
     "gnnx_memcpy_h2d": [_vp, _vp, _sz, _vp],
     "gnnx_memcpy_d2h": [_vp, _vp, _sz, _vp],
     "gnnx_memcpy_d2d": [_vp, _vp, _sz, _vp],
+    "gnnx_memcpy2d_d2d": [_vp, _sz, _vp, _sz, _sz, _sz, _vp],
     "gnnx_stream_create": [C.POINTER(_vp)],
     "gnnx_stream_destroy": [_vp],
     "gnnx_stream_sync": [_vp],
@@ -84,6 +85,7 @@ _SIGS = {
     "gnnx_spmm_plan_destroy": [_vp],
     "gnnx_spmm_plan_info": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
     "gnnx_spmm_plan_set_big_row_threshold": [_vp, _i32],
+    "gnnx_spmm_plan_hub_ids_structured": [_vp, C.POINTER(C.c_int)],
     "gnnx_spmm_csr_bn_sums_workspace": [_i32, _i32, _vp, C.POINTER(_sz)],
     "gnnx_spmm_csr_bn_sums_f32": [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _f32, _vp, _vp, C.c_int, _vp, _vp,
                                   _vp, _sz, _vp, _vp],
@@ -101,6 +103,8 @@ _SIGS = {
     "gnnx_gemm_split_bf16_f32": [C.c_int, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _sz, _vp],
     "gnnx_colsum_workspace": [_i64, _i32, C.POINTER(_sz)],
     "gnnx_colsum_f32": [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp],
+    "gnnx_colsum_copy_f32": [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _i64, _vp, _sz, _vp],
+    "gnnx_gather_row_stride": [_i64, _i32, C.POINTER(_i64)],
     "gnnx_rowscale_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_bias_add_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_axpy_f32": [_i64, _f32, _vp, _vp, _vp],

@@ -21,9 +21,11 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Vector form (F % 4 == 0, 16-B aligned): a row is covered by L = F/4 lanes (16 B each, coalesced); the 256
 // threads form 256/L row groups that walk the slab interleaved, 4 rows in flight per thread; the groups'
 // partials are combined through LDS in group order.  Fixed grid and fixed order => deterministic.
-template <int UNROLL>
+// COPY: every row that is read is also written to `copy` (row stride ldc) -- gnnx_colsum_copy_f32: the upstream gradient on the
+// padded row stride the backward aggregation gathers from, made by the pass that reads it anyway.
+template <int UNROLL, bool COPY = false>
 __global__ __launch_bounds__(256) void colsum_stage1_vec(const float *G, int64_t ldg, int64_t n_rows, int32_t n_feat,
-                                                          int64_t rows_per_block, float *partial)
+                                                          int64_t rows_per_block, float *partial, float *copy = nullptr, int64_t ldc = 0)
 {
     __shared__ float4 red[256];
     const int L = n_feat / 4;            // lanes per row (<= 256)
@@ -45,11 +47,13 @@ __global__ __launch_bounds__(256) void colsum_stage1_vec(const float *G, int64_t
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
                     acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
+                    if constexpr (COPY) *reinterpret_cast<float4 *>(copy + f0 + 4 * li + (r + (int64_t)u * groups) * ldc) = v[u];
                 }
             }
             for (; r < r1; r += groups) {
                 float4 v = *reinterpret_cast<const float4 *>(base + r * ldg);
                 acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+                if constexpr (COPY) *reinterpret_cast<float4 *>(copy + f0 + 4 * li + r * ldc) = v;
             }
         }
         float4 t = acc[0];
@@ -392,8 +396,9 @@ GNNX_API int gnnx_colsum_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes
     return GNNX_OK;
 }
 
-GNNX_API int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out,
-                             void *d_workspace, size_t workspace_bytes, void *stream)
+namespace {
+int colsum_impl(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out, float *d_copy, int64_t ldc,
+                void *d_workspace, size_t workspace_bytes, void *stream)
 {
     GNNX_REQUIRE(n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "negative size");
     if (n_feat == 0) return GNNX_OK;
@@ -408,8 +413,21 @@ GNNX_API int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int3
     int64_t rpb = ceil_div(n_rows > 0 ? n_rows : 1, nb);
     const bool vec = n_feat % 4 == 0 && ldg % 4 == 0 && aligned16(d_G) && aligned16(partial) && n_feat / 4 <= 256 &&
                      256 % (n_feat / 4) == 0;
+    if (d_copy) {   // the copy rides in the 16-byte kernel only; other shapes: the plain sums and a strided copy behind them
+        GNNX_REQUIRE(ldc >= n_feat && d_copy != d_G, GNNX_ERR_INVALID_ARG, "copy: ld < n_feat or aliasing");
+        if (vec && ldc % 4 == 0 && aligned16(d_copy)) {
+            hipLaunchKernelGGL((colsum_stage1_vec<4, true>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
+            GNNX_LAUNCH_CHECK();
+            hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);
+            GNNX_LAUNCH_CHECK();
+            return GNNX_OK;
+        }
+        if (n_rows > 0)
+            GNNX_HIP_CHECK(hipMemcpy2DAsync(d_copy, sizeof(float) * (size_t)ldc, d_G, sizeof(float) * (size_t)ldg, sizeof(float) * (size_t)n_feat,
+                                            (size_t)n_rows, hipMemcpyDeviceToDevice, st));
+    }
     if (vec) {
-        hipLaunchKernelGGL(colsum_stage1_vec<4>, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial);
+        hipLaunchKernelGGL(colsum_stage1_vec<4>, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, nullptr, 0);
     } else if (n_feat >= 128) {
         hipLaunchKernelGGL(colsum_stage1, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial);
     } else {
@@ -421,6 +439,32 @@ GNNX_API int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int3
     hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta,
                        d_out);
     GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
+}
+}  // namespace
+
+GNNX_API int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out,
+                             void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    return colsum_impl(d_G, ldg, n_rows, n_feat, beta, d_out, nullptr, 0, d_workspace, workspace_bytes, stream);
+}
+
+GNNX_API int gnnx_colsum_copy_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out, float *d_copy,
+                                  int64_t ldc, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(d_copy, GNNX_ERR_INVALID_ARG, "copy is null");
+    return colsum_impl(d_G, ldg, n_rows, n_feat, beta, d_out, d_copy, ldc, d_workspace, workspace_bytes, stream);
+}
+
+GNNX_API int gnnx_gather_row_stride(int64_t n_rows, int32_t n_feat, int64_t *ld_out)
+{
+    GNNX_REQUIRE(ld_out && n_rows >= 0 && n_feat >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    // Rows of k * 512 bytes gathered by index from a big matrix: with a power-of-two row pitch the rows of a synthetic power-law
+    // graph's hubs (vertex ids with few one-bits) have addresses with few one-bits and pile onto a few memory channels /
+    // Infinity-Cache slices.  64 floats of padding per row spread them: RMAT 10 M / 100 M, F = 256, vertices as generated, forward
+    // aggregation 17.75 ms on stride 256, 14.64 / 14.35 / 14.13 / 13.88 ms on 264 / 272 / 288 / 320 (13.76 with the vertices
+    // relabelled by a multiplicative hash; scripts/exp_spmm_stride.py).  Small matrices (cache-resident) keep their width.
+    *ld_out = (n_feat > 0 && (n_feat * 4) % 512 == 0 && n_rows * (int64_t)n_feat >= (int64_t)1 << 24) ? (int64_t)n_feat + 64 : (int64_t)n_feat;
     return GNNX_OK;
 }
 

@@ -112,6 +112,15 @@ GNNX_API int gnnx_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void 
     return GNNX_OK;
 }
 
+GNNX_API int gnnx_memcpy2d_d2d(void *d_dst, size_t dst_pitch_bytes, const void *d_src, size_t src_pitch_bytes, size_t width_bytes, size_t rows,
+                               void *stream)
+{
+    if (width_bytes == 0 || rows == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_dst && d_src && dst_pitch_bytes >= width_bytes && src_pitch_bytes >= width_bytes, GNNX_ERR_INVALID_ARG, "null pointer or pitch < width");
+    GNNX_HIP_CHECK(hipMemcpy2DAsync(d_dst, dst_pitch_bytes, d_src, src_pitch_bytes, width_bytes, rows, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return GNNX_OK;
+}
+
 GNNX_API int gnnx_stream_create(void **stream)
 {
     GNNX_REQUIRE(stream, GNNX_ERR_INVALID_ARG, "stream is null");

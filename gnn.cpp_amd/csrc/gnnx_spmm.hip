@@ -47,6 +47,7 @@ struct gnnx_spmm_plan {
     int32_t big_row_threshold = -1;
     std::vector<int32_t> h_hub_degrees;  // host copy of the sorted degrees, longest first
     std::vector<int64_t> h_hub_prefix;   // h_hub_prefix[k] = non-zeros of the k longest rows
+    std::vector<int32_t> h_hub_rows;     // host copy of the hub rows' ids, longest first (gnnx_spmm_plan_hub_ids_structured)
     int32_t *d_hub_rows = nullptr;  // [n_split_rows] the hub rows, longest first: work list of the hub kernels
     unsigned long long *d_counters = nullptr;
     // non-zero-balanced row blocks for the streaming kernel: block k owns rows [d_block_starts[k], [k+1])
@@ -1661,6 +1662,7 @@ int plan_build(gnnx_spmm_plan *plan, const int32_t *d_rowptr, int32_t n_rows, in
         std::vector<int32_t> h_hub(h_rows.size());
         for (size_t i = 0; i < h_rows.size(); i++) h_hub[i] = h_rows[i].x;
         plan->max_hub_degree = h_rows.empty() ? 0 : h_rows[0].y;
+        plan->h_hub_rows = h_hub;
         plan->h_hub_degrees.resize(h_rows.size());
         plan->h_hub_prefix.assign(h_rows.size() + 1, 0);
         for (size_t i = 0; i < h_rows.size(); i++) {
@@ -1718,6 +1720,27 @@ GNNX_API int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int3
         return rc;
     }
     *plan_out = plan;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_spmm_plan_hub_ids_structured(const gnnx_spmm_plan *plan, int *structured)
+{
+    GNNX_REQUIRE(plan && structured, GNNX_ERR_INVALID_ARG, "null pointer");
+    // The hub rows of this CSR are the rows the TRANSPOSED aggregation gathers most (a vertex with many out-edges is read by many
+    // rows of A^T).  Synthetic power-law generators (R-MAT) put them on the ids with few one-bits: then a power-of-two row pitch of
+    // the gathered matrix piles them onto a few memory channels and the caller should use gnnx_gather_row_stride.  Measured here as
+    // the non-zero-weighted mean popcount of the hub ids against half the id width (what ids spread at random would show).
+    *structured = 0;
+    if (plan->h_hub_rows.empty() || plan->n_rows < 2) return GNNX_OK;
+    double bits = 0.0, weight = 0.0;
+    for (size_t i = 0; i < plan->h_hub_rows.size(); i++) {
+        const double w = (double)plan->h_hub_degrees[i];
+        bits += w * (double)__builtin_popcount((uint32_t)plan->h_hub_rows[i]);
+        weight += w;
+    }
+    int width = 0;
+    while ((1ll << width) < (long long)plan->n_rows) width++;
+    *structured = bits / weight < 0.7 * 0.5 * (double)width;
     return GNNX_OK;
 }
 

@@ -223,18 +223,21 @@ tptr<T> matmul(const tptr<T> &lhs, const tptr<T> &rhs)
         const int64_t M = (int64_t)ls[0], K = (int64_t)ls[1], N = (int64_t)rs[1];
         const int64_t lda = ta ? M : K, ldb = tb ? K : N;  // leading dims of the buffers as stored
         auto out = impl::new_out({ls[0], rs[1]}, req);
+        if (const size_t p = detail::PitchRequest::take((size_t)M, (size_t)N)) out->set_device_pitch(p);   // rows on the gather pitch
+        int64_t ldc = N;
+        float *C = out->device_out_pitched(ldc);
         size_t wsb = 0;
         if (!ta && tb) {  // x . W^T: an opt-in request for the batch statistics of the output's columns rides in the epilogue
             if (detail::BnStatsRequest *rq = detail::BnStatsRequest::take((size_t)M, (size_t)N)) {
                 detail::gx(gnnx_gemm_bn_stats_workspace(M, N, K, &wsb), "matmul");
-                detail::gx(gnnx_gemm_bn_stats_f32(M, N, K, A, lda, B, ldb, out->device_out(), N, rq->mean, rq->var,
+                detail::gx(gnnx_gemm_bn_stats_f32(M, N, K, A, lda, B, ldb, C, ldc, rq->mean, rq->var,
                                                   wsb ? detail::workspace(wsb) : nullptr, wsb, st), "matmul");
                 rq->done = true;
                 return out;
             }
         }
         detail::gx(gnnx_gemm_workspace(ta, tb, M, N, K, &wsb), "matmul");
-        detail::gx(gnnx_gemm_f32(ta, tb, M, N, K, 1.0f, A, lda, B, ldb, 0.0f, out->device_out(), N, wsb ? detail::workspace(wsb) : nullptr,
+        detail::gx(gnnx_gemm_f32(ta, tb, M, N, K, 1.0f, A, lda, B, ldb, 0.0f, C, ldc, wsb ? detail::workspace(wsb) : nullptr,
                                  wsb, st), "matmul");
         return out;
     }

@@ -105,6 +105,30 @@ inline uint64_t next_store_id()
     return ++counter;
 }
 
+// The next product with rows x cols outputs is asked to store them on the GATHER row pitch (gnnx_gather_row_stride): GCNConv asks
+// for it around `lin(x)` when its aggregation -- a pitch-aware consumer -- gathers the product's rows.  Same per-thread one-shot
+// pattern as TailReservation.
+struct PitchRequest {
+    size_t rows, cols, ld;
+    static PitchRequest *&pending()
+    {
+        static thread_local PitchRequest *p = nullptr;
+        return p;
+    }
+    PitchRequest(size_t rows_, size_t cols_, size_t ld_) : rows(rows_), cols(cols_), ld(ld_) { pending() = this; }
+    ~PitchRequest()
+    {
+        if (pending() == this) pending() = nullptr;
+    }
+    static size_t take(size_t rows, size_t cols)
+    {
+        PitchRequest *p = pending();
+        if (!p || p->rows != rows || p->cols != cols) return 0;
+        pending() = nullptr;
+        return p->ld;
+    }
+};
+
 template <class T>
 struct Store {
     size_t n = 0;
@@ -120,13 +144,20 @@ struct Store {
     uint64_t id = next_store_id();
     uint64_t version = 0;
 
+    // Device ROW PITCH (elements): 0 = the n elements are contiguous; else the device copy is prow rows of pcol elements, row r at
+    // r * pitch (gnnx_gather_row_stride: a matrix the aggregation gathers rows from).  Only pitch-aware consumers see it
+    // (d_pitched): every generic accessor (d, d_out, h) first makes the storage contiguous again, so code that knows nothing of
+    // pitches stays correct and merely pays one strided copy.
+    size_t pitch = 0, prow = 0, pcol = 0;
+
     explicit Store(size_t n_) : n(n_) {}
     Store(const Store &) = delete;
     Store &operator=(const Store &) = delete;
+    size_t dev_elems() const { return (pitch ? prow * pitch : n) + tail; }
     ~Store()
     {
         delete host;
-        if (dev) dev_free(dev, (n + tail) * sizeof(T));
+        if (dev) dev_free(dev, dev_elems() * sizeof(T));
     }
     void adopt_host(std::valarray<T> *h)
     {
@@ -136,6 +167,39 @@ struct Store {
         dev_ok = false;
         version++;
     }
+    // a fresh (unallocated or dead) device copy gets a row pitch
+    void set_pitch(size_t rows, size_t cols, size_t ld)
+    {
+        if (dev) {
+            dev_free(dev, dev_elems() * sizeof(T));
+            dev = nullptr;
+            dev_ok = false;
+        }
+        if (ld > cols && rows * cols == n) {
+            pitch = ld;
+            prow = rows;
+            pcol = cols;
+        } else {
+            pitch = prow = pcol = 0;
+        }
+    }
+    // back to contiguous rows (contents kept when valid)
+    void make_contiguous()
+    {
+        if (!pitch) return;
+        if constexpr (std::is_same_v<T, bool>) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        void *old = dev;
+        const size_t old_bytes = dev_elems() * sizeof(T), ld = pitch, rows = prow, cols = pcol;
+        pitch = prow = pcol = 0;
+        dev = nullptr;
+        if (old && dev_ok && n) {
+            dev = dev_alloc((n + tail) * sizeof(T));
+            gx(gnnx_memcpy2d_d2d(dev, cols * sizeof(T), old, ld * sizeof(T), cols * sizeof(T), rows, current_stream()), "compact");
+        } else {
+            dev_ok = false;
+        }
+        if (old) dev_free(old, old_bytes);   // (a pooled block: whoever takes it next is ordered behind the copy on this thread's stream)
+    }
     // host view, valid contents
     std::valarray<T> *h()
     {
@@ -143,7 +207,10 @@ struct Store {
         if (!host_ok) {
             if (dev_ok && n) {
                 if constexpr (std::is_same_v<T, bool>) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
-                else gx(gnnx_memcpy_d2h(&(*host)[0], dev, n * sizeof(T), current_stream()), "download");
+                else {
+                    make_contiguous();
+                    gx(gnnx_memcpy_d2h(&(*host)[0], dev, n * sizeof(T), current_stream()), "download");
+                }
             }
             host_ok = true;
         }
@@ -151,12 +218,13 @@ struct Store {
     }
     void ensure_dev_alloc()
     {
-        if (!dev && n + tail) dev = dev_alloc((n + tail) * sizeof(T));   // n == 0 with a reserved tail (a rank without local rows) still allocates
+        if (!dev && dev_elems()) dev = dev_alloc(dev_elems() * sizeof(T));   // n == 0 with a reserved tail (a rank without local rows) still allocates
     }
     // device pointer, valid contents
     T *d()
     {
         if constexpr (std::is_same_v<T, bool>) throw std::runtime_error(ERROR_BACKEND_UNSUPPORTED);
+        make_contiguous();
         ensure_dev_alloc();
         if (!dev_ok) {
             if (host_ok && n) gx(gnnx_memcpy_h2d(dev, &(*host)[0], n * sizeof(T), current_stream()), "upload");
@@ -169,10 +237,31 @@ struct Store {
     // device pointer about to be fully overwritten by a kernel
     T *d_out()
     {
+        if (pitch) set_pitch(0, 0, 0);   // a generic writer knows nothing of pitches
         ensure_dev_alloc();
         dev_ok = true;
         host_ok = false;
         version++;
+        return static_cast<T *>(dev);
+    }
+    // pitch-aware accessors: the device copy as it is laid out; ld = the row pitch in elements (cols when contiguous)
+    T *d_pitched(size_t cols, size_t &ld)
+    {
+        if (!pitch || !dev_ok) {   // contiguous, or not on the device yet: the generic path
+            T *p = d();
+            ld = cols;
+            return p;
+        }
+        ld = pitch;
+        return static_cast<T *>(dev);
+    }
+    T *d_out_pitched(size_t cols, size_t &ld)
+    {
+        ensure_dev_alloc();
+        dev_ok = true;
+        host_ok = false;
+        version++;
+        ld = pitch ? pitch : cols;
         return static_cast<T *>(dev);
     }
     void host_written()
@@ -396,6 +485,26 @@ public:
         return _st->d();
     }
     T *device_out() { return _st->d_out(); }
+    // pitch-aware access to a 2-D tensor's device copy (detail::Store::pitch): ld = row pitch in elements
+    T *device_pitched(int64_t &ld)
+    {
+        materialize();
+        size_t l = 0;
+        T *p = _st->d_pitched(_dims.empty() ? 1 : _dims.back(), l);
+        ld = (int64_t)l;
+        return p;
+    }
+    T *device_out_pitched(int64_t &ld)
+    {
+        size_t l = 0;
+        T *p = _st->d_out_pitched(_dims.empty() ? 1 : _dims.back(), l);
+        ld = (int64_t)l;
+        return p;
+    }
+    void set_device_pitch(size_t ld)
+    {
+        if (_dims.size() == 2 && !_tview) _st->set_pitch(_dims[0], _dims[1], ld);
+    }
     // (id, version) of the device copy's content (detail::Store): call after device_data(), which brings the copy up to date
     uint64_t storage_id() const { return _st ? _st->id : 0; }
     uint64_t storage_version() const { return _st ? _st->version : 0; }

@@ -681,6 +681,70 @@ tptr<float> MessagePassing::propagate(const tensor<int> &edge_index, const tptr<
 }
 
 namespace {
+// pooled device scratch, returned on scope exit (the next kernel that takes the block is ordered behind this thread's stream)
+struct DevScratch {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void alloc(size_t b)
+    {
+        bytes = std::max<size_t>(b, 4);
+        p = cyg::detail::dev_alloc(bytes);
+    }
+    ~DevScratch()
+    {
+        if (p) cyg::detail::dev_free(p, bytes);
+    }
+};
+
+// The row pitch (floats) the aggregation wants the matrix it GATHERS rows from to sit on: padded (gnnx_gather_row_stride) when the
+// rows it gathers most -- the hub rows of the OTHER direction's CSR (`gathered_by`: plan_t for the forward aggregation, plan for
+// the backward one) -- sit on vertex ids with few one-bits (gnnx_spmm_plan_hub_ids_structured); a data set whose ids are already
+// spread keeps its rows on their own width and pays nothing.
+int64_t gather_pitch(int64_t n_rows, int32_t n_feat, const gnnx_spmm_plan *gathered_by)
+{
+    int64_t ld = n_feat;
+    int structured = 0;
+    if (gathered_by) cyg::detail::gx(gnnx_spmm_plan_hub_ids_structured(gathered_by, &structured), "aggregate");
+    if (structured) cyg::detail::gx(gnnx_gather_row_stride(n_rows, n_feat, &ld), "aggregate");
+    return ld;
+}
+
+// The upstream gradient as the backward aggregation gathers it, and the bias gradient.  g is the caller's tensor (rows on their
+// own width): when the gather pitch of its shape is wider, the rows are copied onto it by the pass that sums the columns anyway
+// (gnnx_colsum_copy_f32; a plain strided copy when no bias gradient is wanted) into `pad`; else g is gathered as it lies.
+// Returns the matrix to gather from and its pitch; *dbias (when bias wants a gradient) = column sums of g.
+const float *gathered_gradient(const tptr<float> &g, int64_t n, int32_t f, const gnnx_spmm_plan *gathered_by, bool want_dbias,
+                               const tptr<float> &bias, DevScratch &pad, int64_t &ldg, tptr<float> *dbias)
+{
+    void *st = cyg::detail::current_stream();
+    const int64_t ld = gather_pitch(n, f, gathered_by);
+    if (ld == f) {
+        if (want_dbias) *dbias = cyg::functional::sum(g, 0, bias->rank() == 2);  // dbias = column sums of G, straight from G (no N x F clone)
+        return g->device_pitched(ldg);
+    }
+    int64_t lds = f;
+    const float *gs = g->device_pitched(lds);
+    if (lds != f) {   // already on a pitch (a product's output asked for it)
+        if (want_dbias) *dbias = cyg::functional::sum(g, 0, bias->rank() == 2);
+        ldg = lds;
+        return g->device_pitched(ldg);
+    }
+    pad.alloc(sizeof(float) * (size_t)n * (size_t)ld);
+    if (want_dbias) {
+        *dbias = std::make_shared<tensor<float>>(tensor<float>::device_tag{},
+                                                 bias->rank() == 2 ? std::vector<size_t>{1, (size_t)f} : std::vector<size_t>{(size_t)f}, false);
+        size_t wsb = 0;
+        cyg::detail::gx(gnnx_colsum_workspace(n, f, &wsb), "sum");
+        cyg::detail::gx(gnnx_colsum_copy_f32(gs, f, n, f, 0.0f, (*dbias)->device_out(), (float *)pad.p, ld, cyg::detail::workspace(wsb), wsb, st),
+                        "sum");
+    } else {
+        cyg::detail::gx(gnnx_memcpy2d_d2d(pad.p, sizeof(float) * (size_t)ld, gs, sizeof(float) * (size_t)f, sizeof(float) * (size_t)f, (size_t)n, st),
+                        "aggregate");
+    }
+    ldg = ld;
+    return (const float *)pad.p;
+}
+
 // out = norm (.) (A . x) (+ bias) as ONE SpMM with fused epilogue; backward dX = A^T . (norm (.) G), dbias = colsum(G).
 // Same arithmetic, in the same order, as the MatMul -> Mul -> Add chain it replaces (reference graph.cpp:208-209,188).
 class AggregateOp : public cyg::Operation<tensor<float>> {
@@ -697,8 +761,10 @@ public:
         csr->ensure_plans(f);
         const bool req = x->requires_grad() || (bias && bias->requires_grad());
         auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, req);
+        int64_t ldx = f;
+        const float *xp = x->device_pitched(ldx);   // (the transform's output sits on the gather pitch when GCNConv asked for it)
         cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr, (const int32_t *)csr->colidx, nullptr, nullptr,
-                                          norm->device_data(), bias ? bias->device_data() : nullptr, x->device_data(), f, 0.0f,
+                                          norm->device_data(), bias ? bias->device_data() : nullptr, xp, ldx, 0.0f,
                                           out->device_out(), f, csr->plan, cyg::detail::current_stream()), "aggregate");
         if (req) context->save_for_backward({x, bias ? bias : x});
         has_bias = (bool)bias;
@@ -712,23 +778,27 @@ public:
         const auto shp = x->shape();
         const int32_t f = (int32_t)shp[1];
         void *st = cyg::detail::current_stream();
-        if (has_bias && bias->requires_grad()) {
-            auto db = cyg::functional::sum(g, 0, bias->rank() == 2);  // dbias = column sums of G, straight from G (no N x F clone)
-            bias->backward(db);
+        const bool want_db = has_bias && bias->requires_grad();
+        if (!x->requires_grad()) {
+            if (want_db) bias->backward(cyg::functional::sum(g, 0, bias->rank() == 2));  // dbias = column sums of G, straight from G
+            return;
         }
-        if (x->requires_grad()) {
-            csr->ensure_plans(f);
-            if (!csr->norm_per_nz_t) {  // norm[colidx_t[p]] once per graph
-                cyg::detail::gx(gnnx_malloc(&csr->norm_per_nz_t, sizeof(float) * (size_t)std::max<int64_t>(csr->nnz_t, 1)), "aggregate");
-                cyg::detail::gx(gnnx_gather_rows_f32(norm->device_data(), 1, (const int32_t *)csr->colidx_t, csr->nnz_t, 1,
-                                                     (float *)csr->norm_per_nz_t, 1, st), "aggregate");
-            }
-            auto dx = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
-            cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
-                                              (const float *)csr->norm_per_nz_t, nullptr, nullptr, nullptr, g->device_data(), f, 0.0f,
-                                              dx->device_out(), f, csr->plan_t, st), "aggregate");
-            x->backward(dx);
+        DevScratch gpad;
+        int64_t ldg = f;
+        tptr<float> db;
+        csr->ensure_plans(f);
+        const float *gp = gathered_gradient(g, csr->n, f, csr->plan, want_db, bias, gpad, ldg, &db);   // the backward gathers what A's hub rows read
+        if (want_db) bias->backward(db);
+        if (!csr->norm_per_nz_t) {  // norm[colidx_t[p]] once per graph
+            cyg::detail::gx(gnnx_malloc(&csr->norm_per_nz_t, sizeof(float) * (size_t)std::max<int64_t>(csr->nnz_t, 1)), "aggregate");
+            cyg::detail::gx(gnnx_gather_rows_f32(norm->device_data(), 1, (const int32_t *)csr->colidx_t, csr->nnz_t, 1,
+                                                 (float *)csr->norm_per_nz_t, 1, st), "aggregate");
         }
+        auto dx = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
+        cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
+                                          (const float *)csr->norm_per_nz_t, nullptr, nullptr, nullptr, gp, ldg, 0.0f,
+                                          dx->device_out(), f, csr->plan_t, st), "aggregate");
+        x->backward(dx);
     }
     bool has_bias = false;
 };
@@ -759,9 +829,13 @@ public:
             var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
             size_t wsb = 0;
             cyg::detail::gx(gnnx_bn_workspace(n, f, &wsb), "BatchNorm");
-            cyg::detail::gx(gnnx_bn_stats_f32(h->device_data(), f, n, f, mean->device_out(), var->device_out(), cyg::detail::workspace(wsb),
+            int64_t ldh0 = f;
+            const float *hp0 = h->device_pitched(ldh0);
+            cyg::detail::gx(gnnx_bn_stats_f32(hp0, ldh0, n, f, mean->device_out(), var->device_out(), cyg::detail::workspace(wsb),
                                               wsb, st), "BatchNorm");
         }
+        int64_t ldh = f;
+        const float *hp = h->device_pitched(ldh);   // (on the gather pitch when GCNConv asked the transform for it)
         const bool req = h->requires_grad() || bias->requires_grad() || gamma->requires_grad() || (beta && beta->requires_grad());
         auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, req);
         gnnx_spmm_fusion fu{};
@@ -772,7 +846,7 @@ public:
         fu.bn_eps = eps;
         fu.relu_in = 1;
         cyg::detail::gx(gnnx_spmm_csr_fused_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr, (const int32_t *)csr->colidx, nullptr,
-                                                nullptr, norm->device_data(), bias->device_data(), h->device_data(), f, 0.0f,
+                                                nullptr, norm->device_data(), bias->device_data(), hp, ldh, 0.0f,
                                                 out->device_out(), f, &fu, csr->plan, st), "aggregate");
         has_beta = (bool)beta;
         if (req) context->save_for_backward({h, bias, gamma, beta ? beta : gamma});
@@ -787,12 +861,17 @@ public:
         const int64_t n = (int64_t)shp[0];
         const int32_t f = (int32_t)shp[1];
         void *st = cyg::detail::current_stream();
-        if (bias->requires_grad()) {
-            auto db = cyg::functional::sum(g, 0, bias->rank() == 2);  // dbias = column sums of G, straight from G (no N x F clone)
-            bias->backward(db);
+        if (!(h->requires_grad() || gamma->requires_grad() || (has_beta && beta->requires_grad()))) {
+            if (bias->requires_grad()) bias->backward(cyg::functional::sum(g, 0, bias->rank() == 2));
+            return;
         }
-        if (!(h->requires_grad() || gamma->requires_grad() || (has_beta && beta->requires_grad()))) return;
+        DevScratch gpad;
+        int64_t ldg = f, ldh = f;
+        tptr<float> db;
         csr->ensure_plans(f);
+        const float *gp = gathered_gradient(g, n, f, csr->plan, bias->requires_grad(), bias, gpad, ldg, &db);
+        if (bias->requires_grad()) bias->backward(db);
+        const float *hp = h->device_pitched(ldh);
         if (!csr->norm_per_nz_t) {
             cyg::detail::gx(gnnx_malloc(&csr->norm_per_nz_t, sizeof(float) * (size_t)std::max<int64_t>(csr->nnz_t, 1)), "aggregate");
             cyg::detail::gx(gnnx_gather_rows_f32(norm->device_data(), 1, (const int32_t *)csr->colidx_t, csr->nnz_t, 1,
@@ -813,19 +892,19 @@ public:
                                 gnnx_spmm_csr_bn_sums_workspace(csr->n, f, csr->plan_t, &sums_ws) == GNNX_OK && f % 4 == 0 && f > 64;
         if (fused_sums) {
             cyg::detail::gx(gnnx_spmm_csr_bn_sums_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
-                                                      (const float *)csr->norm_per_nz_t, g->device_data(), f, dy->device_out(), f,
-                                                      h->device_data(), f, mean->device_data(), var->device_data(), eps,
+                                                      (const float *)csr->norm_per_nz_t, gp, ldg, dy->device_out(), f,
+                                                      hp, ldh, mean->device_data(), var->device_data(), eps,
                                                       gamma->device_data(), beta_d, 1, dgamma->device_out(), dbeta->device_out(),
                                                       cyg::detail::workspace(sums_ws), sums_ws, csr->plan_t, st), "aggregate");
-            cyg::detail::gx(gnnx_bn_relu_bwd_apply_f32(h->device_data(), f, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
+            cyg::detail::gx(gnnx_bn_relu_bwd_apply_f32(hp, ldh, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
                                                        var->device_data(), eps, gamma->device_data(), beta_d, 1, dgamma->device_data(),
                                                        dbeta->device_data(), n, dh->device_out(), f, cyg::detail::workspace(wsb), wsb, st),
                             "BatchNorm");
         } else {
             cyg::detail::gx(gnnx_spmm_csr_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr_t, (const int32_t *)csr->colidx_t,
-                                              (const float *)csr->norm_per_nz_t, nullptr, nullptr, nullptr, g->device_data(), f, 0.0f,
+                                              (const float *)csr->norm_per_nz_t, nullptr, nullptr, nullptr, gp, ldg, 0.0f,
                                               dy->device_out(), f, csr->plan_t, st), "aggregate");
-            cyg::detail::gx(nn::bn_backward_fn()(h->device_data(), f, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
+            cyg::detail::gx(nn::bn_backward_fn()(hp, ldh, nullptr, 0, dy->device_data(), f, n, f, mean->device_data(),
                                                  var->device_data(), eps, gamma->device_data(), beta_d, 1, dh->device_out(), f,
                                                  dgamma->device_out(), dbeta->device_out(), cyg::detail::workspace(wsb), wsb, st),
                             "BatchNorm");
@@ -883,6 +962,12 @@ tptr<float> GCNConv::forward(Data &&input)
         }
         tptr<float> out, st_mean, st_var;
         bool have_stats = false;
+        // the transform's output is gathered row by row by the aggregation below: it is asked to write its rows on the gather pitch
+        // (a power-of-two pitch piles the hub rows of a power-law graph onto a few memory channels: gnnx_gather_row_stride)
+        const size_t n_rows = input.x()->shape()[0];
+        _cache_adj->csr()->ensure_plans((int32_t)_out_channels);
+        cyg::detail::PitchRequest on_pitch(n_rows, _out_channels,
+                                           (size_t)gather_pitch((int64_t)n_rows, (int32_t)_out_channels, _cache_adj->csr()->plan_t));
         if (fuse_bn_stats && !hot_path_only) {   // opt-in: the statistics ride in the transform's epilogue
             st_mean = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, _out_channels}, false);
             st_var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, _out_channels}, false);

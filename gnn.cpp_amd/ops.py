@@ -65,6 +65,12 @@ class SpmmPlan:
         capi.call("gnnx_spmm_plan_info", self.h, C.byref(a), C.byref(b))
         self.n_split_rows, self.n_hub_nnz = a.value, b.value   # hub rows (degree > chunk) and their non-zeros
 
+    def hub_ids_structured(self):
+        """gnnx_spmm_plan_hub_ids_structured: the hub rows sit on ids with few one-bits (a synthetic power-law graph as generated)."""
+        v = C.c_int(0)
+        capi.call("gnnx_spmm_plan_hub_ids_structured", self.h, C.byref(v))
+        return bool(v.value)
+
     def set_big_row_threshold(self, threshold):
         """Hub rows longer than `threshold` take the producer / consumer hub kernel (< 0: the library picks them per call, the
         default; same bits for every value)."""
@@ -337,6 +343,32 @@ def colsum(G, out=None, beta=0.0):
     wsb = capi.colsum_workspace(N, F)
     ws = _workspace(wsb, G.device, "colsum")
     capi.call("gnnx_colsum_f32", _ptr(G), _ld(G), N, F, float(beta), _ptr(out), _ptr(ws), wsb, _stream())
+    return out
+
+
+def gather_row_stride(n_rows, n_feat):
+    """gnnx_gather_row_stride: the row pitch (floats) for a matrix whose rows the aggregation gathers (n_feat, or n_feat + 64 for large
+    matrices of 512-byte-multiple rows: spreads the hub rows of a synthetic power-law graph over the memory channels)."""
+    ld = C.c_int64(0)
+    capi.call("gnnx_gather_row_stride", int(n_rows), int(n_feat), C.byref(ld))
+    return ld.value
+
+
+def empty_gathered(n_rows, n_feat, device="cuda"):
+    """An uninitialised [n_rows, n_feat] view of a buffer on the gather pitch (gather_row_stride)."""
+    ld = gather_row_stride(n_rows, n_feat)
+    return torch.empty((n_rows, ld), dtype=torch.float32, device=device)[:, :n_feat]
+
+
+def colsum_copy(G, copy, out=None, beta=0.0):
+    """gnnx_colsum_copy_f32: column sums of G (as colsum, same bits) and, from the same pass, G's rows copied into `copy` (a view on
+    another row stride: empty_gathered)."""
+    N, F = G.shape
+    if out is None:
+        out = torch.empty(F, dtype=torch.float32, device=G.device)
+    wsb = capi.colsum_workspace(N, F)
+    ws = _workspace(wsb, G.device, "colsum")
+    capi.call("gnnx_colsum_copy_f32", _ptr(G), _ld(G), N, F, float(beta), _ptr(out), _ptr(copy), _ld(copy), _ptr(ws), wsb, _stream())
     return out
 
 

@@ -60,6 +60,9 @@ int gnnx_memset(void *d_ptr, int value, size_t bytes, void *stream);
 int gnnx_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int gnnx_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream); /* synchronises `stream` */
 int gnnx_memcpy_d2d(void *d_dst, const void *d_src, size_t bytes, void *stream);
+/* rows x width_bytes between two pitched device buffers (stream-ordered) */
+int gnnx_memcpy2d_d2d(void *d_dst, size_t dst_pitch_bytes, const void *d_src, size_t src_pitch_bytes, size_t width_bytes, size_t rows,
+                      void *stream);
 int gnnx_stream_create(void **stream);
 int gnnx_stream_destroy(void *stream);
 int gnnx_stream_sync(void *stream);
@@ -175,6 +178,10 @@ int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_hub_rows, int64_t
  * eighth of it).  threshold >= 0 fixes the cut (rows longer than it; tests pass 0: every hub row), < 0 restores the default.  Same
  * bits for every choice. */
 int gnnx_spmm_plan_set_big_row_threshold(gnnx_spmm_plan *plan, int32_t threshold);
+/* *structured = 1 when the plan's hub rows sit on vertex ids with few one-bits (non-zero-weighted mean popcount well below half the id
+ * width: what R-MAT and most synthetic power-law generators produce).  The hub rows of CSR(A) are the rows the aggregation over
+ * CSR(A^T) gathers most, and vice versa: with such ids the gathered matrix wants the padded row pitch of gnnx_gather_row_stride. */
+int gnnx_spmm_plan_hub_ids_structured(const gnnx_spmm_plan *plan, int *structured);
 
 int gnnx_spmm_csr_f32(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_rowptr,
                       const int32_t *d_colidx, const float *d_vals, const float *d_colscale,
@@ -296,6 +303,15 @@ int gnnx_gemm_split_bf16_f32(int transB, int64_t M, int64_t N, int64_t K, const 
 /* dbias: out[f] = beta*out[f] + sum_i G[i,f]  (Add::_backward -> sum_to_size, reference operation.h:114-128,
  * tensor.h:618-638).  Two-stage deterministic tree (fixed grid); workspace gnnx_colsum_workspace() bytes. */
 int gnnx_colsum_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes);
+/* gnnx_colsum_copy_f32: the same sums (same bits) and, from the same pass, a copy of G's rows on another row stride: d_copy[i * ldc + f]
+ * = G[i * ldg + f] -- the upstream gradient laid out for the backward aggregation's gather (gnnx_gather_row_stride).
+ * gnnx_gather_row_stride: the row pitch (in floats) a matrix whose rows are GATHERED by the aggregation should be stored on:
+ * n_feat, or n_feat + 64 when a row is a multiple of 512 bytes and the matrix is large -- with a power-of-two pitch the hub rows of
+ * a synthetic power-law graph (vertex ids with few one-bits) pile onto a few memory channels (forward aggregation of RMAT 10 M /
+ * 100 M, F = 256, vertices as generated: 17.8 ms on pitch 256, 13.9 ms on pitch 320; 13.8 ms after relabelling the vertices). */
+int gnnx_gather_row_stride(int64_t n_rows, int32_t n_feat, int64_t *ld_out);
+int gnnx_colsum_copy_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out, float *d_copy,
+                         int64_t ldc, void *d_workspace, size_t workspace_bytes, void *stream);
 int gnnx_colsum_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out,
                     void *d_workspace, size_t workspace_bytes, void *stream);
 

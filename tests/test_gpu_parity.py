@@ -261,6 +261,25 @@ def test_plan_hub_rows_keep_the_reference_order(env, n, e, F, chunk):
     assert torch.equal(ops.aggregate_fwd(g, dev(env, H), dev(env, bias)), out)
 
 
+@pytest.mark.parametrize("n,F", [(70001, 256), (5000, 128), (3001, 100), (2000, 33), (4096, 1024)])
+def test_colsum_copy_and_gather_pitch(env, n, F):
+    """gnnx_colsum_copy_f32: the column sums are gnnx_colsum_f32's bits, the copy holds G's rows on the other pitch (pad columns
+    untouched); gnnx_gather_row_stride pads only large matrices of 512-byte-multiple rows; an aggregation gathering from the
+    padded copy gives the bits of the one gathering from G."""
+    ops, torch = env["ops"], env["torch"]
+    G = ops.uniform_pm1(77, (n, F), device=env["dev"])
+    ld = F + 64
+    buf = torch.full((n, ld), -7.0, dtype=torch.float32, device=env["dev"])
+    s1 = ops.colsum_copy(G, buf[:, :F])
+    assert torch.equal(s1, ops.colsum(G)) and torch.equal(buf[:, :F], G) and bool((buf[:, F:] == -7.0).all())
+    assert ops.gather_row_stride(10_000_000, 256) == 320 and ops.gather_row_stride(10_000_000, 128) == 192
+    assert ops.gather_row_stride(10_000_000, 100) == 100 and ops.gather_row_stride(1000, 256) == 256
+    src, dst = synth.rmat_edges(5, n, 8 * n)
+    g = ops.CsrGraph.from_coo(dev(env, src), dev(env, dst), n)
+    assert torch.equal(ops.aggregate_bwd(g, buf[:, :F]), ops.aggregate_bwd(g, G))
+    assert torch.equal(ops.aggregate_fwd(g, buf[:, :F]), ops.aggregate_fwd(g, G))
+
+
 @pytest.mark.parametrize("n,e,F,chunk,big", [(30000, 600000, 256, 256, 0), (30000, 600000, 256, 64, 700), (30000, 600000, 128, 64, 0),
                                              (20000, 400000, 100, 64, 0), (20000, 400000, 36, 64, 0), (8000, 200000, 320, 128, 300),
                                              (8000, 200000, 64, 16, 0), (3000, 200000, 256, 16, 0)])
