@@ -5,7 +5,7 @@
 # combined with a trace domain) of the SAME bench command; for the GEMMs one SQ-counter pass of scripts/exp_gemm.py.  Raw output
 # lands under gpurun_out/prof_<tag>_*; scripts/summarize_profile.py turns it into the small files committed under profiles/.
 set -euo pipefail
-TAG=${1:-r02}
+TAG=${1:-r04}
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
