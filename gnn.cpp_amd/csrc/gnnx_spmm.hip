@@ -1148,8 +1148,18 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         else                                                                                                                           \
             asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"((s).d[i]) : "v"(ad), "i"(32 * (i)), "i"(32 * (i) + 16) : "memory"); \
     } while (0)
-    auto issue_reads = [&](Set &s, uint32_t ad) {   // one ring slot -> 16 registers
-        GNNX_PC_R2(s, ad, 0); GNNX_PC_R2(s, ad, 1); GNNX_PC_R2(s, ad, 2); GNNX_PC_R2(s, ad, 3);
+    float acc = 0.f;
+    // one ring slot -> 16 registers.  The accumulator is an in-out operand of the block's first read -- nothing is done to it: it
+    // only keeps the adds of the sub-chunk in front of this block IN FRONT of it.  Left to itself the compiler issues a chunk's four
+    // blocks of reads first and its 64 adds last, and three of the four waits then stall for most of an LDS round trip (4.8 ns per
+    // neighbour for the consumer alone); with 16 adds between the blocks the round trips are covered.  (Pinning the adds
+    // themselves with volatile asm cost a register copy per add -- a half of a 64-bit asm operand -- and was slower: 6.1 ns.)
+    auto issue_reads = [&](Set &s, uint32_t ad) {
+        if constexpr (SLAB == 64)
+            asm volatile("ds_read2st64_b32 %0, %2 offset0:0 offset1:1" : "=v"(s.d[0]), "+v"(acc) : "v"(ad) : "memory");
+        else
+            asm volatile("ds_read2_b32 %0, %2 offset0:0 offset1:16" : "=v"(s.d[0]), "+v"(acc) : "v"(ad) : "memory");
+        GNNX_PC_R2(s, ad, 1); GNNX_PC_R2(s, ad, 2); GNNX_PC_R2(s, ad, 3);
         GNNX_PC_R2(s, ad, 4); GNNX_PC_R2(s, ad, 5); GNNX_PC_R2(s, ad, 6); GNNX_PC_R2(s, ad, 7);
     };
 #undef GNNX_PC_R2
@@ -1164,10 +1174,7 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
     };
     using Keep8 = std::integral_constant<int, 8>;
     using None = std::integral_constant<int, 0>;
-    float acc = 0.f;
-    // acc = RN(acc + x), sixteen times.  (Plain adds: the compiler issues a chunk's four blocks of reads first and its 64 adds last.
-    // Pinning the adds between the read blocks with volatile asm -- which covers the reads' latency on paper -- measured SLOWER,
-    // 6.1 vs 4.8 ns per neighbour for the consumer alone, as did one read after every add: 10.6.)
+    // acc = RN(acc + x), sixteen times
     auto adds = [&](const Set &s) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {

@@ -941,7 +941,7 @@ tptr<float> GCNConv::forward(Data &&input)
         // identity of the edge_index tensor's device copy -- (storage id, content version), tensor.h detail::Store: the version moves
         // when the list is uploaded again after the host side was handed out for writing (data()) or set_data() / a kernel rewrote
         // it, the id is unique per storage (a new tensor at a freed one's address is another id) -- so a forward costs two integer
-        // compares: no pass over the list, no host synchronisation, capturable in a hipGraph.  (The reference rebuilds on every
+        // compares: no pass over the list, no host synchronisation.  (The reference rebuilds on every
         // forward, graph.cpp:172-185.)
         tensor<int> *ei = input.edge_index();
         (void)ei->device_data();   // brings the device copy up to date (uploads, and bumps the version, if the host side was written)

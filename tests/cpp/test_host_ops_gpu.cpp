@@ -155,6 +155,60 @@ int main()
         }
         CHECK(all_zero(*s->data() - e));
     });
+    section("row pitch", [] {  // ---- a product asked onto a row pitch (detail::PitchRequest): pitch-aware consumers see the pitch,
+                               // everything else sees the same values on contiguous rows (tensor.h, detail::Store)
+        const size_t N = 300, K = 64, F = 32, LD = 48;
+        auto X = randn(vector<size_t>{N, K}, -1, 1, true), W = randn(vector<size_t>{F, K}, -1, 1, true);
+        auto plain = X->mm(W->t());
+        const valarray<float> want = *plain->data();
+        tptr<float> h;
+        {
+            detail::PitchRequest on_pitch(N, F, LD);
+            h = X->mm(W->t());
+        }
+        int64_t ld = 0;
+        const float *hp = h->device_pitched(ld);
+        CHECK(ld == (int64_t)LD && hp != nullptr);
+        {   // a request that does not match the product's shape is left alone
+            detail::PitchRequest other(N + 1, F, LD);
+            auto h2 = X->mm(W->t());
+            int64_t ld2 = 0;
+            h2->device_pitched(ld2);
+            CHECK(ld2 == (int64_t)F);
+        }
+        // a pitch-aware consumer: the aggregation gathers the pitched rows; same bits as from contiguous rows
+        vector<int> src, dst;
+        for (int i = 0; i < (int)N; i++)
+            for (int d = 1; d <= 3; d++) {
+                src.push_back(i);
+                dst.push_back((i * 7 + d * 13) % (int)N);
+            }
+        auto ei = graph::vec_to_edge_list(src, dst);
+        auto adj = graph::edge_to_adj_mat(*ei, nullptr, N);
+        adj->fill_diagonal_(0);
+        auto deg = adj->sum(-1, true) + 1;
+        deg = deg->pow(-0.5);
+        auto norm = adj->mm(deg);
+        norm *= deg;
+        graph::GCNConv layer(K, F);
+        auto a_pitched = layer.aggregate_and_update(h, *ei, &norm), a_plain = layer.aggregate_and_update(plain, *ei, &norm);
+        CHECK(all_zero(*a_pitched->data() - *a_plain->data()));
+        // ... and its backward reaches X through the product whose output was pitched
+        auto g = randn(vector<size_t>{N, F});
+        a_pitched->backward(g);
+        const valarray<float> dx1 = *X->grad();
+        X->zero_grad();
+        W->zero_grad();
+        a_plain->backward(g);
+        CHECK(all_zero(dx1 - *X->grad()));
+        // generic code (data(), elementwise operators) sees contiguous rows with the same values
+        auto twice = h + h;
+        CHECK(all_zero(*twice->data() - (want + want)));
+        CHECK(all_zero(*h->data() - want));
+        int64_t ld3 = 0;
+        h->device_pitched(ld3);
+        CHECK(ld3 == (int64_t)F);   // the generic accessors made the storage contiguous
+    });
     if (failures == 0) printf("OK\n");
     return failures ? 1 : 0;
 }
