@@ -1734,20 +1734,28 @@ GNNX_API int gnnx_spmm_plan_hub_ids_structured(const gnnx_spmm_plan *plan, int *
 {
     GNNX_REQUIRE(plan && structured, GNNX_ERR_INVALID_ARG, "null pointer");
     // The hub rows of this CSR are the rows the TRANSPOSED aggregation gathers most (a vertex with many out-edges is read by many
-    // rows of A^T).  Synthetic power-law generators (R-MAT) put them on the ids with few one-bits: then a power-of-two row pitch of
-    // the gathered matrix piles them onto a few memory channels and the caller should use gnnx_gather_row_stride.  Measured here as
-    // the non-zero-weighted mean popcount of the hub ids against half the id width (what ids spread at random would show).
+    // rows of A^T).  Synthetic power-law generators (R-MAT) draw the bits of an id independently, so the hubs are the ids with few
+    // one-bits: with a power-of-two row pitch of the gathered matrix the address bits that pick the memory channel / cache slice are
+    // mostly zero for the hottest rows and the caller should use gnnx_gather_row_stride.  Measured here as the non-zero-weighted mean
+    // popcount of the hub ids against half the id width (what ids spread at random show).  Hubs sorted to the front as one dense
+    // block of consecutive ids have few one-bits too but consecutive addresses, which spread by themselves: not flagged.
+    // (The residues of the ids modulo 128 do NOT tell: the multiplicative relabelling keeps them -- 128 divides 10^7 -- and cures the
+    // pile-up all the same; the bits that matter sit higher.)
     *structured = 0;
-    if (plan->h_hub_rows.empty() || plan->n_rows < 2) return GNNX_OK;
+    if (plan->h_hub_rows.size() < 64 || plan->n_rows < 1024) return GNNX_OK;
     double bits = 0.0, weight = 0.0;
+    int32_t lo = plan->h_hub_rows[0], hi = plan->h_hub_rows[0];
     for (size_t i = 0; i < plan->h_hub_rows.size(); i++) {
         const double w = (double)plan->h_hub_degrees[i];
         bits += w * (double)__builtin_popcount((uint32_t)plan->h_hub_rows[i]);
         weight += w;
+        lo = plan->h_hub_rows[i] < lo ? plan->h_hub_rows[i] : lo;
+        hi = plan->h_hub_rows[i] > hi ? plan->h_hub_rows[i] : hi;
     }
     int width = 0;
     while ((1ll << width) < (long long)plan->n_rows) width++;
-    *structured = bits / weight < 0.7 * 0.5 * (double)width;
+    const bool dense_block = (int64_t)hi - (int64_t)lo < 4 * (int64_t)plan->h_hub_rows.size();
+    *structured = !dense_block && bits / weight < 0.7 * 0.5 * (double)width;
     return GNNX_OK;
 }
 

@@ -179,7 +179,8 @@ int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_hub_rows, int64_t
  * bits for every choice. */
 int gnnx_spmm_plan_set_big_row_threshold(gnnx_spmm_plan *plan, int32_t threshold);
 /* *structured = 1 when the plan's hub rows sit on vertex ids with few one-bits (non-zero-weighted mean popcount well below half the id
- * width: what R-MAT and most synthetic power-law generators produce).  The hub rows of CSR(A) are the rows the aggregation over
+ * width) and are not one dense block of consecutive ids -- what R-MAT and other generators that draw the bits of an id independently
+ * produce; ids spread at random, or hubs sorted to the front, do not.  The hub rows of CSR(A) are the rows the aggregation over
  * CSR(A^T) gathers most, and vice versa: with such ids the gathered matrix wants the padded row pitch of gnnx_gather_row_stride. */
 int gnnx_spmm_plan_hub_ids_structured(const gnnx_spmm_plan *plan, int *structured);
 

@@ -280,6 +280,27 @@ def test_colsum_copy_and_gather_pitch(env, n, F):
     assert torch.equal(ops.aggregate_fwd(g, buf[:, :F]), ops.aggregate_fwd(g, G))
 
 
+def test_hub_id_structure_detector(env):
+    """gnnx_spmm_plan_hub_ids_structured: an R-MAT graph as generated (hubs on the ids with few one-bits) is flagged, the same graph
+    with its labels spread by the multiplicative hash or with its hubs sorted to the front as one dense block is not."""
+    ops, torch = env["ops"], env["torch"]
+    n, e = 400_000, 6_000_000
+    src, dst = ops.rmat_edges(9, n, e, device=env["dev"])
+    g = ops.CsrGraph.from_coo(src, dst, n, norm=False)
+    g.make_plans(64, 256)
+    assert g.plan.n_split_rows >= 512 and g.plan.hub_ids_structured() and g.plan_t.hub_ids_structured()
+    gs = ops.CsrGraph.from_coo(src, dst, n, norm=False, relabel="scramble")
+    gs.make_plans(64, 256)
+    assert not gs.plan.hub_ids_structured() and not gs.plan_t.hub_ids_structured()
+    deg = (g.rowptr[1:] - g.rowptr[:-1]) + (g.rowptr_t[1:] - g.rowptr_t[:-1])
+    order = torch.sort(deg, descending=True, stable=True).indices          # vertex of rank k
+    nid = torch.empty(n, dtype=torch.int32, device=env["dev"])
+    nid[order] = torch.arange(n, dtype=torch.int32, device=env["dev"])
+    gd = ops.CsrGraph.from_coo(src, dst, n, norm=False, relabel=nid)
+    gd.make_plans(64, 256)
+    assert not gd.plan.hub_ids_structured() and not gd.plan_t.hub_ids_structured()
+
+
 @pytest.mark.parametrize("n,e,F,chunk,big", [(30000, 600000, 256, 256, 0), (30000, 600000, 256, 64, 700), (30000, 600000, 128, 64, 0),
                                              (20000, 400000, 100, 64, 0), (20000, 400000, 36, 64, 0), (8000, 200000, 320, 128, 300),
                                              (8000, 200000, 64, 16, 0), (3000, 200000, 256, 16, 0)])
