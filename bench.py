@@ -694,7 +694,7 @@ class TrainStep(SingleGpu):
             a, b = self.capi.Event(), self.capi.Event()
             a.record(stream)
         logits = self.net.forward(self.X)
-        _, dlog = ops.softmax_ce(logits, self.target, colsum_out=self.net.db[-1])   # last layer's bias gradient from the loss kernel
+        _, dlog = ops.softmax_ce(logits, self.target, colsum_out=self.net.db[-1], grad_out=self.net.grad_buffer())   # last layer's bias gradient from the loss kernel
         self.net.backward(dlog, input_grad=False, have_last_bias_grad=True)           # the features are data: no dX of layer 1
         self.net.step(lr=1e-3)
         if timed:

@@ -630,6 +630,23 @@ class GcnStack:
         self.db = [torch.zeros_like(b) for b in self.b]
         self._saved = None
         self._buf = {}
+        # The matrices the aggregations GATHER rows from -- H_l = h_l W_l^T forward, the gradients G_l backward -- sit on the padded
+        # row pitch (gnnx_gather_row_stride) when the graph's hub ids call for it (a synthetic power-law graph in its as-generated
+        # vertex order: gnnx_spmm_plan_hub_ids_structured).  Every one of them is written by a kernel of this stack (the products,
+        # the loss: softmax_ce(grad_out=net.grad_buffer())), so the pitch costs nothing per step; same bits.
+        self.gather_pitch = bool(g.plan is not None and g.plan_t is not None and (g.plan.hub_ids_structured() or g.plan_t.hub_ids_structured()))
+
+    def _gathered(self, key, n, F, device):
+        """persistent [n, F] buffer for a gathered matrix: on the gather pitch when the graph wants it"""
+        t = self._buf.get(key)
+        if t is None or tuple(t.shape) != (n, F):
+            t = self._buf[key] = empty_gathered(n, F, device=device) if self.gather_pitch else torch.empty((n, F), dtype=torch.float32, device=device)
+        return t
+
+    def grad_buffer(self, n=None):
+        """Where the loss should write dlogits (softmax_ce(..., grad_out=net.grad_buffer())): the top gradient is gathered by the last
+        layer's backward aggregation."""
+        return self._gathered(("G", len(self.W)), self.g.n if n is None else n, self.dims[-1], self.Wp[0].device)
 
     def _zeros(self, key, shape, device):
         """persistent zero-initialised buffer (padded layout: pad columns are written once, here)"""
@@ -651,7 +668,7 @@ class GcnStack:
         if not self.padded:
             saved, h = [], X
             for l in range(L):
-                H = linear_fwd(h, self.W[l])
+                H = linear_fwd(h, self.W[l], out=self._gathered(("H", l), X.shape[0], self.dims[l + 1], X.device))
                 # the ReLU between layers rides in the aggregation's epilogue: only relu(Z) is stored (its sign is the mask)
                 Y = aggregate_fwd(self.g, H, self.b[l], relu_out=l + 1 < L)
                 saved.append((h, Y))
@@ -707,7 +724,8 @@ class GcnStack:
             if l == 0:
                 G = gemm(dH, Wl) if input_grad else None             # dX of the first layer: no ReLU below it
             elif fused:
-                G, _ = gemm_relu_colsum(dH, Wl, hl, colsum_out=self.db[l - 1])   # h = Y_{l-1} = relu output of the layer below
+                # h = Y_{l-1} = relu output of the layer below; G_{l-1} is gathered by that layer's backward aggregation
+                G, _ = gemm_relu_colsum(dH, Wl, hl, out=self._gathered(("G", l), dH.shape[0], Wl.shape[1], dH.device), colsum_out=self.db[l - 1])
             else:
                 G = gemm(dH, Wl)
                 G, _, _ = bn_relu_bwd(hl, hl, G, relu=True)

@@ -280,6 +280,35 @@ def test_colsum_copy_and_gather_pitch(env, n, F):
     assert torch.equal(ops.aggregate_fwd(g, buf[:, :F]), ops.aggregate_fwd(g, G))
 
 
+def test_gcn_stack_on_the_gather_pitch(env):
+    """ops.GcnStack on an as-generated R-MAT graph large enough for the padded gather pitch: the stack notices the hub ids
+    (gnnx_spmm_plan_hub_ids_structured) and keeps H_l and the gradients G_l -- all written by its own kernels -- on the pitch; one
+    training step (forward, softmax-CE into net.grad_buffer(), backward) gives the bits of the same stack on contiguous rows."""
+    ops, torch = env["ops"], env["torch"]
+    n, e, dims = 70_000, 1_400_000, [256, 256, 128]
+    src, dst = ops.rmat_edges(31, n, e, device=env["dev"])
+    g = ops.CsrGraph.from_coo(src, dst, n)
+    g.make_plans(64, 256)
+    X = ops.uniform_pm1(32, (n, dims[0]), device=env["dev"]) * 1e-4   # (hub rows sum thousands of terms: keep the max-free softmax finite)
+    t = ((7 * torch.arange(n, device=env["dev"]) + 3) % dims[-1]).to(torch.int32)
+    nets = [ops.GcnStack(g, dims, seed=40), ops.GcnStack(g, dims, seed=40)]
+    assert nets[0].gather_pitch and ops.gather_row_stride(n, 256) == 320
+    nets[1].gather_pitch = False
+    res = []
+    for net in nets:
+        logits = net.forward(X)
+        loss, dlog = ops.softmax_ce(logits, t, colsum_out=net.db[-1], grad_out=net.grad_buffer())
+        dX = net.backward(dlog, have_last_bias_grad=True)
+        res.append((logits.clone(), loss.clone(), dX.clone(), [w.clone() for w in net.dW], [b.clone() for b in net.db]))
+    assert nets[0]._buf[("H", 0)].stride(0) == 320 and nets[1]._buf[("H", 0)].stride(0) == 256
+    assert nets[0].grad_buffer().stride(0) == dims[-1]          # 128 floats = 512-byte rows, but 70 000 x 128 is below the size that pads
+    a, b = res
+    assert bool(torch.isfinite(a[1]).all()) and float(a[2].abs().max()) > 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for x, y in zip(a[3] + a[4], b[3] + b[4]):
+        assert torch.equal(x, y)
+
+
 def test_hub_id_structure_detector(env):
     """gnnx_spmm_plan_hub_ids_structured: an R-MAT graph as generated (hubs on the ids with few one-bits) is flagged, the same graph
     with its labels spread by the multiplicative hash or with its hubs sorted to the front as one dense block is not."""
