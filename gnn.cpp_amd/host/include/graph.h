@@ -108,6 +108,9 @@ public:
     // them) -- a single-pass variance finished in double, within rounding of the two-pass one but not bit-equal to it, so the
     // layer output moves at the 1e-6 level.  Shapes the fused kernel does not cover fall back to the exact pair of calls.
     bool fuse_bn_stats = false;
+    // the row pitch (floats) the last forward asked the transform's output onto: out_channels, or out_channels + 64 when the graph's hub
+    // ids call for the padded gather pitch (gnnx_gather_row_stride; INTEGRATION.md "Vertex order of synthetic graphs")
+    size_t gathered_row_pitch = 0;
     size_t _in_channels, _out_channels;
     float _dropout;
 

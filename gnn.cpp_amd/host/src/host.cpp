@@ -704,6 +704,8 @@ int64_t gather_pitch(int64_t n_rows, int32_t n_feat, const gnnx_spmm_plan *gathe
 {
     int64_t ld = n_feat;
     int structured = 0;
+    static const bool off = std::getenv("GNNCPP_NO_GATHER_PITCH") != nullptr;   // A/B switch of the tests (same bits either way), read once
+    if (off) return ld;
     if (gathered_by) cyg::detail::gx(gnnx_spmm_plan_hub_ids_structured(gathered_by, &structured), "aggregate");
     if (structured) cyg::detail::gx(gnnx_gather_row_stride(n_rows, n_feat, &ld), "aggregate");
     return ld;
@@ -966,8 +968,8 @@ tptr<float> GCNConv::forward(Data &&input)
         // (a power-of-two pitch piles the hub rows of a power-law graph onto a few memory channels: gnnx_gather_row_stride)
         const size_t n_rows = input.x()->shape()[0];
         _cache_adj->csr()->ensure_plans((int32_t)_out_channels);
-        cyg::detail::PitchRequest on_pitch(n_rows, _out_channels,
-                                           (size_t)gather_pitch((int64_t)n_rows, (int32_t)_out_channels, _cache_adj->csr()->plan_t));
+        gathered_row_pitch = (size_t)gather_pitch((int64_t)n_rows, (int32_t)_out_channels, _cache_adj->csr()->plan_t);
+        cyg::detail::PitchRequest on_pitch(n_rows, _out_channels, gathered_row_pitch);
         if (fuse_bn_stats && !hot_path_only) {   // opt-in: the statistics ride in the transform's epilogue
             st_mean = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, _out_channels}, false);
             st_var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, _out_channels}, false);

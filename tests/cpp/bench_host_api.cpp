@@ -8,6 +8,7 @@
 // Edges: R-MAT from the same SplitMix64 stream as gnn.cpp_amd/synth.py (seed 1, a,b,c = 0.57,0.19,0.19).
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <valarray>
 #include <vector>
@@ -87,10 +88,21 @@ static void run_config(long n, long e, size_t F, int steps, bool hot, bool scram
     }
     gnnx_device_sync();
     double ms = (now_s() - t0) / steps * 1e3;
+    // probes of the results (every 997th element, summed in double, as hex so that two runs can be compared bit for bit): the first
+    // call's output, and the input / weight gradients the last step left
+    auto probe = [](const std::valarray<float> &v) {
+        double acc = 0.0;
+        for (size_t i = 0; i < v.size(); i += 997) acc += (double)v[i];
+        uint64_t bits;
+        memcpy(&bits, &acc, sizeof(bits));
+        return bits;
+    };
+    const uint64_t p_out = probe(*out->data()), p_dx = probe(*x->grad()), p_dw = probe(*layer.get_parameter("weight")->grad());
     printf("{\"bench\": \"host_api GCNConv fwd+bwd\", \"n_nodes\": %ld, \"n_edges\": %ld, \"features\": %zu, \"hot_path_only\": %d, "
            "\"scrambled_labels\": %d, \"fuse_bn_stats\": %d, \"rmat_seed\": %llu, \"ms_per_step\": %.3f, \"first_call_s\": %.3f, \"edge_gen_s\": %.3f, "
-           "\"out_checksum\": %.6e}\n",
-           n, e, F, (int)hot, (int)scramble, (int)fuse_bn_stats, (unsigned long long)seed, ms, t_first, t_gen, (double)(*out->data())[12345 % (n * F)]);
+           "\"out_checksum\": %.6e, \"gathered_row_pitch\": %zu, \"probe_out\": \"%016llx\", \"probe_dx\": \"%016llx\", \"probe_dw\": \"%016llx\"}\n",
+           n, e, F, (int)hot, (int)scramble, (int)fuse_bn_stats, (unsigned long long)seed, ms, t_first, t_gen, (double)(*out->data())[12345 % (n * F)],
+           layer.gathered_row_pitch, (unsigned long long)p_out, (unsigned long long)p_dx, (unsigned long long)p_dw);
     fflush(stdout);
 }
 

@@ -131,6 +131,31 @@ def test_edge_attr_forms_of_the_graph_functions(name):
         assert same(got[key + "_ea"], d["ref_" + key + "_ea"]), key
 
 
+def test_gather_pitch_through_the_cpp_call_sites_same_bits():
+    """graph::GCNConv on an R-MAT graph in its as-generated vertex order, large enough for the padded gather pitch (70 000 x 256): the
+    layer notices the hub ids and keeps the transform's output and the copy of the upstream gradient on the pitch -- hot path and the
+    full BatchNorm + ReLU layer give the same output, input gradient and weight gradient, bit for bit, as with the pitch switched
+    off (GNNCPP_NO_GATHER_PITCH=1)."""
+    import json
+    exe = os.path.join(ROOT, "tests", "cpp", "bench_host_api")
+    assert os.path.exists(exe), "build it with __graft_entry__.build()"
+
+    def run(env_extra):
+        env = dict(os.environ)
+        env.update(env_extra)
+        r = subprocess.run([exe, "70000", "1400000", "256", "1", "2", "0", "5"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+        rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(rows) == 2
+        return ({row["hot_path_only"]: (row["probe_out"], row["probe_dx"], row["probe_dw"]) for row in rows},
+                {row["gathered_row_pitch"] for row in rows})
+
+    (on, pitch_on), (off, pitch_off) = run({}), run({"GNNCPP_NO_GATHER_PITCH": "1"})
+    assert pitch_on == {320} and pitch_off == {256}, (pitch_on, pitch_off)
+    assert on == off, (on, off)
+    assert len({v for v in on.values()}) == 2   # (hot path and full layer are different computations: the probes are not degenerate)
+
+
 def test_sharded_layer_through_the_cpp_api():
     """tests/cpp/test_host_sharded_gpu.cpp: graph::Partition + GCNConv::shard() with P = 2, 4, 8 ranks as threads over the
     in-process communicator (the C-ABI's gnnx_partition_deal / gnnx_halo_plan_* / gnnx_halo_exchange_rows_f32 underneath)
