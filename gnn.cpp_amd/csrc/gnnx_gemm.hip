@@ -414,44 +414,55 @@ __device__ __forceinline__ void lds_read_b32(float &dst, uint32_t addr)
 // is the bench shape; 4 x 2 (512 threads, 256 x 128) takes 128-wide outputs (BASELINE configs[2]).  A k-major operand row of
 // 256 floats is one wave-instruction; one of 128 floats is half of one, so an instruction carries two rows (k and k + 16): see the
 // operand image below -- conflict-free fragment reads at both widths.
-template <int WM_, int WN_>
+template <int WM_, int WN_, int BK_ = 32>
 struct DmaGeo {
     static constexpr int WM = WM_, WN = WN_, NW = WM * WN, NT = 64 * NW;
-    static constexpr int BM = 64 * WM, BN = 64 * WN, BK = 32;
-    static constexpr int A_STAGE_BYTES = BM * BK * 4;                 // K-contiguous image: [BM rows][8 slots of 16 B]
-    static constexpr int A_PER_WAVE = (BM / 8) / NW;                  // 1-KiB wave-instructions per wavefront and K-tile
+    static constexpr int BM = 64 * WM, BN = 64 * WN, BK = BK_;
+    static_assert(BK == 32 || BK == 16, "K-tile of 32 or 16");
+    // K-contiguous image: [BM rows][SLOTS slots of 16 B], slot s of row r holding k-group s ^ a_xor(r).  A 16-lane fragment read takes
+    // one word of 16 consecutive rows x 4 q: rows 64 / BK apart share their banks, so the XOR runs over row / (64 / BK).
+    static constexpr int SLOTS = BK / 4;                              // k-groups (16 B) per row of the image
+    static constexpr int A_ROW_BYTES = BK * 4, A_BLOCK_BYTES = 16 * A_ROW_BYTES;   // one row; one MFMA block of 16 rows
+    static constexpr int A_ROWS_PER_INSTR = 1024 / A_ROW_BYTES;       // rows one 1-KiB wave-instruction brings (8 / 16)
+    static constexpr int a_xor(int row) { return (row / (64 / BK)) % SLOTS; }
+    static constexpr int A_STAGE_BYTES = BM * BK * 4;
+    static constexpr int A_PER_WAVE = (BM / A_ROWS_PER_INSTR) / NW;   // 1-KiB wave-instructions per wavefront and K-tile
     // k-major operand image (B here, both operands of the TN kernel): one DMA wave-instruction = 1 KiB = one k row of 256 floats or
     // TWO k rows of 128, landing in a piece of 272 words (256 of data + 16 of padding: every instruction has its own LDS base, so
     // pieces can be padded although the bytes of one instruction cannot).  A fragment read takes word (k = 4 KG + q, column c) for
     // the four q of a wavefront at once, so consecutive q must sit 16 banks apart: with one row per piece they are consecutive
-    // pieces (272 = 16 mod 64); with two rows per piece the instruction carries rows I and I + 16 -- NOT two neighbours, which would
-    // put q and q + 1 a multiple of 64 words apart (the 2-way conflict of the first version: 0.69 of the matrix peak at N = 128) --
-    // so that rows 4 KG .. 4 KG + 3 are again four consecutive pieces.
+    // pieces (272 = 16 mod 64); with two rows per piece the instruction carries rows I and I + BK / 2 -- NOT two neighbours, which
+    // would put q and q + 1 a multiple of 64 words apart (the 2-way conflict of the first version: 0.69 of the matrix peak at
+    // N = 128) -- so that rows 4 KG .. 4 KG + 3 are again four consecutive pieces.
     static constexpr int rows_per_instr(int width) { return 256 / width; }
     static constexpr int KPIECE_BYTES = 272 * 4;
     static constexpr int kstage_bytes(int width) { return (BK / rows_per_instr(width)) * KPIECE_BYTES; }
     // byte offset of k-group KG (rows 4 KG .. 4 KG + 3; the row inside the group is q * KPIECE_BYTES in the lane's address register)
     static constexpr int kgroup_off(int width, int KG)
     {
-        return rows_per_instr(width) == 1 ? 4 * KG * KPIECE_BYTES : (4 * (KG % 4)) * KPIECE_BYTES + (KG / 4) * 512;
+        return rows_per_instr(width) == 1 ? 4 * KG * KPIECE_BYTES : (4 * (KG % (BK / 8))) * KPIECE_BYTES + (KG / (BK / 8)) * 512;
     }
     // k row (inside the K-tile) that lane `lane` of wave-instruction I brings
     static constexpr int krow_of(int width, int I, int lane) { return rows_per_instr(width) == 1 ? I : I + (BK / 2) * (lane / 32); }
     static constexpr int B_STAGE_BYTES = kstage_bytes(BN);
     static constexpr int B_PIECE_BYTES = KPIECE_BYTES;                 // LDS bytes one B wave-instruction covers (>= 1024)
     static constexpr int B_PER_WAVE = (BK / rows_per_instr(BN)) / NW;
-    static constexpr int LDS_BYTES = 2 * A_STAGE_BYTES + 2 * B_STAGE_BYTES;
-    static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1 && A_PER_WAVE + B_PER_WAVE >= 4, "the epilogue needs four private 1-KiB pieces");
+    static constexpr int STAGES_BYTES = 2 * A_STAGE_BYTES + 2 * B_STAGE_BYTES;
+    // the epilogue stages a block row of C (16 rows x 64 columns) in FOUR 1-KiB pieces private to the wavefront: its own DMA pieces
+    // of the idle stage and, where a K-tile gives a wavefront fewer than four, pieces of its own behind the stages
+    static constexpr int EP_EXTRA = A_PER_WAVE + B_PER_WAVE >= 4 ? 0 : 4 - A_PER_WAVE - B_PER_WAVE;
+    static constexpr int LDS_BYTES = STAGES_BYTES + NW * EP_EXTRA * 1024;
+    static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1, "too many wavefronts for the operand tile");
 };
 
 template <class GEO, int STAGE_ID, int KG>
-__device__ __forceinline__ void dma2_read_group(float (&a)[4], float (&b)[4], const uint32_t (&ak)[8], uint32_t bk)
+__device__ __forceinline__ void dma2_read_group(float (&a)[4], float (&b)[4], const uint32_t (&ak)[GEO::SLOTS], uint32_t bk)
 {
-    constexpr int SA = STAGE_ID * GEO::A_STAGE_BYTES;
-    lds_read_b32<SA + 0 * 2048>(a[0], ak[KG]);
-    lds_read_b32<SA + 1 * 2048>(a[1], ak[KG]);
-    lds_read_b32<SA + 2 * 2048>(a[2], ak[KG]);
-    lds_read_b32<SA + 3 * 2048>(a[3], ak[KG]);
+    constexpr int SA = STAGE_ID * GEO::A_STAGE_BYTES, BLK = GEO::A_BLOCK_BYTES;
+    lds_read_b32<SA + 0 * BLK>(a[0], ak[KG]);
+    lds_read_b32<SA + 1 * BLK>(a[1], ak[KG]);
+    lds_read_b32<SA + 2 * BLK>(a[2], ak[KG]);
+    lds_read_b32<SA + 3 * BLK>(a[3], ak[KG]);
     constexpr int SB = STAGE_ID * GEO::B_STAGE_BYTES + GEO::kgroup_off(GEO::BN, KG);  // k row 4 KG + q (q is in the address register)
     lds_read_b32<SB + 0 * 64>(b[0], bk);
     lds_read_b32<SB + 1 * 64>(b[1], bk);
@@ -481,6 +492,13 @@ __device__ __forceinline__ void dma2_read_group(float (&a)[4], float (&b)[4], co
     GNNX_DMA2_STEP(ST, 6, 0, 1);                                          \
     GNNX_DMA2_WAIT(0, 1);                                                 \
     GNNX_DMA2_MFMA(1)
+#define GNNX_DMA2_KTILE16(ST)                                             \
+    dma2_read_group<GEO, ST, 0>(a[0], b[0], ak, bk);                     \
+    GNNX_DMA2_STEP(ST, 0, 0, 1);                                          \
+    GNNX_DMA2_STEP(ST, 1, 1, 0);                                          \
+    GNNX_DMA2_STEP(ST, 2, 0, 1);                                          \
+    GNNX_DMA2_WAIT(0, 1);                                                 \
+    GNNX_DMA2_MFMA(1)
 
 // LDS-DMA with a wave-uniform 64-bit base in SGPRs + a per-lane 32-bit BYTE offset (the saddr form: no 64-bit vector address
 // arithmetic, no zero-extended offset pairs to keep alive).  M0 = LDS destination of lane 0; it is compiler-reserved, so it is
@@ -493,7 +511,7 @@ __device__ __forceinline__ void dma_16B(uint32_t voff_bytes, const float *sbase,
 }
 
 #ifdef GNNX_EXPERIMENTS
-#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // 1: no C stores, 2: no operand loads after the first (timing only)
+#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // timing only -- 1: no epilogue, 2: no operand loads after the first, 4: the epilogue's LDS round trip without its stores, 8: stores straight from the accumulators (16 rows x 64 B per instruction)
 #else
 #define GNNX_ABLATE(bit) false
 #endif
@@ -515,11 +533,13 @@ struct GemmFuse {
 // NG (N guard): the last column tile is narrower than BN (N % 4 == 0): lanes whose 16 bytes lie past column N neither load B
 // (their LDS slots keep whatever they held: the products of those columns are garbage and stay in registers) nor store C nor
 // contribute column sums.
-template <int WM_, int WN_, int FUSE, bool NG>
-__global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate, GemmFuse fu)
+// BK_ = 16: half the K-tile, so that TWO workgroups are resident per CU (4 wavefronts per SIMD as before): the C-store epilogue and
+// the K-tile barriers of one run under the MFMAs of the other.
+template <int WM_, int WN_, int FUSE, bool NG, int BK_ = 32>
+__global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate, GemmFuse fu)
 {
     (void)ablate;
-    using GEO = DmaGeo<WM_, WN_>;
+    using GEO = DmaGeo<WM_, WN_, BK_>;
     constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK, NW = GEO::NW;
     constexpr int APW = GEO::A_PER_WAVE, BPW = GEO::B_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];  // [2][A stage], then [2][B stage]
@@ -536,8 +556,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
     uint32_t offa[APW], offb[BPW], pa[APW], pb[BPW];
 #pragma unroll
     for (int u = 0; u < APW; u++) {
-        const int row = 8 * (wave + NW * u) + (lane >> 3);
-        const int kg = (lane & 7) ^ ((row >> 1) & 7);
+        const int row = GEO::A_ROWS_PER_INSTR * (wave + NW * u) + lane / GEO::SLOTS;
+        const int kg = (lane % GEO::SLOTS) ^ GEO::a_xor(row);
         offa[u] = (uint32_t)(row * g.lda + 4 * kg) * 4u;
         pa[u] = lds0 + (uint32_t)((wave + NW * u) * 1024);
     }
@@ -561,14 +581,14 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
             if (u < BPW && okb) dma_16B(offb[u < BPW ? u : 0], bbase, pb[u < BPW ? u : 0] + stage * GEO::B_STAGE_BYTES);
         }
     };
-    // ---- fragment address registers (bytes): the 8 k-groups of this lane's row of block 0 (the row's slot XOR is the same in
-    // every 16-row block: (16 i + r) >> 1 & 7 == r >> 1 & 7)
-    uint32_t ak[8];
+    // ---- fragment address registers (bytes): the k-groups of this lane's row of block 0 (the row's slot XOR is the same in
+    // every 16-row block: 16 rows are a whole number of XOR periods)
+    uint32_t ak[GEO::SLOTS];
     {
         const int row = wm * 64 + r16;
-        const uint32_t xa = (uint32_t)(((row >> 1) & 7) << 4);
+        const uint32_t xa = (uint32_t)(GEO::a_xor(row) << 4);
 #pragma unroll
-        for (int kg = 0; kg < 8; kg++) ak[kg] = lds0 + (uint32_t)(row * 128 + 4 * q) + (((uint32_t)kg << 4) ^ xa);
+        for (int kg = 0; kg < GEO::SLOTS; kg++) ak[kg] = lds0 + (uint32_t)(row * GEO::A_ROW_BYTES + 4 * q) + (((uint32_t)kg << 4) ^ xa);
     }
     const uint32_t bk = lds0 + B0 + (uint32_t)(q * GEO::KPIECE_BYTES + (wn * 64 + r16) * 4);
     // ---- epilogue through LDS.  D = mfma(b, a): a lane holds C[16 i + r16][16 j + 4 q .. + 3] of its wavefront's 64 x 64
@@ -580,7 +600,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         if (p < APW) ep[p] = pa[p < APW ? p : 0] + GEO::A_STAGE_BYTES;
-        else ep[p] = pb[p >= APW && p - APW < BPW ? p - APW : 0] + GEO::B_STAGE_BYTES;
+        else if (p - APW < BPW) ep[p] = pb[p >= APW && p - APW < BPW ? p - APW : 0] + GEO::B_STAGE_BYTES;
+        else ep[p] = lds0 + (uint32_t)(GEO::STAGES_BYTES + (wave * GEO::EP_EXTRA + (p - APW - BPW)) * 1024);
     }
     const int pw = r16 >> 2;
     const uint32_t ep_wr = (pw == 0 ? ep[0] : pw == 1 ? ep[1] : pw == 2 ? ep[2] : ep[3]) + (uint32_t)((r16 & 3) * 256) +
@@ -613,11 +634,11 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
         for (int64_t k0 = 0; k0 < g.K; k0 += 2 * BK) {
             const bool last = k0 + 2 * BK >= g.K;
             if (!GNNX_ABLATE(2)) issue(1, mt, k0 + BK);   // K % 64 == 0: the odd K-tile of this trip always exists
-            GNNX_DMA2_KTILE(0);
+            if constexpr (BK == 32) { GNNX_DMA2_KTILE(0); } else { GNNX_DMA2_KTILE16(0); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if ((!last || mt_next < m_tiles) && !GNNX_ABLATE(2)) issue(0, last ? mt_next : mt, last ? 0 : k0 + 2 * BK);
-            GNNX_DMA2_KTILE(1);
+            if constexpr (BK == 32) { GNNX_DMA2_KTILE(1); } else { GNNX_DMA2_KTILE16(1); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -634,6 +655,18 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
         }
         const float alpha = g.alpha;
         char *ctile = reinterpret_cast<char *>(g.C) + (mt * BM * g.ldc + n0) * ES;
+        if constexpr (FUSE == 0 && !NG) {
+            if (GNNX_ABLATE(8)) {   // A/B: straight from the accumulators, 16 rows x 64 B per store instruction, no LDS
+                const uint32_t offd = (uint32_t)((wm * 64 + r16) * g.ldc + wn * 64 + 4 * q) * 4u;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    char *crow = ctile + (int64_t)(16 * i) * g.ldc * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) *reinterpret_cast<gemm_f32x4acc *>(crow + offd + 64 * j) = acc[i][j] * alpha;
+                }
+                continue;
+            }
+        }
         const char *ytile = FUSE == 1 ? reinterpret_cast<const char *>(fu.ymask + mt * BM * fu.ldy + n0) : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -677,7 +710,9 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_kernel(GemmArgs g, in
                     ob.h[3] = (__bf16)o[p][3];
                     if (okc) *reinterpret_cast<uint2 *>(crow + (int64_t)(4 * p) * g.ldc * ES + offc) = ob.u;
                 } else {
-                    if (okc) *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * ES + offc) = o[p];
+                    if (GNNX_ABLATE(4)) {   // A/B: the LDS round trip without the stores
+                        asm volatile("" ::"v"(o[p]));
+                    } else if (okc) *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * ES + offc) = o[p];
                 }
             }
         }
@@ -1080,42 +1115,43 @@ int lds_opt_in(K kernel, size_t lds, std::atomic<uint64_t> &done)
     return GNNX_OK;
 }
 
-template <int WM, int WN, bool NG>
+template <int WM, int WN, bool NG, int BKT = 32>
 int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse, int64_t *partial_rows, int fuse_mode)
 {
-    using GEO = DmaGeo<WM, WN>;
+    using GEO = DmaGeo<WM, WN, BKT>;
     constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK;
     if ((int64_t)BM * g.lda >= (1ll << 28) || (int64_t)BK * g.ldb >= (1ll << 28) || (int64_t)BM * g.ldc >= (1ll << 28))
         return GNNX_OK;  // per-lane BYTE offsets are 32-bit
     const int64_t m_tiles = g.M / BM, cols = ceil_div(g.N, (int64_t)BN);
     constexpr size_t lds = GEO::LDS_BYTES;   // 4 x 4: 2 x (32 KB + 34 KB) = 132 KB; 4 x 2: 2 x (32 KB + 17 KB) = 98 KB; 2 x 2: 66 KB
     constexpr int wg_per_cu = 160 * 1024 / lds >= 2 ? 2 : 1;   // resident workgroups: as many as the LDS of a CU holds
-    int64_t gy = ceil_div((int64_t)kNumCU * wg_per_cu, cols);
+    static const int wgpcu_env = [] { const char *e = experiment_env("GNNX_GEMM_WGPCU"); return e ? atoi(e) : 0; }();   // A/B: resident workgroups per CU
+    int64_t gy = ceil_div((int64_t)kNumCU * (wgpcu_env > 0 ? wgpcu_env : wg_per_cu), cols);
     if (gy > m_tiles) gy = m_tiles;
     static std::atomic<uint64_t> done_plain{0}, done_fuse{0}, done_stats{0};
     static const int ablate = [] { const char *e = experiment_env("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
     if (fuse_mode == 3) {
         static std::atomic<uint64_t> done_bf16{0};
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 3, NG>, lds, done_bf16);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 3, NG, BKT>, lds, done_bf16);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 3, NG>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 3, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
     } else if (fuse && fuse_mode == 2) {
         if (!aligned16(fuse->ymask)) return GNNX_OK;
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 2, NG>, lds, done_stats);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 2, NG, BKT>, lds, done_stats);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 2, NG>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 2, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else if (fuse) {
         if (fuse->ldy % 4 || !aligned16(fuse->ymask) || (int64_t)BM * fuse->ldy >= (1ll << 28)) return GNNX_OK;
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 1, NG>, lds, done_fuse);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 1, NG, BKT>, lds, done_fuse);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 1, NG>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 1, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else {
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0, NG>, lds, done_plain);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0, NG, BKT>, lds, done_plain);
         if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0, NG>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
+        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
     }
     GNNX_LAUNCH_CHECK();
     *rows_done = m_tiles * BM;
@@ -1130,12 +1166,22 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const Gemm
     if (!dma_shape_ok(g.M, g.N, g.K)) return GNNX_OK;
     if (g.lda % 4 || g.ldb % 4 || g.ldc % 4 || !aligned16(g.A) || !aligned16(g.B) || !aligned16(g.C)) return GNNX_OK;
     if (fuse_mode == 3 && g.alpha != 1.0f) return GNNX_OK;
+#ifdef GNNX_EXPERIMENTS
+    static const int geo256 = [] { const char *e = experiment_env("GNNX_GEMM_GEO256"); return e ? atoi(e) : 0; }();
+    if (g.N % 256 == 0 && geo256 == 2416) return launch_dma_geo<2, 4, false, 16>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+#endif
     if (g.N % 256 == 0) return launch_dma_geo<4, 4, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
     static const int geo128 = [] { const char *e = experiment_env("GNNX_GEMM_GEO128"); return e ? atoi(e) : 0; }();
     if (geo128 == 22) {   // A/B: 128 x 128 tiles, two resident workgroups of 4 wavefronts per CU
         if (g.N % 128 == 0) return launch_dma_geo<2, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
         return launch_dma_geo<2, 2, true>(g, st, rows_done, fuse, partial_rows, fuse_mode);
     }
+#ifdef GNNX_EXPERIMENTS
+    if (geo128 == 4216) {   // A/B: the 256 x 128 tile on K-tiles of 16, two resident workgroups per CU
+        if (g.N % 128 == 0) return launch_dma_geo<4, 2, false, 16>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+        return launch_dma_geo<4, 2, true, 16>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    }
+#endif
     if (g.N % 128 == 0) return launch_dma_geo<4, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
     return launch_dma_geo<4, 2, true>(g, st, rows_done, fuse, partial_rows, fuse_mode);
 }
