@@ -402,7 +402,7 @@ def main():
                        "step": "layer fwd+bwd" if not args.train_layers else
                        f"{args.train_layers}-layer GCN training step (fwd, softmax-CE, bwd of every parameter, SGD; no input gradient); value counts {args.train_layers}*nnz",
                        "parallelism": "single" if world == 1 and not args.force_sharded else
-                       f"1-D vertex shard x{world} ({args.partition}), halo all-to-all-v, schedule {args.schedule}" +
+                       f"1-D vertex shard x{world} ({args.partition}), halo all-to-all-v, schedule {'training' if args.train_layers else args.schedule}" +
                        (" (X and G both inputs of the step, as at N = 1: each chain's compute under the other chain's exchange)"
                         if args.schedule == "overlap" and not args.train_layers else "") +
                        (f" (forward -> backward dependence honoured; exchanges pipelined in {runner_chunks} row chunks)"

@@ -23,13 +23,10 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Scope guards for device temporaries: released on EVERY exit path of the enclosing scope (the GNNX_HIP_CHECK / GNNX_REQUIRE early
-// returns included).  DeviceFree: a hipMallocAsync allocation, freed in stream order; DeviceFreeSync: a hipMalloc allocation.
-struct DeviceFree {
-    void *p;
-    hipStream_t st;
-    ~DeviceFree() { if (p) (void)hipFreeAsync(p, st); }
-};
+// Scope guard for a device temporary (hipMalloc): released on EVERY exit path of the enclosing scope (the GNNX_HIP_CHECK /
+// GNNX_REQUIRE early returns included).  Temporaries are only made by build-time calls (CSR, plans, norm), which synchronise anyway;
+// no stream-ordered pool allocations: with rank threads running such calls concurrently, each on its own stream, they gave wrong
+// results now and then (gnnx_degree_norm_f32).
 struct DeviceFreeSync {
     void *p = nullptr;
     ~DeviceFreeSync() { if (p) (void)hipFree(p); }

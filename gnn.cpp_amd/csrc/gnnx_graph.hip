@@ -307,14 +307,14 @@ GNNX_API int gnnx_equal_i32(const int32_t *d_a, const int32_t *d_b, int64_t n, i
     if (n == 0 || d_a == d_b) return GNNX_OK;
     GNNX_REQUIRE(d_a && d_b, GNNX_ERR_INVALID_ARG, "null pointer");
     hipStream_t st = as_stream(stream);
-    int32_t *flag = nullptr;
-    GNNX_HIP_CHECK(hipMallocAsync((void **)&flag, sizeof(int32_t), st));
+    DeviceFreeSync flag_g;   // plain hipMalloc / hipFree, as every temporary of the build-time calls (see gnnx_degree_norm_f32)
+    GNNX_HIP_CHECK(hipMalloc(&flag_g.p, sizeof(int32_t)));
+    int32_t *flag = static_cast<int32_t *>(flag_g.p);
     GNNX_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(differ_kernel, dim3((uint32_t)ceil_div(n, 256)), dim3(256), 0, st, d_a, d_b, n, flag);
     GNNX_LAUNCH_CHECK();
     int32_t h = 0;
     GNNX_HIP_CHECK(hipMemcpyAsync(&h, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    GNNX_HIP_CHECK(hipFreeAsync(flag, st));
     GNNX_HIP_CHECK(hipStreamSynchronize(st));
     *equal_out = h ? 0 : 1;
     return GNNX_OK;
@@ -345,13 +345,13 @@ GNNX_API int gnnx_csr_validate(const int32_t *d_rowptr, const int32_t *d_colidx,
     GNNX_HIP_CHECK(hipMemcpyAsync(&h[0], d_rowptr + n_rows, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     GNNX_HIP_CHECK(hipStreamSynchronize(st));
     GNNX_REQUIRE(h[0] >= 0 && (h[0] == 0 || d_colidx), GNNX_ERR_INVALID_ARG, "colidx is null but the graph has %d entries", h[0]);
-    int32_t *bad = nullptr;
-    GNNX_HIP_CHECK(hipMallocAsync((void **)&bad, sizeof(int32_t), st));
+    DeviceFreeSync bad_g;
+    GNNX_HIP_CHECK(hipMalloc(&bad_g.p, sizeof(int32_t)));
+    int32_t *bad = static_cast<int32_t *>(bad_g.p);
     GNNX_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int32_t), st));
     hipLaunchKernelGGL(csr_validate_kernel, dim3((uint32_t)ceil_div(n_rows, 256)), dim3(256), 0, st, d_rowptr, d_colidx, n_rows, n_cols, bad);
     GNNX_LAUNCH_CHECK();
     GNNX_HIP_CHECK(hipMemcpyAsync(&h[1], bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    GNNX_HIP_CHECK(hipFreeAsync(bad, st));
     GNNX_HIP_CHECK(hipStreamSynchronize(st));
     GNNX_REQUIRE(!h[1], GNNX_ERR_INDEX_RANGE, "CSR is malformed: rowptr not monotone from 0, or a column id outside [0, %d)", n_cols);
     return GNNX_OK;
@@ -540,16 +540,17 @@ GNNX_API int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_coli
         // rows' own s: d_s when written here, else the caller's column-indexed vector is also row-indexed
         const float *s_rows = d_s ? d_s : d_s_cols;
         const float *s_cols = d_s_cols ? d_s_cols : d_s;
-        // scratch for the list of long rows: stream-ordered allocation, this is a once-per-graph build call
-        int32_t *list = nullptr;
-        GNNX_HIP_CHECK(hipMallocAsync((void **)&list, sizeof(int32_t) * ((size_t)n_rows + 1), st));
+        // scratch for the list of long rows (a once-per-graph build call: plain hipMalloc, freed behind a synchronisation)
+        DeviceFreeSync list_g;
+        GNNX_HIP_CHECK(hipMalloc(&list_g.p, sizeof(int32_t) * ((size_t)n_rows + 1)));
+        int32_t *list = static_cast<int32_t *>(list_g.p);
         int32_t *count = list + n_rows;
         GNNX_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(norm_kernel, grid, dim3(T), 0, st, d_rowptr, d_colidx, n_rows, s_rows, s_cols, d_norm, list, count);
         GNNX_LAUNCH_CHECK();
         hipLaunchKernelGGL(norm_long_kernel, dim3(1024), dim3(256), 0, st, d_rowptr, d_colidx, s_rows, s_cols, d_norm, list, count);
         GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(hipFreeAsync(list, st));
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // the list is freed on return
     }
     return GNNX_OK;
 }
