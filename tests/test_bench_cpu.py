@@ -32,14 +32,18 @@ def test_roofline_traffic_comes_from_the_newest_profile_of_the_same_graph():
     spec = importlib.util.spec_from_file_location("bench_mod_cpu", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    pats = [r"^spmm_hub_kernel<\d+, 0, ", r"^spmm_(stream_)?kernel<\d+, \d+, \d+, 0, "]
+    pats = [(r"^spmm_hub_kernel<\d+, 0, ", True), (r"^spmm_hubpc_kernel<0, ", False), (r"^spmm_(stream_)?kernel<\d+, \d+, \d+, 0, ", True)]
+    import hashlib
+    spmm_sha = hashlib.sha256(open(os.path.join(ROOT, "gnn.cpp_amd", "csrc", "gnnx_spmm.hip"), "rb").read()).hexdigest()
     for wl, lo, hi in (("rmat10m_100m_f256", 100e9, 112.2e9), ("rmat1m_10m_f128", 3e9, 5.7e9), ("products_2p4m_62m_f100", 26e9, 36e9)):
         tr = bench.profiled_traffic(wl, pats)
         assert tr is not None, wl
         total, src = tr
         assert lo < total < hi, (wl, total)
-        assert src["file"].startswith("profiles/r03_") and len(src["kernels"]) == 2 and src["profiled_nnz"] and src["git_head_of_profiled_build"]
+        assert src["file"].startswith("profiles/r04_") and len(src["kernels"]) in (2, 3) and src["profiled_nnz"] and src["git_head_of_profiled_build"]
         assert any("spmm_hub_kernel" in k for k in src["kernels"]) and any("spmm_stream_kernel" in k for k in src["kernels"])
+        # bench.py refuses a profile made with another aggregation source: the committed one must match the tree
+        assert src["spmm_source_sha256_of_profiled_build"] == spmm_sha, (wl, "re-run scripts/profile_all.sh: gnnx_spmm.hip changed since the profile")
     assert bench.profiled_traffic("no_such_workload", pats) is None
     # the algorithmic byte count of SURVEY.md 8(d) for the headline graph
     assert bench.spmm_bytes(10_000_000, 10_000_000, 99_100_605, 256, bias=True) == 112_195_422_968
