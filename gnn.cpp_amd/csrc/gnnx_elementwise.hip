@@ -23,7 +23,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // partials are combined through LDS in group order.  Fixed grid and fixed order => deterministic.
 // COPY: every row that is read is also written to `copy` (row stride ldc) -- gnnx_colsum_copy_f32: the upstream gradient on the
 // padded row stride the backward aggregation gathers from, made by the pass that reads it anyway.
-template <int UNROLL, bool COPY = false>
+template <int UNROLL, bool COPY = false, bool NT = false>
 __global__ __launch_bounds__(256) void colsum_stage1_vec(const float *G, int64_t ldg, int64_t n_rows, int32_t n_feat,
                                                           int64_t rows_per_block, float *partial, float *copy = nullptr, int64_t ldc = 0)
 {
@@ -47,7 +47,14 @@ __global__ __launch_bounds__(256) void colsum_stage1_vec(const float *G, int64_t
 #pragma unroll
                 for (int u = 0; u < UNROLL; u++) {
                     acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
-                    if constexpr (COPY) *reinterpret_cast<float4 *>(copy + f0 + 4 * li + (r + (int64_t)u * groups) * ldc) = v[u];
+                    if constexpr (COPY) {
+                        float4 *dst = reinterpret_cast<float4 *>(copy + f0 + 4 * li + (r + (int64_t)u * groups) * ldc);
+                        if constexpr (NT) {
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            f4v w = {v[u].x, v[u].y, v[u].z, v[u].w};
+                            __builtin_nontemporal_store(w, reinterpret_cast<f4v *>(dst));
+                        } else *dst = v[u];
+                    }
                 }
             }
             for (; r < r1; r += groups) {
@@ -142,8 +149,12 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float *partial, int32
 
 int colsum_blocks(int64_t n_rows)
 {
+    // two resident workgroups per CU, each streaming ONE contiguous range of rows: 10 M x 256 sums in 1.65 ms (6.2 TB/s; 1.73 with
+    // 2048 workgroups, 1.91 with 8192), sums + copy in 3.46 ms (5.9 TB/s read + written; 3.98 / 4.08) -- scripts/exp_colsum_copy.py
     int64_t b = ceil_div(n_rows, 64);
-    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+    static const int cap_env = [] { const char *e = experiment_env("GNNX_COLSUM_BLOCKS"); return e ? atoi(e) : 0; }();   // A/B
+    const int64_t cap = cap_env > 0 ? cap_env : 2 * kNumCU;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 // ---- row-wise elementwise -------------------------------------------------------------------------
@@ -416,6 +427,30 @@ int colsum_impl(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, f
     if (d_copy) {   // the copy rides in the 16-byte kernel only; other shapes: the plain sums and a strided copy behind them
         GNNX_REQUIRE(ldc >= n_feat && d_copy != d_G, GNNX_ERR_INVALID_ARG, "copy: ld < n_feat or aliasing");
         if (vec && ldc % 4 == 0 && aligned16(d_copy)) {
+#ifdef GNNX_EXPERIMENTS
+            static const int nt_env = [] { const char *e = experiment_env("GNNX_COLSUM_NT"); return e ? atoi(e) : 0; }();
+            if (nt_env == 8) {
+                hipLaunchKernelGGL((colsum_stage1_vec<8, true, false>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
+                GNNX_LAUNCH_CHECK();
+                hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);
+                GNNX_LAUNCH_CHECK();
+                return GNNX_OK;
+            }
+            if (nt_env == 2) {
+                hipLaunchKernelGGL((colsum_stage1_vec<2, true, false>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
+                GNNX_LAUNCH_CHECK();
+                hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);
+                GNNX_LAUNCH_CHECK();
+                return GNNX_OK;
+            }
+            if (nt_env) {
+                hipLaunchKernelGGL((colsum_stage1_vec<4, true, true>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
+                GNNX_LAUNCH_CHECK();
+                hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);
+                GNNX_LAUNCH_CHECK();
+                return GNNX_OK;
+            }
+#endif
             hipLaunchKernelGGL((colsum_stage1_vec<4, true>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
             GNNX_LAUNCH_CHECK();
             hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);

@@ -350,6 +350,12 @@ inline bool bn_vec_ok(int32_t n_feat, const void *a, int64_t lda, const void *b,
     return n_feat % 4 == 0 && n_feat <= 1024 && al(a, lda) && al(b, ldb) && al(c, ldc) && al(d, ldd);
 }
 
+int64_t apply_block_cap()
+{
+    static const int cap_env = [] { const char *e = experiment_env("GNNX_BN_APPLY_BLOCKS"); return e ? atoi(e) : 0; }();   // A/B
+    return cap_env > 0 ? cap_env : 8192;
+}
+
 int pick_fw(int32_t n_feat)
 {
     int fw = 1;
@@ -359,7 +365,9 @@ int pick_fw(int32_t n_feat)
 int n_blocks_for(int64_t n_rows)
 {
     int64_t b = ceil_div(n_rows, 64);
-    return (int)(b < 1 ? 1 : (b > kBlocks ? kBlocks : b));
+    static const int cap_env = [] { const char *e = experiment_env("GNNX_BN_REDUCE_BLOCKS"); return e ? atoi(e) : 0; }();   // A/B
+    const int64_t cap = cap_env > 0 ? cap_env : kBlocks;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 template <class OP>
@@ -386,7 +394,7 @@ int launch_bn_apply_vec(const float *d_X, int64_t ldx, const float *d_Y, int64_t
 {
     const int rows_pass = 4 * (256 / (n_feat / 4));   // rows one workgroup has in flight
     int64_t nb = ceil_div(n_rows, (int64_t)rows_pass);
-    if (nb > 8192) nb = 8192;
+    if (nb > apply_block_cap()) nb = apply_block_cap();
     BnBwdVecArgs p{};
     p.X = d_X; p.Y = d_Y; p.dY = d_dY; p.mean = d_mean; p.var = d_var; p.gamma = d_gamma; p.beta = d_beta;
     p.ldx = ldx; p.ldy = ldy; p.ldd = ldd; p.n_rows = n_rows; p.rows_per_block = ceil_div(n_rows, nb); p.n_feat = n_feat;
@@ -432,7 +440,7 @@ GNNX_API int gnnx_bn_relu_fwd_f32(const float *d_X, int64_t ldx, int64_t n_rows,
     if (bn_vec_ok(n_feat, d_X, ldx, d_Y, ldy, nullptr, 0, nullptr, 0)) {
         const int rows_pass = 4 * (256 / (n_feat / 4));
         int64_t nb = ceil_div(n_rows, (int64_t)rows_pass);
-        if (nb > 8192) nb = 8192;
+        if (nb > apply_block_cap()) nb = apply_block_cap();
         hipLaunchKernelGGL(bn_fwd_vec_kernel, dim3((uint32_t)nb), dim3(256), 0, as_stream(stream), d_X, ldx, n_rows, n_feat, d_mean, d_var, eps,
                            d_gamma, d_beta, relu, d_Y, ldy, ceil_div(n_rows, nb));
         GNNX_LAUNCH_CHECK();
