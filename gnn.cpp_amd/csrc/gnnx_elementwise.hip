@@ -23,60 +23,59 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // partials are combined through LDS in group order.  Fixed grid and fixed order => deterministic.
 // COPY: every row that is read is also written to `copy` (row stride ldc) -- gnnx_colsum_copy_f32: the upstream gradient on the
 // padded row stride the backward aggregation gathers from, made by the pass that reads it anyway.
-template <int UNROLL, bool COPY = false, bool NT = false>
+template <int UNROLL, bool COPY = false>
 __global__ __launch_bounds__(256) void colsum_stage1_vec(const float *G, int64_t ldg, int64_t n_rows, int32_t n_feat,
-                                                          int64_t rows_per_block, float *partial, float *copy = nullptr, int64_t ldc = 0)
+                                                          int64_t rows_per_range, int ranges_per_block, float *partial, float *copy = nullptr,
+                                                          int64_t ldc = 0)
 {
+    // partial[v] = sums of row range v (rows_per_range consecutive rows); a workgroup takes ranges_per_block consecutive ranges one
+    // after the other, so the partials -- and with them every bit of the result -- do not depend on how many workgroups are launched
     __shared__ float4 red[256];
     const int L = n_feat / 4;            // lanes per row (<= 256)
     const int groups = 256 / L;          // row groups per pass
     const int li = threadIdx.x % L, grp = threadIdx.x / L;
-    int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    int64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
-    for (int f0 = 0; f0 < n_feat; f0 += 4 * L) {  // one iteration unless F > 1024
-        float4 acc[UNROLL];
+    for (int v = 0; v < ranges_per_block; v++) {
+        const int64_t range = (int64_t)blockIdx.x * ranges_per_block + v;
+        int64_t r0 = range * rows_per_range;
+        int64_t r1 = r0 + rows_per_range < n_rows ? r0 + rows_per_range : n_rows;
+        for (int f0 = 0; f0 < n_feat; f0 += 4 * L) {  // one iteration unless F > 1024
+            float4 acc[UNROLL];
 #pragma unroll
-        for (int u = 0; u < UNROLL; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grp < groups && f0 + 4 * li < n_feat) {
-            const float *base = G + f0 + 4 * li;
-            int64_t r = r0 + grp;
-            for (; r + (int64_t)(UNROLL - 1) * groups < r1; r += (int64_t)UNROLL * groups) {
-                float4 v[UNROLL];
+            for (int u = 0; u < UNROLL; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grp < groups && f0 + 4 * li < n_feat) {
+                const float *base = G + f0 + 4 * li;
+                int64_t r = r0 + grp;
+                for (; r + (int64_t)(UNROLL - 1) * groups < r1; r += (int64_t)UNROLL * groups) {
+                    float4 w[UNROLL];
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++) v[u] = *reinterpret_cast<const float4 *>(base + (r + (int64_t)u * groups) * ldg);
+                    for (int u = 0; u < UNROLL; u++) w[u] = *reinterpret_cast<const float4 *>(base + (r + (int64_t)u * groups) * ldg);
 #pragma unroll
-                for (int u = 0; u < UNROLL; u++) {
-                    acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
-                    if constexpr (COPY) {
-                        float4 *dst = reinterpret_cast<float4 *>(copy + f0 + 4 * li + (r + (int64_t)u * groups) * ldc);
-                        if constexpr (NT) {
-                            typedef float f4v __attribute__((ext_vector_type(4)));
-                            f4v w = {v[u].x, v[u].y, v[u].z, v[u].w};
-                            __builtin_nontemporal_store(w, reinterpret_cast<f4v *>(dst));
-                        } else *dst = v[u];
+                    for (int u = 0; u < UNROLL; u++) {
+                        acc[u].x += w[u].x; acc[u].y += w[u].y; acc[u].z += w[u].z; acc[u].w += w[u].w;
+                        if constexpr (COPY) *reinterpret_cast<float4 *>(copy + f0 + 4 * li + (r + (int64_t)u * groups) * ldc) = w[u];
                     }
                 }
+                for (; r < r1; r += groups) {
+                    float4 w = *reinterpret_cast<const float4 *>(base + r * ldg);
+                    acc[0].x += w.x; acc[0].y += w.y; acc[0].z += w.z; acc[0].w += w.w;
+                    if constexpr (COPY) *reinterpret_cast<float4 *>(copy + f0 + 4 * li + r * ldc) = w;
+                }
             }
-            for (; r < r1; r += groups) {
-                float4 v = *reinterpret_cast<const float4 *>(base + r * ldg);
-                acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
-                if constexpr (COPY) *reinterpret_cast<float4 *>(copy + f0 + 4 * li + r * ldc) = v;
-            }
-        }
-        float4 t = acc[0];
+            float4 t = acc[0];
 #pragma unroll
-        for (int u = 1; u < UNROLL; u++) { t.x += acc[u].x; t.y += acc[u].y; t.z += acc[u].z; t.w += acc[u].w; }
-        red[threadIdx.x] = t;
-        __syncthreads();
-        if (grp == 0 && f0 + 4 * li < n_feat) {
-            float4 s4 = red[li];
-            for (int k = 1; k < groups; k++) {
-                float4 o = red[k * L + li];
-                s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+            for (int u = 1; u < UNROLL; u++) { t.x += acc[u].x; t.y += acc[u].y; t.z += acc[u].z; t.w += acc[u].w; }
+            red[threadIdx.x] = t;
+            __syncthreads();
+            if (grp == 0 && f0 + 4 * li < n_feat) {
+                float4 s4 = red[li];
+                for (int k = 1; k < groups; k++) {
+                    float4 o = red[k * L + li];
+                    s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+                }
+                *reinterpret_cast<float4 *>(partial + range * n_feat + f0 + 4 * li) = s4;
             }
-            *reinterpret_cast<float4 *>(partial + (int64_t)blockIdx.x * n_feat + f0 + 4 * li) = s4;
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -427,31 +426,12 @@ int colsum_impl(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, f
     if (d_copy) {   // the copy rides in the 16-byte kernel only; other shapes: the plain sums and a strided copy behind them
         GNNX_REQUIRE(ldc >= n_feat && d_copy != d_G, GNNX_ERR_INVALID_ARG, "copy: ld < n_feat or aliasing");
         if (vec && ldc % 4 == 0 && aligned16(d_copy)) {
-#ifdef GNNX_EXPERIMENTS
-            static const int nt_env = [] { const char *e = experiment_env("GNNX_COLSUM_NT"); return e ? atoi(e) : 0; }();
-            if (nt_env == 8) {
-                hipLaunchKernelGGL((colsum_stage1_vec<8, true, false>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
-                GNNX_LAUNCH_CHECK();
-                hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);
-                GNNX_LAUNCH_CHECK();
-                return GNNX_OK;
-            }
-            if (nt_env == 2) {
-                hipLaunchKernelGGL((colsum_stage1_vec<2, true, false>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
-                GNNX_LAUNCH_CHECK();
-                hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);
-                GNNX_LAUNCH_CHECK();
-                return GNNX_OK;
-            }
-            if (nt_env) {
-                hipLaunchKernelGGL((colsum_stage1_vec<4, true, true>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
-                GNNX_LAUNCH_CHECK();
-                hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);
-                GNNX_LAUNCH_CHECK();
-                return GNNX_OK;
-            }
-#endif
-            hipLaunchKernelGGL((colsum_stage1_vec<4, true>), dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, d_copy, ldc);
+            // read + write streams: ONE workgroup per CU (two row ranges each, the same partials as the plain sums) -- 10 M x 256 inside
+            // the layer step: 3.40 ms, against 4.04 with two workgroups per CU and 4.10 with eight (scripts/exp_colsum_copy.py, bench.py)
+            static const int rpb_env = [] { const char *e = experiment_env("GNNX_COLSUM_COPY_RANGES"); return e ? atoi(e) : 0; }();   // A/B
+            int per = rpb_env > 0 ? rpb_env : 2;
+            if (nb % per != 0) per = 1;
+            hipLaunchKernelGGL((colsum_stage1_vec<4, true>), dim3(nb / per), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, per, partial, d_copy, ldc);
             GNNX_LAUNCH_CHECK();
             hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_out);
             GNNX_LAUNCH_CHECK();
@@ -462,7 +442,7 @@ int colsum_impl(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, f
                                             (size_t)n_rows, hipMemcpyDeviceToDevice, st));
     }
     if (vec) {
-        hipLaunchKernelGGL(colsum_stage1_vec<4>, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial, nullptr, 0);
+        hipLaunchKernelGGL(colsum_stage1_vec<4>, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, 1, partial, nullptr, 0);
     } else if (n_feat >= 128) {
         hipLaunchKernelGGL(colsum_stage1, dim3(nb), dim3(256), 0, st, d_G, ldg, n_rows, n_feat, rpb, partial);
     } else {

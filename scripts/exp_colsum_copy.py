@@ -36,7 +36,9 @@ out = torch.empty(F, dtype=torch.float32, device=dev)
 ms = timeit(lambda: ops.colsum(G, out=out))
 print(f"colsum                {ms:7.3f} ms  {n * F * 4 / ms / 1e6:7.1f} GB/s read")
 ld = ops.gather_row_stride(n, F)
+spacer = torch.empty(int(os.environ.get("SPACER_MB", 0)) << 20, dtype=torch.uint8, device=dev) if os.environ.get("SPACER_MB") else None   # another placement of the copy
 Gp = ops.empty_gathered(n, F, device=dev)
+print(f"G at {G.data_ptr():#x}, copy at {Gp.data_ptr():#x}")
 ms = timeit(lambda: ops.colsum_copy(G, Gp, out=out))
 print(f"colsum + copy (ld {ld}) {ms:7.3f} ms  {2 * n * F * 4 / ms / 1e6:7.1f} GB/s read + written   NT={os.environ.get('GNNX_COLSUM_NT', '0')}")
 assert torch.equal(Gp, G)

@@ -40,7 +40,7 @@ def main():
         g.make_plans(1024, F)
         out = torch.empty((n, F), dtype=torch.float32, device=dev)
         bias = torch.zeros(F, dtype=torch.float32, device=dev)
-        for ld in ((256, 264, 272, 288, 320) if relabel is None else (256,)):
+        for ld in (tuple(int(v) for v in os.environ.get("STRIDES", "256,264,272,288,320").split(",")) if relabel is None else (256,)):
             Hp = torch.empty((n, ld), dtype=torch.float32, device=dev)
             Hp[:, :F] = ops.uniform_pm1(1, (n, F), device=dev)
             H = Hp[:, :F]
