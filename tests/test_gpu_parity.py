@@ -1666,3 +1666,51 @@ def test_split_gemm_rejects_shapes_it_does_not_cover(env):
         ops.gemm_split(X, W, transB=True)          # K % 16 != 0
     with pytest.raises(capi.GnnxError):
         ops.gemm_split(ops.uniform_pm1(984, (100, 64), device=env["dev"]), ops.uniform_pm1(985, (100, 64), device=env["dev"]), transB=True)  # N % 128
+
+
+def test_layer_step_captured_in_a_hip_graph_same_bits(env):
+    """The C-ABI compute calls neither allocate nor synchronise (workspaces grown by a first eager step), so one layer step -- transform,
+    planned aggregation with BOTH hub kernels forked onto the side streams and joined back with events, column sums, backward
+    aggregation, the two gradient products -- is capturable in a hipGraph as it stands (bench.py --hip-graph): three replays give the
+    bits of the eager step."""
+    ops, torch = env["ops"], env["torch"]
+    n, e, F = 30000, 600000, 128
+    src, dst, rp, ci, g = make_graph(env, n, e, seed=911)
+    g.make_plans(chunk=64, max_feat=F, big_rows=700)   # rows above 700 on the producer / consumer kernel, the other hub rows on spmm_hub_kernel
+    deg = np.diff(rp)
+    assert (deg > 700).sum() >= 1 and ((deg > 64) & (deg <= 700)).sum() >= 4
+    X, W = dev(env, synth.uniform_pm1(1, (n, F))), dev(env, synth.uniform_pm1(2, (F, F), scale=F ** -0.5))
+    G, bias = dev(env, synth.uniform_pm1(3, (n, F))), dev(env, synth.uniform_pm1(4, (F,)))
+    bufs = {k: torch.empty((n, F), dtype=torch.float32, device=env["dev"]) for k in ("H", "out", "dH", "dX")}
+    dW, db = torch.empty((F, F), dtype=torch.float32, device=env["dev"]), torch.empty(F, dtype=torch.float32, device=env["dev"])
+
+    def step():
+        ops.linear_fwd(X, W, out=bufs["H"])
+        ops.aggregate_fwd(g, bufs["H"], bias, out=bufs["out"])
+        ops.colsum(G, out=db)
+        ops.aggregate_bwd(g, G, out=bufs["dH"])
+        ops.gemm(bufs["dH"], W, out=bufs["dX"])
+        ops.gemm(bufs["dH"], X, transA=True, out=dW)
+
+    step()
+    torch.cuda.synchronize()
+    ref = {k: v.clone() for k, v in bufs.items()}
+    ref_dW, ref_db = dW.clone(), db.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step()   # (the capture stream's own side streams and workspaces exist before the capture starts)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        step()
+    for _ in range(3):
+        for v in bufs.values():
+            v.zero_()
+        dW.zero_()
+        db.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in bufs:
+            assert torch.equal(bufs[k], ref[k]), k
+        assert torch.equal(dW, ref_dW) and torch.equal(db, ref_db)
