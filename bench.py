@@ -116,8 +116,9 @@ def _timed_ms(capi, fn, reps=5, warmup=2):
     return a.elapsed_ms(b) / reps
 
 
-def copy_ceiling(capi, dev, gib=4, variant=0):
-    """float4 copy of `gib` GiB (read + written bytes / time), GB/s."""
+def copy_ceiling(capi, dev, gib=10, variant=0):
+    """float4 copy of `gib` GiB (read + written bytes / time), GB/s.  (10 GiB -- the size of one of the step's matrices: 6.0 TB/s; 4 GiB:
+    5.7, the launch's ramp and tail weigh more.)"""
     L = _ceilings_lib()
     n = gib * 2 ** 30 // 4
     src = torch.full((n,), 1.0, dtype=torch.float32, device=dev)
@@ -152,7 +153,7 @@ def measure_ceilings(capi, dev):
          "fabric_gather_38MB_GBps": best(lambda: gather_ceiling(capi, dev, table_mb=38)),
          "fabric_gather": "sum of 8 uniformly random 1-KiB rows of a 160 MB table (Infinity-Cache resident) per streamed output row; "
                           "gathered + index + written bytes / time (bench_kernels/ceilings.hip)",
-         "hbm_copy": "float4 copy of 4 GiB, read + written bytes / time"}
+         "hbm_copy": "float4 copy of 10 GiB, read + written bytes / time"}
     torch.cuda.empty_cache()
     return c
 
