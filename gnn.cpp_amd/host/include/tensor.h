@@ -290,12 +290,14 @@ struct Csr {
     uint32_t flags = GNNX_CSR_KEEP_SELF_LOOPS;       // edge_to_adj_mat keeps the diagonal; fill_diagonal_(0) strips it
     // load-balancing plans of the SpMM (power-law rows), built on demand for a feature width
     gnnx_spmm_plan *plan = nullptr, *plan_t = nullptr;
+    gnnx_spmm_plan *plan_pro = nullptr;   // forward plan of the aggregation that applies BatchNorm / ReLU to every gathered row (ensure_prologue_plan)
     int32_t plan_feat = 0;
     void *norm_per_nz_t = nullptr;  // norm[colidx_t[p]]: the backward's per-source scale as a coalesced stream
     ~Csr();
     void build();            // (re)build A from the COO with `flags`
     void ensure_transpose();
     void ensure_plans(int32_t n_feat);
+    void ensure_prologue_plan(int32_t n_feat);
     void drop_plans();
 };
 

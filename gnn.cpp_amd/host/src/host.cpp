@@ -119,7 +119,8 @@ void Csr::drop_plans()
 {
     if (plan) gnnx_spmm_plan_destroy(plan);
     if (plan_t) gnnx_spmm_plan_destroy(plan_t);
-    plan = plan_t = nullptr;
+    if (plan_pro) gnnx_spmm_plan_destroy(plan_pro);
+    plan = plan_t = plan_pro = nullptr;
     plan_feat = 0;
 }
 
@@ -132,6 +133,18 @@ void Csr::ensure_plans(int32_t n_feat)
     gx(gnnx_spmm_plan_create((const int32_t *)rowptr, n, kChunk, n_feat, &plan, current_stream()), "plan");
     gx(gnnx_spmm_plan_create((const int32_t *)rowptr_t, n, kChunk, n_feat, &plan_t, current_stream()), "plan");
     plan_feat = n_feat;
+}
+
+void Csr::ensure_prologue_plan(int32_t n_feat)
+{
+    if (plan_pro) return;
+    // With the BatchNorm / ReLU prologue the hub kernel is bound by its vector ALU (five separately rounded operations per gathered
+    // element on one wavefront per SIMD) while the streaming kernel carries the prologue at its plain speed: rows of up to 4096
+    // non-zeros stay with the streaming kernel (RMAT 10 M / 100 M, F = 256: 15.3 -> 14.65 ms; without a prologue 1024 is the better
+    // threshold, 13.6 vs 13.7 ms; scripts/exp_hub_prologue.py).  Same bits: a row's order of additions does not depend on the kernel.
+    constexpr int32_t kChunkPrologue = 4096;
+    static const int32_t chunk = [] { const char *e = std::getenv("GNNCPP_PROLOGUE_CHUNK"); return e && atoi(e) > 0 ? atoi(e) : kChunkPrologue; }();   // A/B
+    gx(gnnx_spmm_plan_create((const int32_t *)rowptr, n, chunk, n_feat, &plan_pro, current_stream()), "plan");
 }
 
 static void build_one(const void *src, const void *dst, int64_t n_edges, int32_t n, uint32_t flags, void **rowptr, void **colidx,
@@ -826,6 +839,7 @@ public:
         const int32_t f = (int32_t)shp[1];
         void *st = cyg::detail::current_stream();
         csr->ensure_plans(f);
+        csr->ensure_prologue_plan(f);
         if (!have_stats) {
             mean = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
             var = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{1, shp[1]}, false);
@@ -849,7 +863,7 @@ public:
         fu.relu_in = 1;
         cyg::detail::gx(gnnx_spmm_csr_fused_f32(csr->n, csr->n, f, (const int32_t *)csr->rowptr, (const int32_t *)csr->colidx, nullptr,
                                                 nullptr, norm->device_data(), bias->device_data(), hp, ldh, 0.0f,
-                                                out->device_out(), f, &fu, csr->plan, st), "aggregate");
+                                                out->device_out(), f, &fu, csr->plan_pro, st), "aggregate");
         has_beta = (bool)beta;
         if (req) context->save_for_backward({h, bias, gamma, beta ? beta : gamma});
         return out;

@@ -45,8 +45,10 @@ def main():
     beta = torch.zeros(F, dtype=torch.float32, device=dev)
     bn = (mean, var, gamma, beta, 1e-5)
     ref = None
-    for name, thr in (("default split", None), ("all hub rows on the pc kernel", 0)):
-        g.make_plans(1024, F, big_rows=thr)
+    chunks = [int(c) for c in os.environ.get("CHUNKS", "1024").split(",")]   # hub threshold (rows above it leave the streaming kernel)
+    for name, thr, chunk in [("default split", None, c) for c in chunks] + [("all hub rows on the pc kernel", 0, chunks[0])]:
+        name = f"chunk {chunk} {name}"
+        g.make_plans(chunk, F, big_rows=thr)
         plain = timed(lambda: ops.aggregate_fwd(g, H, bias, out=out))
         pro = timed(lambda: ops.aggregate_fwd(g, H, bias, out=out, bn=bn, relu_in=True))
         o = ops.aggregate_fwd(g, H, bias, bn=bn, relu_in=True)
