@@ -19,14 +19,17 @@ constexpr int kNumXCD = 8;
 
 int set_error(int status, const char *fmt, ...);
 
+// Device copy of table[k] = the HOST libm's powf((float)k, -0.5f), k = 0 .. *len_out - 1 >= need_len - 1, on the current device:
+// process-wide, built once under a mutex, immutable and never freed (gnnx_graph.hip) -- usable from any thread on any stream.
+int libm_pow_m05_table(size_t need_len, const float **d_table_out, size_t *len_out);
+
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Scope guard for a device temporary (hipMalloc): released on EVERY exit path of the enclosing scope (the GNNX_HIP_CHECK /
-// GNNX_REQUIRE early returns included).  Temporaries are only made by build-time calls (CSR, plans, norm), which synchronise anyway;
-// no stream-ordered pool allocations: with rank threads running such calls concurrently, each on its own stream, they gave wrong
-// results now and then (gnnx_degree_norm_f32).
+// GNNX_REQUIRE early returns included).  Temporaries are only made by build-time calls (CSR, plans, norm), which synchronise their
+// stream before the guard runs; hipFree itself synchronises the device before the memory can be handed out again.
 struct DeviceFreeSync {
     void *p = nullptr;
     ~DeviceFreeSync() { if (p) (void)hipFree(p); }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void pow_scan_kernel(const float *x, int64_t n
     int32_t mx = 0, bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float v = x[i];
-        if (!(v >= 0.f && v <= (float)kPowTableMax && v == truncf(v))) bad = 1;
+        if (!(v >= 0.f && v <= (float)kPowTableMax && v == truncf(v)) || (v == 0.f && signbit(v))) bad = 1;   // pow(-0, e < 0) = -inf: not the table's +inf
         else mx = (int32_t)v > mx ? (int32_t)v : mx;
     }
 #pragma unroll
@@ -641,31 +641,29 @@ GNNX_API int gnnx_pow_f32(const float *d_x, int64_t n, float exponent, float *d_
     int64_t blocks = ceil_div(n, 256);
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;
     // The reference evaluates std::pow on the HOST (functional.h:253), i.e. the host libm's powf, and the one call on the hot path is
-    // deg->pow(-0.5) on the degrees 1 + rowsum(A): non-negative integers.  For such an argument vector (every element an integer in
-    // [0, 2^24]) the result is looked up in a table of that very libm call, table[k] = powf((float)k, e) -- the reference's bits, where a
-    // device pow would be 1 ulp off for some k.  One reduction, one host synchronisation and max + 1 libm calls: a graph-build call,
-    // not a per-step one.  Any other argument vector is evaluated on the device (tolerance-level against the host libm).
-    // (temporaries with the synchronous allocator and synchronous copies, as in gnnx_degree_norm_f32: see the note there)
-    DeviceFreeSync info_g, table_g;
-    GNNX_HIP_CHECK(hipMalloc(&info_g.p, 2 * sizeof(int32_t)));
-    int32_t *d_info = static_cast<int32_t *>(info_g.p);
-    GNNX_HIP_CHECK(hipMemsetAsync(d_info, 0, 2 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(pow_scan_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, d_info);
-    GNNX_LAUNCH_CHECK();
-    GNNX_HIP_CHECK(hipStreamSynchronize(st));
-    int32_t info[2] = {0, 1};
-    GNNX_HIP_CHECK(hipMemcpy(info, d_info, sizeof(info), hipMemcpyDeviceToHost));
-    if (!info[1]) {
-        std::vector<float> table((size_t)info[0] + 1);
-        volatile float e = exponent;   // a run-time exponent: the call stays the libm's powf whatever the optimiser knows about it
-        for (int64_t k = 0; k <= info[0]; k++) table[(size_t)k] = powf((float)k, e);
-        GNNX_HIP_CHECK(hipMalloc(&table_g.p, sizeof(float) * table.size()));
-        float *d_table = static_cast<float *>(table_g.p);
-        GNNX_HIP_CHECK(hipMemcpy(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice));   // complete on return
-        hipLaunchKernelGGL(pow_table_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, d_table, d_y);
+    // deg->pow(-0.5) on the degrees 1 + rowsum(A): non-negative integers.  For exponent -0.5 and such an argument vector (every element
+    // an integer in [0, 2^24], no negative zero) the result is looked up in the process-wide table of that very libm call
+    // (libm_pow_m05_table, gnnx_graph.hip) -- the reference's bits, where a device pow would be 1 ulp off for some k.  One reduction and
+    // one host synchronisation: a graph-build call, not a per-step one.  Every other exponent or argument vector is evaluated on the
+    // device without any synchronisation (tolerance-level against the host libm; stream-asynchronous, capturable).
+    if (exponent == -0.5f) {
+        DeviceFreeSync info_g;
+        GNNX_HIP_CHECK(hipMalloc(&info_g.p, 2 * sizeof(int32_t)));
+        int32_t *d_info = static_cast<int32_t *>(info_g.p);
+        GNNX_HIP_CHECK(hipMemsetAsync(d_info, 0, 2 * sizeof(int32_t), st));
+        hipLaunchKernelGGL(pow_scan_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, d_info);
         GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // the table is freed behind the kernel
-        return GNNX_OK;
+        int32_t info[2] = {0, 1};
+        GNNX_HIP_CHECK(hipMemcpyAsync(info, d_info, sizeof(info), hipMemcpyDeviceToHost, st));
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));
+        if (!info[1]) {
+            const float *d_table = nullptr;
+            const int rc = libm_pow_m05_table((size_t)info[0] + 1, &d_table, nullptr);
+            if (rc != GNNX_OK) return rc;
+            hipLaunchKernelGGL(pow_table_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, d_table, d_y);
+            GNNX_LAUNCH_CHECK();
+            return GNNX_OK;   // (the table is immutable and never freed: nothing to wait for)
+        }
     }
     hipLaunchKernelGGL(pow_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, d_x, n, exponent, d_y);
     GNNX_LAUNCH_CHECK();

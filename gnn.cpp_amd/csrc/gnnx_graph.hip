@@ -16,6 +16,9 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <mutex>
+#include <vector>
+
 #include "gnnx_common.h"
 
 // Parity depends on separately rounded fp32 mul / add (the reference has no FMA): never contract.
@@ -108,11 +111,17 @@ __global__ void deg_rsqrt_exp_kernel(const int32_t *rowptr, int32_t n_rows, floa
 }
 #endif
 
-__global__ void deg_pow_table_kernel(const int32_t *rowptr, int32_t n_rows, const float *table, float *s)
+__global__ void deg_pow_table_kernel(const int32_t *rowptr, int32_t n_rows, const float *table, int32_t table_len, float *s, int32_t *bad)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
-    s[i] = table[rowptr[i + 1] - rowptr[i] + 1];   // table[k] = powf((float)k, -0.5f)
+    const int32_t k = rowptr[i + 1] - rowptr[i] + 1;   // table[k] = powf((float)k, -0.5f)
+    if (k < 1 || k >= table_len) {   // never on a consistent rowptr (the table covers 1 + max degree): an error, not a wild read
+        atomicOr(bad, 1);
+        s[i] = 0.f;
+        return;
+    }
+    s[i] = table[k];
 }
 
 // norm_i = fl(fl(sum_{j desc} s_j) * s_i), strictly sequential in the reference's matmul order (descending column)
@@ -162,6 +171,55 @@ __global__ __launch_bounds__(256) void norm_long_kernel(const int32_t *rowptr, c
     }
 }
 
+}  // namespace
+
+// ---- the host libm's powf(k, -0.5f), k = 0 .. len-1, on the device --------------------------------------------------------------
+// One table per device for the whole process: built on the host with the very call the reference makes (functional.h:253 -> glibc
+// powf; 1 ulp from the correctly rounded value for 9 685 of the 2^24 integers, so no device-side rsqrt reproduces it), uploaded
+// synchronously under a mutex, then IMMUTABLE: a longer table is a new allocation, the old one stays alive (and valid: a prefix of
+// the new one) for kernels that are still reading it -- growth is geometric, so the retired copies sum to less than the live one.
+// Callers on any thread and any stream may use the returned pointer without further ordering.
+namespace gnnx {
+int libm_pow_m05_table(size_t need_len, const float **d_table_out, size_t *len_out)
+{
+    constexpr int kMaxDev = 64;
+    constexpr size_t kMaxLen = ((size_t)1 << 24) + 2;   // floats hold integers exactly up to 2^24
+    struct Table {
+        float *d = nullptr;
+        size_t len = 0;
+    };
+    static std::mutex mu;
+    static Table tables[kMaxDev];
+    GNNX_REQUIRE(d_table_out && need_len <= kMaxLen, GNNX_ERR_UNSUPPORTED, "degree table of %zu entries (limit %zu)", need_len, kMaxLen);
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    GNNX_REQUIRE(dev >= 0 && dev < kMaxDev, GNNX_ERR_UNSUPPORTED, "device index %d", dev);
+    std::lock_guard<std::mutex> lk(mu);
+    Table &t = tables[dev];
+    if (t.len < need_len) {
+        size_t len = need_len > 2 * t.len ? need_len : 2 * t.len;
+        if (len < 4096) len = 4096;
+        if (len > kMaxLen) len = kMaxLen;
+        std::vector<float> h(len);
+        volatile float expo = -0.5f;   // a run-time exponent: the call stays a libm powf call whatever the optimiser knows about -0.5
+        for (size_t k = 0; k < len; k++) h[k] = powf((float)k, expo);
+        float *d = nullptr;
+        GNNX_HIP_CHECK(hipMalloc((void **)&d, sizeof(float) * len));
+        const hipError_t e = hipMemcpy(d, h.data(), sizeof(float) * len, hipMemcpyHostToDevice);   // complete on return
+        if (e != hipSuccess) {
+            (void)hipFree(d);
+            GNNX_HIP_CHECK(e);
+        }
+        t.d = d;   // (the previous table, if any, is retired, not freed: a kernel of another thread may be reading it)
+        t.len = len;
+    }
+    *d_table_out = t.d;
+    if (len_out) *len_out = t.len;
+    return GNNX_OK;
+}
+}  // namespace gnnx
+
+namespace {
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct CsrWorkspace {
@@ -502,33 +560,31 @@ GNNX_API int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_coli
     } else
 #endif
     if (d_s) {
-        // table[k] = the host libm's powf((float)k, -0.5f) for k = 1 .. 1 + max degree: what the reference evaluates per vertex
-        // (functional.h:253).  One reduction + one host synchronisation + (1 + max degree) libm calls, once per graph.
-        // Every temporary with the SYNCHRONOUS allocator and synchronous copies.  This is a once-per-graph call, and rank threads of an
-        // in-process group build their shards concurrently, each on a stream of its own: with stream-ordered temporaries
-        // (hipMallocAsync / hipFreeAsync) and asynchronous copies from / to pageable host memory the table path gave a wrong s now and
-        // then (tests/cpp/test_host_sharded_gpu with 4 ranks: 1-4 of 10 runs exact, whether or not the copy was waited for before the
-        // kernel that reads the table; the device-side rsqrt: 6 of 6; this form: 21 of 22, the odd one not reproduced in 12 more).
-        DeviceFreeSync max_g, table_g;
-        GNNX_HIP_CHECK(hipMalloc(&max_g.p, sizeof(int32_t)));
-        int32_t *d_max = static_cast<int32_t *>(max_g.p);
-        GNNX_HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(int32_t), st));
+        // s = table[deg + 1], table[k] = the host libm's powf((float)k, -0.5f): what the reference evaluates per vertex
+        // (functional.h:253).  The table is the process-wide, immutable, grow-only one of libm_pow_m05_table() -- rank threads of an
+        // in-process group that build their shards concurrently share it and never build, upload or free a table of their own.
+        // One reduction + one host synchronisation per call (a once-per-graph call).
+        DeviceFreeSync max_g;
+        GNNX_HIP_CHECK(hipMalloc(&max_g.p, 2 * sizeof(int32_t)));
+        int32_t *d_max = static_cast<int32_t *>(max_g.p);   // [0] max degree, [1] error flag of the lookup kernel
+        GNNX_HIP_CHECK(hipMemsetAsync(d_max, 0, 2 * sizeof(int32_t), st));
         hipLaunchKernelGGL(max_degree_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_max);
         GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(hipStreamSynchronize(st));
         int32_t h_max = 0;
-        GNNX_HIP_CHECK(hipMemcpy(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost));
+        GNNX_HIP_CHECK(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));
         GNNX_REQUIRE(h_max >= 0, GNNX_ERR_INVALID_ARG, "rowptr is not monotone");
-        std::vector<float> table((size_t)h_max + 2);
-        table[0] = 0.f;
-        volatile float expo = -0.5f;   // a run-time exponent: the call stays a libm powf call whatever the optimiser knows about -0.5
-        for (int64_t k = 1; k <= (int64_t)h_max + 1; k++) table[(size_t)k] = powf((float)k, expo);
-        GNNX_HIP_CHECK(hipMalloc(&table_g.p, sizeof(float) * table.size()));
-        float *d_table = static_cast<float *>(table_g.p);
-        GNNX_HIP_CHECK(hipMemcpy(d_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice));   // complete on return
-        hipLaunchKernelGGL(deg_pow_table_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_table, d_s);
+        const float *d_table = nullptr;
+        size_t table_len = 0;
+        const int rc = libm_pow_m05_table((size_t)h_max + 2, &d_table, &table_len);
+        if (rc != GNNX_OK) return rc;
+        hipLaunchKernelGGL(deg_pow_table_kernel, grid, dim3(T), 0, st, d_rowptr, n_rows, d_table, (int32_t)(table_len < 0x7fffffffu ? table_len : 0x7fffffffu),
+                           d_s, d_max + 1);
         GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // the table is freed behind the kernel
+        int32_t h_bad = 0;
+        GNNX_HIP_CHECK(hipMemcpyAsync(&h_bad, d_max + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // (d_max is freed behind the kernel)
+        GNNX_REQUIRE(!h_bad, GNNX_ERR_HIP, "degree table lookup out of range (max degree read back as %d): rowptr changed under the call?", h_max);
     }
     if (d_norm) {
         if (!d_colidx) {  // only a graph without entries may come without colidx (once-per-graph call: the sync is fine)

@@ -6,7 +6,9 @@
 //
 // Execution model: one rank per GPU.  A rank is either a process (RCCL transport, `Comm::rccl`) or a thread of one
 // process (`Comm::local_group`); in both cases a rank's tensors, stream, workspace and allocator cache belong to the
-// thread that runs it (they are thread_local in this backend).
+// thread that runs it: every thread gets a stream of its OWN on its first use of the backend (host.cpp: ThreadRuntime; no
+// thread issues on the legacy NULL stream), and whatever crosses threads is ordered explicitly -- the in-process collectives
+// synchronise the calling rank's stream on both sides of a host barrier (gnnx_comm.hip).
 #ifndef GNNCPP_AMD_DIST_H
 #define GNNCPP_AMD_DIST_H
 
@@ -42,6 +44,15 @@ private:
 
 namespace graph {
 
+// Device snapshots of the stages of ONE sharded layer step, taken on the rank's stream without any host synchronisation
+// when Partition::trace is set (tests: a mismatch against the unsharded layer is localised to its first wrong stage).
+struct ShardTrace {
+    cyg::tptr<float> h_ext;   // [n_local + fwd.n_halo, F]: the transform's rows and the halo rows as received
+    cyg::tptr<float> out;     // [n_local, F]
+    cyg::tptr<float> g_ext;   // [n_local + bwd.n_halo, F]: the upstream gradient's rows and its halo rows as received
+    cyg::tptr<float> dy;      // [n_local, F]: the backward aggregation's output
+};
+
 // The shard of one graph that one rank owns: vertices dealt by degree (every rank: n/P +- 1 rows, the same degree mix,
 // the same send volume per peer), rows of A and of A^T as CSR over [local | halo] columns -- a row's entries in the
 // reference's order, so a rank's output rows are the unsharded layer's rows bit for bit -- both halo plans, and the
@@ -71,6 +82,9 @@ public:
     Side fwd, bwd;
     std::shared_ptr<dist::Comm> comm;
     cyg::tptr<float> norm;          // [n_local, 1]
+    cyg::tptr<float> s_ext;         // [n_local + fwd.n_halo, 1]: deg^-1/2 of my rows, then of the halo columns as received
+    std::shared_ptr<ShardTrace> trace;   // optional: stage snapshots of the next layer step (see ShardTrace)
+    std::vector<int> halo_new_ids(const Side &s) const;   // new (rank-contiguous) vertex id of every halo column, in halo order
     void *norm_nz_bwd = nullptr;    // float per non-zero of bwd: norm of the entry's column (the source vertex)
     void ensure_spmm_plans(int32_t n_feat);
     // exchange rows of a [n_local + n_halo, n_feat] device buffer: fills the halo tail from the owners

@@ -110,14 +110,15 @@ Partition::Partition(const tensor<int> &edge_index, size_t num_nodes, std::share
     // aggregation per non-zero
     const size_t nl = (size_t)_n_local;
     {
-        Scratch s_ext(sizeof(float) * (nl + (size_t)fwd.n_halo));
-        gx(gnnx_memset(s_ext.p, 0, s_ext.bytes, st), "partition");
-        gx(gnnx_degree_norm_f32((const int32_t *)fwd.rowptr, (const int32_t *)fwd.colidx, (int32_t)nl, s_ext.as<float>(), nullptr, nullptr,
-                                st), "partition");
-        exchange(fwd, s_ext.as<float>(), 1);
+        const size_t n_ext = nl + (size_t)fwd.n_halo;
+        s_ext = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{std::max<size_t>(n_ext, 1), 1}, false);
+        float *sx = s_ext->device_out();
+        gx(gnnx_memset(sx, 0, sizeof(float) * std::max<size_t>(n_ext, 1), st), "partition");
+        gx(gnnx_degree_norm_f32((const int32_t *)fwd.rowptr, (const int32_t *)fwd.colidx, (int32_t)nl, sx, nullptr, nullptr, st), "partition");
+        exchange(fwd, sx, 1);
         norm = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{std::max<size_t>(nl, 1), 1}, false);
-        gx(gnnx_degree_norm_f32((const int32_t *)fwd.rowptr, (const int32_t *)fwd.colidx, (int32_t)nl, nullptr, s_ext.as<float>(),
-                                norm->device_out(), st), "partition");
+        gx(gnnx_degree_norm_f32((const int32_t *)fwd.rowptr, (const int32_t *)fwd.colidx, (int32_t)nl, nullptr, sx, norm->device_out(), st),
+           "partition");
         Scratch nb(sizeof(float) * (nl + (size_t)bwd.n_halo));
         gx(gnnx_memset(nb.p, 0, nb.bytes, st), "partition");
         if (nl) gx(gnnx_memcpy_d2d(nb.p, norm->device_data(), sizeof(float) * nl, st), "partition");
@@ -126,6 +127,16 @@ Partition::Partition(const tensor<int> &edge_index, size_t num_nodes, std::share
         gx(gnnx_gather_rows_f32(nb.as<float>(), 1, (const int32_t *)bwd.colidx, bwd.nnz, 1, (float *)norm_nz_bwd, 1, st), "partition");
         gx(gnnx_stream_sync(st), "partition");  // scratch goes back to the pool below
     }
+}
+
+std::vector<int> Partition::halo_new_ids(const Side &s) const
+{
+    std::vector<int> out((size_t)s.n_halo, -1);
+    if (s.n_halo == 0) return out;
+    const int32_t *d_ids = nullptr;
+    gx(gnnx_halo_plan_info(s.plan, nullptr, nullptr, nullptr, nullptr, nullptr, &d_ids, nullptr), "partition");
+    gx(gnnx_memcpy_d2h(out.data(), d_ids, sizeof(int32_t) * out.size(), current_stream()), "partition");
+    return out;
 }
 
 Partition::~Partition()
@@ -238,6 +249,12 @@ public:
         float *hext = in_place ? h->device_data() : hext_buf.as<float>();
         if (!in_place && nl) gx(gnnx_memcpy_d2d(hext, h->device_data(), sizeof(float) * (size_t)nl * f, st), "aggregate");
         part->exchange(part->fwd, hext, f);
+        auto snapshot = [&](const float *src, size_t rows) {
+            auto t = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{std::max<size_t>(rows, 1), (size_t)f}, false);
+            if (rows) gx(gnnx_memcpy_d2d(t->device_out(), src, sizeof(float) * rows * (size_t)f, st), "trace");
+            return t;
+        };
+        if (part->trace) part->trace->h_ext = snapshot(hext, (size_t)(nl + part->fwd.n_halo));
         const bool req = h->requires_grad() || (bias && bias->requires_grad()) || (use_bn && gamma->requires_grad()) ||
                          (has_beta && beta->requires_grad());
         auto out = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, req);
@@ -255,6 +272,7 @@ public:
                                          bias ? bias->device_data() : nullptr, hext, f, 0.0f, out->device_out(), f, use_bn ? &fu : nullptr,
                                          part->fwd.spmm_plan, st);
         gx(rc, "aggregate");
+        if (part->trace) part->trace->out = snapshot(out->device_data(), (size_t)nl);
         has_bias = (bool)bias;
         if (req) context->save_for_backward({h, bias ? bias : h, use_bn ? gamma : h, has_beta ? beta : h});
         return out;
@@ -276,11 +294,18 @@ public:
         float *gext = gext_buf.as<float>();
         if (nl) gx(gnnx_memcpy_d2d(gext, g->device_data(), sizeof(float) * (size_t)nl * f, st), "aggregate");
         part->exchange(part->bwd, gext, f);
+        auto snapshot = [&](const float *src, size_t rows) {
+            auto t = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{std::max<size_t>(rows, 1), (size_t)f}, false);
+            if (rows) gx(gnnx_memcpy_d2d(t->device_out(), src, sizeof(float) * rows * (size_t)f, st), "trace");
+            return t;
+        };
+        if (part->trace) part->trace->g_ext = snapshot(gext, (size_t)(nl + part->bwd.n_halo));
         auto dy = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, shp, false);
         int rc = gnnx_spmm_csr_f32((int32_t)nl, (int32_t)(nl + part->bwd.n_halo), f, (const int32_t *)part->bwd.rowptr,
                                    (const int32_t *)part->bwd.colidx, (const float *)part->norm_nz_bwd, nullptr, nullptr, nullptr, gext, f,
                                    0.0f, dy->device_out(), f, part->bwd.spmm_plan, st);
         gx(rc, "aggregate");
+        if (part->trace) part->trace->dy = snapshot(dy->device_data(), (size_t)nl);
         if (!use_bn) {
             if (h->requires_grad()) h->backward(dy);
             return;

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <iterator>
+#include <mutex>
 #include <random>
 #include <unordered_map>
 #include <vector>
@@ -18,13 +20,77 @@ using namespace cyg;
 namespace cyg {
 namespace detail {
 
-// Per-THREAD runtime state: the stream every op of this thread is enqueued on, its grow-only scratch and its allocator
-// cache.  Contract: a rank (dist.h) = one host thread = one in-order stream; tensors are created, used and released by the
-// thread that runs their rank, so a cached block is only ever re-issued to work queued behind its last user on the same
-// stream -- no events needed.  Switching the thread's stream drains the old one first.
-static thread_local void *g_stream = nullptr;
-static thread_local void *g_ws = nullptr;
-static thread_local size_t g_ws_bytes = 0;
+// Per-THREAD runtime state.  Contract: a rank (dist.h) = one host thread = one in-order stream of its own.
+//   * The stream is created on the thread's first use of the backend (a non-blocking stream on the device current at that moment;
+//     no thread ever issues on the legacy NULL stream, whose implicit cross-stream synchronisation would couple the rank threads of
+//     an in-process group) and destroyed, drained, when the thread ends.  set_current_stream() lets an embedding application
+//     supply its own (not owned, never destroyed here).
+//   * Scratch and the allocator cache belong to the thread: a cached block is only ever re-issued to work queued behind its last
+//     user on the same stream -- no events needed.  Every block carries its owner: a block released by ANOTHER thread (a tensor that
+//     outlived its rank thread, or was handed across threads) is not cached but given back to the driver, whose free synchronises the
+//     device -- so the contract "tensors are used by the thread that made them" is a performance rule, not a correctness one.
+//   * Everything that crosses threads is ordered explicitly: the in-process collectives (gnnx_comm.hip: stream synchronisation on
+//     both sides of a host barrier) and the driver's own device-wide synchronisation in hipFree.
+struct ThreadRuntime;
+static ThreadRuntime &rt();
+static std::mutex g_owner_mu;
+static std::unordered_map<void *, ThreadRuntime *> g_owner;   // live block -> the thread runtime whose stream last used it
+
+struct ThreadRuntime {
+    void *stream = nullptr;
+    bool stream_owned = false, stream_set = false;
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+    std::unordered_map<size_t, std::vector<void *>> blocks;
+
+    void *get_stream()
+    {
+        if (!stream_set) {
+            gx(gnnx_stream_create(&stream), "stream");
+            stream_owned = true;
+            stream_set = true;
+        }
+        return stream;
+    }
+    void drain()
+    {
+        if (stream_set) (void)gnnx_stream_sync(stream);
+    }
+    void release_blocks()
+    {
+        {
+            std::lock_guard<std::mutex> lk(g_owner_mu);
+            for (auto &kv : blocks)
+                for (void *p : kv.second) g_owner.erase(p);
+        }
+        for (auto &kv : blocks) {
+            for (void *p : kv.second) gnnx_free(p);
+            kv.second.clear();
+        }
+    }
+    // A rank thread of dist::Comm::local_group that exits must not strand its blocks, its scratch or its stream.  Blocks of this
+    // thread that are still alive inside tensors (owned by someone else now) lose their owner: their release frees them directly.
+    ~ThreadRuntime()
+    {
+        drain();
+        release_blocks();
+        if (ws) gnnx_free(ws);
+        ws = nullptr;
+        ws_bytes = 0;
+        {
+            std::lock_guard<std::mutex> lk(g_owner_mu);
+            for (auto it = g_owner.begin(); it != g_owner.end();) it = it->second == this ? g_owner.erase(it) : std::next(it);
+        }
+        if (stream_owned && stream) (void)gnnx_stream_destroy(stream);
+        stream = nullptr;
+        stream_set = stream_owned = false;
+    }
+};
+static ThreadRuntime &rt()
+{
+    static thread_local ThreadRuntime r;
+    return r;
+}
 
 void gx(int status, const char *where)
 {
@@ -40,59 +106,49 @@ void gx(int status, const char *where)
     throw std::runtime_error(msg);
 }
 
-void *current_stream() { return g_stream; }
+void *current_stream() { return rt().get_stream(); }
 void set_current_stream(void *stream)
 {
-    if (stream == g_stream) return;
-    gx(gnnx_stream_sync(g_stream), "set_current_stream");  // cached blocks / scratch may still be in use on the old stream
-    g_stream = stream;
+    ThreadRuntime &r = rt();
+    if (r.stream_set && stream == r.stream) return;
+    if (r.stream_set) {
+        gx(gnnx_stream_sync(r.stream), "set_current_stream");  // cached blocks / scratch may still be in use on the old stream
+        if (r.stream_owned && r.stream) gx(gnnx_stream_destroy(r.stream), "set_current_stream");
+    }
+    r.stream = stream;
+    r.stream_owned = false;
+    r.stream_set = true;
 }
 
 void *workspace(size_t bytes)
 {
     if (bytes == 0) return nullptr;
-    if (bytes > g_ws_bytes) {
-        if (g_ws) {
-            gx(gnnx_stream_sync(g_stream), "workspace");
-            gnnx_free(g_ws);
+    ThreadRuntime &r = rt();
+    if (bytes > r.ws_bytes) {
+        if (r.ws) {
+            gx(gnnx_stream_sync(r.get_stream()), "workspace");
+            gnnx_free(r.ws);
         }
-        g_ws = nullptr;
-        gx(gnnx_malloc(&g_ws, bytes), "workspace");
-        g_ws_bytes = bytes;
+        r.ws = nullptr;
+        r.ws_bytes = 0;
+        gx(gnnx_malloc(&r.ws, bytes), "workspace");
+        r.ws_bytes = bytes;
     }
-    return g_ws;
+    return r.ws;
 }
 
-// The per-thread allocator cache and scratch are given back to the device when their thread ends (a rank thread of
-// dist::Comm::local_group that exits must not strand its blocks).
-struct ThreadPool {
-    std::unordered_map<size_t, std::vector<void *>> blocks;
-    ~ThreadPool()
-    {
-        if (g_stream || !blocks.empty() || g_ws) (void)gnnx_stream_sync(g_stream);
-        for (auto &kv : blocks)
-            for (void *p : kv.second) gnnx_free(p);
-        if (g_ws) gnnx_free(g_ws);
-        g_ws = nullptr;
-        g_ws_bytes = 0;
-    }
-};
-static std::unordered_map<size_t, std::vector<void *>> &pool()
-{
-    static thread_local ThreadPool p;
-    return p.blocks;
-}
 static size_t bucket(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
 void *dev_alloc(size_t bytes)
 {
     if (bytes == 0) return nullptr;
     const size_t b = bucket(bytes);
-    auto &fl = pool()[b];
+    ThreadRuntime &r = rt();
+    auto &fl = r.blocks[b];
     if (!fl.empty()) {
         void *p = fl.back();
         fl.pop_back();
-        return p;
+        return p;   // (still registered to this thread)
     }
     void *p = nullptr;
     int st = gnnx_malloc(&p, b);
@@ -100,12 +156,24 @@ void *dev_alloc(size_t bytes)
         cyg::empty_cache();
         gx(gnnx_malloc(&p, b), "alloc");
     }
+    std::lock_guard<std::mutex> lk(g_owner_mu);
+    g_owner[p] = &r;
     return p;
 }
 
 void dev_free(void *ptr, size_t bytes)
 {
-    if (ptr) pool()[bucket(bytes)].push_back(ptr);
+    if (!ptr) return;
+    ThreadRuntime &r = rt();
+    bool mine;
+    {
+        std::lock_guard<std::mutex> lk(g_owner_mu);
+        auto it = g_owner.find(ptr);
+        mine = it != g_owner.end() && it->second == &r;
+        if (!mine && it != g_owner.end()) g_owner.erase(it);
+    }
+    if (mine) r.blocks[bucket(bytes)].push_back(ptr);
+    else gnnx_free(ptr);   // another thread's block (or an orphan): hipFree synchronises the device before the memory is reused
 }
 
 Csr::~Csr()
@@ -212,21 +280,26 @@ void Csr::ensure_transpose()
 
 void empty_cache()
 {
-    detail::gx(gnnx_stream_sync(detail::current_stream()), "empty_cache");
-    for (auto &[b, fl] : detail::pool()) {
-        for (void *p : fl) gnnx_free(p);
-        fl.clear();
-    }
+    detail::rt().drain();
+    detail::rt().release_blocks();
 }
 
+// One generator for the process, like the reference's global engine (utils.cpp:6) -- but rank threads construct their layers
+// concurrently (nn::Linear draws its initial weights), so every draw takes a lock.
+static std::mutex g_rng_mu;
 static std::mt19937_64 &engine()
 {
     static std::mt19937_64 e(0x5eed5eedull);
     return e;
 }
-void manual_seed(unsigned long long seed) { engine().seed(seed); }
+void manual_seed(unsigned long long seed)
+{
+    std::lock_guard<std::mutex> lk(g_rng_mu);
+    engine().seed(seed);
+}
 float generate_random(const float &low, const float &high)
 {
+    std::lock_guard<std::mutex> lk(g_rng_mu);
     return std::uniform_real_distribution<float>(low, high)(engine());
 }
 tptr<float> randn(std::vector<size_t> dims, int low, int high, bool requires_grad)

@@ -8,8 +8,10 @@
 //     different order).
 // Also covers the ADVICE item on the graph cache: an edge_index edited in place, or replaced by one of the same size, must
 // not hit the cached adjacency.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <valarray>
 #include <vector>
@@ -114,6 +116,129 @@ static float max_abs(const valarray<float> &a)
     return m;
 }
 
+// ---- stage-by-stage diagnosis of a sharded step -------------------------------------------------------------------------------
+// Every rank keeps device snapshots of its stages (graph::ShardTrace: taken on the rank's stream, no host synchronisation, so the
+// run that is checked is the run that is traced).  When a rank's output or input gradient differs from the unsharded layer, the
+// stages are compared IN ORDER with references computed here on the host in the reference's own summation order -- s (host libm
+// powf), norm and both aggregations (descending column, one accumulator) bit for bit, the dense products within 1e-5 -- and the
+// FIRST stage that differs is named per rank: s local, s halo, norm, H local, H halo, out, G halo, dY, dX.
+struct RankStages {
+    vector<int> verts, halo_f, halo_b;            // original id of local row k; NEW ids of the halo columns (forward / transposed shard)
+    valarray<float> s_ext, norm, h_ext, out, g_ext, dy, dx;
+    int64_t lo = 0;
+};
+
+struct HostGraph {
+    vector<vector<int>> out_nb, in_nb;   // ascending, duplicates collapsed, self loops dropped (reference graph.cpp:21-75)
+    vector<float> s, norm;
+};
+
+static HostGraph host_graph(const Problem &p)
+{
+    HostGraph g;
+    g.out_nb.resize(p.n);
+    g.in_nb.resize(p.n);
+    for (size_t i = 0; i < p.e; i++)
+        if (p.src[i] != p.dst[i]) g.out_nb[(size_t)p.src[i]].push_back(p.dst[i]);
+    for (auto &v : g.out_nb) {
+        sort(v.begin(), v.end());
+        v.erase(unique(v.begin(), v.end()), v.end());
+    }
+    for (size_t r = 0; r < p.n; r++)
+        for (int c : g.out_nb[r]) g.in_nb[(size_t)c].push_back((int)r);   // rows visited ascending => ascending
+    g.s.resize(p.n);
+    g.norm.resize(p.n);
+    volatile float expo = -0.5f;
+    for (size_t v = 0; v < p.n; v++) g.s[v] = powf((float)(g.out_nb[v].size() + 1), expo);
+    for (size_t v = 0; v < p.n; v++) {
+        volatile float acc = 0.f;
+        for (size_t k = g.out_nb[v].size(); k-- > 0;) acc = acc + g.s[(size_t)g.out_nb[v][k]];
+        volatile float prod = acc * g.s[v];
+        g.norm[v] = prod;
+    }
+    return g;
+}
+
+static void diagnose(const Problem &p, bool hot_path_only, int world, const vector<RankStages> &st, const Result &ref)
+{
+    const HostGraph g = host_graph(p);
+    // new id -> original vertex, from every rank's row list (new ids are rank-contiguous: lo + k)
+    vector<int> orig_of(p.n, -1);
+    for (int r = 0; r < world; r++)
+        for (size_t k = 0; k < st[r].verts.size(); k++) orig_of[(size_t)st[r].lo + k] = st[r].verts[k];
+    // H = X . W^T on the host in double (the products are tolerance-level), rows on demand
+    auto h_row = [&](int v, size_t f) {
+        double acc = 0.0;
+        for (size_t k = 0; k < p.fin; k++) acc += (double)p.X[(size_t)v * p.fin + k] * (double)p.W[f * p.fin + k];
+        return (float)acc;
+    };
+    for (int r = 0; r < world; r++) {
+        const RankStages &q = st[r];
+        const size_t nl = q.verts.size(), F = p.fout;
+        const char *first = nullptr;
+        char detail[256] = "";
+        auto fail = [&](const char *stage, size_t idx, float got, float want) {
+            if (first) return;
+            first = stage;
+            snprintf(detail, sizeof(detail), "element %zu: %.9g, expected %.9g", idx, got, want);
+        };
+        for (size_t i = 0; i < nl && !first; i++)
+            if (q.s_ext[i] != g.s[(size_t)q.verts[i]]) fail("s local", i, q.s_ext[i], g.s[(size_t)q.verts[i]]);
+        for (size_t k = 0; k < q.halo_f.size() && !first; k++) {
+            const int v = orig_of[(size_t)q.halo_f[k]];
+            if (q.s_ext[nl + k] != g.s[(size_t)v]) fail("s halo", k, q.s_ext[nl + k], g.s[(size_t)v]);
+        }
+        for (size_t i = 0; i < nl && !first; i++)
+            if (q.norm[i] != g.norm[(size_t)q.verts[i]]) fail("norm", i, q.norm[i], g.norm[(size_t)q.verts[i]]);
+        for (size_t i = 0; i < nl && !first; i++)
+            for (size_t f = 0; f < F && !first; f++) {
+                const float want = h_row(q.verts[i], f);
+                if (!(fabsf(q.h_ext[i * F + f] - want) <= 1e-5f * fmaxf(1.f, fabsf(want)))) fail("H local", i * F + f, q.h_ext[i * F + f], want);
+            }
+        for (size_t k = 0; k < q.halo_f.size() && !first; k++) {   // a received row is the owner's row, bit for bit
+            const size_t nid = (size_t)q.halo_f[k];
+            int owner = 0;
+            while (owner + 1 < world && (int64_t)nid >= st[owner + 1].lo) owner++;
+            const size_t row = nid - (size_t)st[owner].lo;
+            for (size_t f = 0; f < F && !first; f++)
+                if (q.h_ext[(nl + k) * F + f] != st[owner].h_ext[row * F + f]) fail("H halo", k * F + f, q.h_ext[(nl + k) * F + f], st[owner].h_ext[row * F + f]);
+        }
+        for (size_t i = 0; i < nl && !first; i++)
+            for (size_t f = 0; f < F && !first; f++) {
+                const float want = ref.out[(size_t)q.verts[i] * F + f];
+                if (!(fabsf(q.out[i * F + f] - want) <= 1e-5f * fmaxf(1.f, fabsf(want)))) fail("out", i * F + f, q.out[i * F + f], want);
+            }
+        for (size_t i = 0; i < nl && !first; i++)
+            for (size_t f = 0; f < F && !first; f++)
+                if (q.g_ext[i * F + f] != p.G[(size_t)q.verts[i] * F + f]) fail("G local", i * F + f, q.g_ext[i * F + f], p.G[(size_t)q.verts[i] * F + f]);
+        for (size_t k = 0; k < q.halo_b.size() && !first; k++) {
+            const int v = orig_of[(size_t)q.halo_b[k]];
+            for (size_t f = 0; f < F && !first; f++)
+                if (q.g_ext[(nl + k) * F + f] != p.G[(size_t)v * F + f]) fail("G halo", k * F + f, q.g_ext[(nl + k) * F + f], p.G[(size_t)v * F + f]);
+        }
+        for (size_t i = 0; i < nl && !first; i++) {   // dY_j = sum over in-neighbours i, DESCENDING, of fl(norm_i * G_i): the reference's order
+            const auto &nb = g.in_nb[(size_t)q.verts[i]];
+            for (size_t f = 0; f < F && !first; f++) {
+                volatile float acc = 0.f;
+                for (size_t k = nb.size(); k-- > 0;) {
+                    volatile float term = p.G[(size_t)nb[k] * F + f] * g.norm[(size_t)nb[k]];
+                    acc = acc + term;
+                }
+                const float want = acc;
+                if (q.dy[i * F + f] != want) fail("dY", i * F + f, q.dy[i * F + f], want);
+            }
+        }
+        for (size_t i = 0; i < nl && !first && hot_path_only; i++)
+            for (size_t f = 0; f < p.fin && !first; f++) {
+                const float want = ref.dx[(size_t)q.verts[i] * p.fin + f];
+                if (!(fabsf(q.dx[i * p.fin + f] - want) <= 1e-5f * fmaxf(1.f, fabsf(want)))) fail("dX", i * p.fin + f, q.dx[i * p.fin + f], want);
+            }
+        if (first) printf("DIAG world %d rank %d: first differing stage = %s (%s)\n", world, r, first, detail);
+        else printf("DIAG world %d rank %d: every traced stage matches its reference%s\n", world, r,
+                    hot_path_only ? "" : " (the BatchNorm stages are not traced)");
+    }
+}
+
 static void run_sharded(const Problem &p, bool hot_path_only, int world, const Result &ref)
 {
     auto comms = dist::Comm::local_group(world);
@@ -121,12 +246,14 @@ static void run_sharded(const Problem &p, bool hot_path_only, int world, const R
     vector<int> covered(p.n, 0);
     vector<float> worst_out((size_t)world, 0.f), worst_dx((size_t)world, 0.f);
     vector<Result> res((size_t)world);
+    vector<RankStages> stages((size_t)world);
     vector<thread> th;
     for (int rank = 0; rank < world; rank++) {
         th.emplace_back([&, rank] {
             try {
                 auto ei = graph::vec_to_edge_list(p.src, p.dst);
                 auto part = make_shared<graph::Partition>(*ei, p.n, comms[rank], 3);
+                part->trace = make_shared<graph::ShardTrace>();
                 auto verts = part->local_vertices();
                 const size_t nl = verts.size();
                 auto *xl = new valarray<float>(nl * p.fin);
@@ -164,6 +291,19 @@ static void run_sharded(const Problem &p, bool hot_path_only, int world, const R
                     res[rank].dgamma = *layer.get_parameter("gammas")->grad();
                     res[rank].dbeta = *layer.get_parameter("betas")->grad();
                 }
+                // the stages of this very run, for the diagnosis
+                RankStages &q = stages[rank];
+                q.verts = verts;
+                q.lo = part->cuts()[(size_t)rank];
+                q.halo_f = part->halo_new_ids(part->fwd);
+                q.halo_b = part->halo_new_ids(part->bwd);
+                q.s_ext = *part->s_ext->data();
+                q.norm = *part->norm->data();
+                q.h_ext = *part->trace->h_ext->data();
+                q.out = *part->trace->out->data();
+                q.g_ext = *part->trace->g_ext->data();
+                q.dy = *part->trace->dy->data();
+                q.dx = dx;
                 // take_rows gathers the same rows on the device
                 auto full = make_shared<tensor<float>>(vector<size_t>{p.n, p.fin}, new valarray<float>(p.X), false);
                 auto mine = part->take_rows(full);
@@ -195,6 +335,7 @@ static void run_sharded(const Problem &p, bool hot_path_only, int world, const R
             if (!(fabsf(a[i] - b[i]) <= tol)) return false;
         return true;
     };
+    const int failures_before = failures;
     for (int r = 0; r < world; r++) {
         if (!(worst_out[r] <= 1e-5f)) printf("world %d rank %d: out off by %.3e\n", world, r, worst_out[r]);
         if (!(worst_dx[r] <= 1e-5f)) printf("world %d rank %d: dx off by %.3e\n", world, r, worst_dx[r]);
@@ -207,6 +348,8 @@ static void run_sharded(const Problem &p, bool hot_path_only, int world, const R
             CHECK(close_norm(res[r].dbeta, ref.dbeta));
         }
     }
+    static const bool always = getenv("GNNCPP_TEST_DIAGNOSE") != nullptr;   // run the stage comparison on a passing run too
+    if (failures != failures_before || always) diagnose(p, hot_path_only, world, stages, ref);
 }
 
 // the static-graph cache of GCNConv::forward must be keyed on content

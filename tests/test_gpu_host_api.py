@@ -163,8 +163,15 @@ def test_sharded_layer_through_the_cpp_api():
     content-keyed graph cache."""
     exe = os.path.join(ROOT, "tests", "cpp", "test_host_sharded_gpu")
     assert os.path.exists(exe), "build it with __graft_entry__.build()"
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and r.stdout.strip().endswith("SHARDED_HOST_OK"), r.stdout[-3000:] + r.stderr[-3000:]
+    # GNNCPP_TEST_DIAGNOSE: the stage-by-stage comparison (s local, s halo, norm, H local, H halo, out, G halo, dY, dX against host
+    # references in the reference's summation order) also runs on a PASSING step, so the diagnosis a failure would print is itself
+    # under test: every rank of every run must report that all traced stages match.  On a failure the binary names, per rank, the
+    # first stage that differs -- in the same run, from device snapshots taken on the rank's stream.
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, GNNCPP_TEST_DIAGNOSE="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("SHARDED_HOST_OK"), r.stdout[-6000:] + r.stderr[-3000:]
+    diag = [ln for ln in r.stdout.splitlines() if ln.startswith("DIAG ")]
+    assert len(diag) == 2 * (2 + 4) + 8, diag   # hot path and full layer at world 2 and 4, the tiny graph at world 8
+    assert all("every traced stage matches" in ln for ln in diag), diag
 
 
 @pytest.mark.parametrize("name", ["karate_l1", "rmat64", "rmat1024", "cora_l2"])
