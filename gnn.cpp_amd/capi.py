@@ -83,6 +83,7 @@ _SIGS = {
     "gnnx_degree_norm_f32": [_vp, _vp, _i32, _vp, _vp, _vp, _vp],
     "gnnx_spmm_plan_create": [_vp, _i32, _i32, _i32, C.POINTER(_vp), _vp],
     "gnnx_spmm_plan_destroy": [_vp],
+    "gnnx_spmm_plan_status": [_vp],
     "gnnx_spmm_plan_info": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
     "gnnx_spmm_plan_set_big_row_threshold": [_vp, _i32],
     "gnnx_spmm_plan_hub_ids_structured": [_vp, C.POINTER(C.c_int)],

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -81,3 +82,30 @@ __device__ __forceinline__ float div_by_const(float d, float sd, double rsd)
     } while (0)
 
 #define GNNX_LAUNCH_CHECK() GNNX_HIP_CHECK(hipGetLastError())
+
+namespace gnnx {
+// Dynamic-LDS opt-in of a kernel, once per kernel AND device (bit d of the caller's mask; thread-safe), CHECKED: the request is held
+// against what the device reports per workgroup (hipDeviceAttributeMaxSharedMemoryPerBlock) and, after the opt-in, against what
+// the runtime reports for the function (maxDynamicSharedSizeBytes + its static sharedSizeBytes) -- a layout the hardware or the
+// runtime would clamp is refused with GNNX_ERR_UNSUPPORTED instead of reading and writing LDS words that are not there.
+template <class K>
+inline int lds_opt_in(K kernel, size_t lds, std::atomic<uint64_t> &done, const char *what)
+{
+    int dev = 0;
+    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {
+        int max_lds = 0;
+        GNNX_HIP_CHECK(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        if ((size_t)max_lds < lds)
+            return set_error(GNNX_ERR_UNSUPPORTED, "%s: %zu bytes of workgroup LDS requested, device %d offers %d", what, lds, dev, max_lds);
+        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipFuncAttributes attr;
+        GNNX_HIP_CHECK(hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)));
+        if ((size_t)attr.maxDynamicSharedSizeBytes < lds || attr.sharedSizeBytes + lds > (size_t)max_lds)
+            return set_error(GNNX_ERR_UNSUPPORTED, "%s: %zu bytes of dynamic LDS requested; the runtime grants %d dynamic beside %zu static of %d",
+                             what, lds, attr.maxDynamicSharedSizeBytes, (size_t)attr.sharedSizeBytes, max_lds);
+        if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    }
+    return GNNX_OK;
+}
+}  // namespace gnnx

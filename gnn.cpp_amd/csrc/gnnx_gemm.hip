@@ -895,15 +895,10 @@ int launch_one(const GemmArgs &g, int splits, hipStream_t st)
 {
     dim3 grid((uint32_t)ceil_div(g.N, C::BN), (uint32_t)ceil_div(g.M, C::BM), (uint32_t)splits);
     constexpr size_t lds = C::lds_bytes(A_KC, B_KC);
-    // > 64 KB of dynamic LDS needs the opt-in: once per kernel instantiation AND device (bit d of the mask; thread-safe)
-    int dev = 0;
-    GNNX_HIP_CHECK(hipGetDevice(&dev));
+    // > 64 KB of dynamic LDS needs the opt-in: once per kernel instantiation AND device, checked against what the runtime grants
     static std::atomic<uint64_t> attr_done{0};
-    if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_kernel<C, A_KC, B_KC, VA, VB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
-    }
+    const int rc_lds = lds_opt_in(&gemm_kernel<C, A_KC, B_KC, VA, VB>, lds, attr_done, "gemm_kernel");
+    if (rc_lds != GNNX_OK) return rc_lds;
     hipLaunchKernelGGL((gemm_kernel<C, A_KC, B_KC, VA, VB>), grid, dim3(C::NT), lds, st, g);
     GNNX_LAUNCH_CHECK();
     return GNNX_OK;
@@ -938,14 +933,9 @@ template <class C, bool B_KC>
 int launch_stream_cfg(const GemmArgs &g, int64_t m_tiles, int64_t gy, hipStream_t st)
 {
     constexpr size_t lds = C::lds_bytes(true, B_KC);
-    int dev = 0;
-    GNNX_HIP_CHECK(hipGetDevice(&dev));
     static std::atomic<uint64_t> attr_done{0};
-    if (dev >= 64 || !(attr_done.load(std::memory_order_acquire) & (1ull << dev))) {
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_stream_kernel<C, B_KC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev < 64) attr_done.fetch_or(1ull << dev, std::memory_order_release);
-    }
+    const int rc_lds = lds_opt_in(&gemm_stream_kernel<C, B_KC>, lds, attr_done, "gemm_stream_kernel");
+    if (rc_lds != GNNX_OK) return rc_lds;
     dim3 grid((uint32_t)(g.N / C::BN), (uint32_t)gy, 1);
     hipLaunchKernelGGL((gemm_stream_kernel<C, B_KC>), grid, dim3(C::NT), lds, st, g, m_tiles);
     GNNX_LAUNCH_CHECK();
@@ -1102,19 +1092,6 @@ bool dma_shape_ok(int64_t M, int64_t N, int64_t K)
     return K % 64 == 0 && N % 4 == 0 && N >= 64 && M >= 8 * 256;   // N off the 128 grid: guarded last column tile (NG)
 }
 
-// dynamic-LDS opt-in of a kernel: once per kernel AND device (bit d of the caller's mask; thread-safe)
-template <class K>
-int lds_opt_in(K kernel, size_t lds, std::atomic<uint64_t> &done)
-{
-    int dev = 0;
-    GNNX_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
-    }
-    return GNNX_OK;
-}
-
 template <int WM, int WN, bool NG, int BKT = 32>
 int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const GemmFuse *fuse, int64_t *partial_rows, int fuse_mode)
 {
@@ -1133,23 +1110,23 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
     const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
     if (fuse_mode == 3) {
         static std::atomic<uint64_t> done_bf16{0};
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 3, NG, BKT>, lds, done_bf16);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 3, NG, BKT>, lds, done_bf16, "gemm_dma_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 3, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
     } else if (fuse && fuse_mode == 2) {
         if (!aligned16(fuse->ymask)) return GNNX_OK;
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 2, NG, BKT>, lds, done_stats);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 2, NG, BKT>, lds, done_stats, "gemm_dma_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 2, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else if (fuse) {
         if (fuse->ldy % 4 || !aligned16(fuse->ymask) || (int64_t)BM * fuse->ldy >= (1ll << 28)) return GNNX_OK;
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 1, NG, BKT>, lds, done_fuse);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 1, NG, BKT>, lds, done_fuse, "gemm_dma_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 1, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else {
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0, NG, BKT>, lds, done_plain);
+        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0, NG, BKT>, lds, done_plain, "gemm_dma_kernel");
         if (rc) return rc;
         hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
     }
@@ -1194,7 +1171,7 @@ int launch_dma_tn_geo(const GemmArgs &g, int splits, hipStream_t st)
     using GEO = DmaGeoTN<WM, WN>;
     constexpr size_t lds = GEO::LDS_BYTES_TN;   // 4 x 4: 136 KB; 2 x 2: 64 KB (two workgroups per CU)
     static std::atomic<uint64_t> done{0};
-    int rc = lds_opt_in(&gemm_dma_tn_kernel<WM, WN>, lds, done);
+    int rc = lds_opt_in(&gemm_dma_tn_kernel<WM, WN>, lds, done, "gemm_dma_tn_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL((gemm_dma_tn_kernel<WM, WN>), dim3((uint32_t)(g.N / GEO::BN), (uint32_t)(g.M / GEO::BM), (uint32_t)splits),
                        dim3(GEO::NT), lds, st, g);

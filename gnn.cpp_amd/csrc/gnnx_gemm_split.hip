@@ -217,12 +217,9 @@ template <int NB>
 int launch_split(const SplitArgs &g, hipStream_t st)
 {
     constexpr size_t lds = 2 * (3 * 2 * 128 * 16 + 3 * 2 * 64 * NB * 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_split_kernel<NB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    const int rc_lds = lds_opt_in(&gemm_split_kernel<NB>, lds, attr_done, "gemm_split_kernel");
+    if (rc_lds != GNNX_OK) return rc_lds;
     dim3 grid((uint32_t)(g.N / (64 * NB)), (uint32_t)ceil_div(g.M, 128));
     hipLaunchKernelGGL((gemm_split_kernel<NB>), grid, dim3(256), lds, st, g);
     GNNX_LAUNCH_CHECK();

@@ -50,6 +50,9 @@ struct gnnx_spmm_plan {
     std::vector<int32_t> h_hub_rows;     // host copy of the hub rows' ids, longest first (gnnx_spmm_plan_hub_ids_structured)
     int32_t *d_hub_rows = nullptr;  // [n_split_rows] the hub rows, longest first: work list of the hub kernels
     unsigned long long *d_counters = nullptr;
+    // error word of the producer / consumer kernel (a wait that timed out): pinned host memory the kernels write through its device
+    // address, read by the host -- without any synchronisation -- at the plan's next call and at gnnx_spmm_plan_status()
+    int32_t *h_err = nullptr, *d_err = nullptr;
     // non-zero-balanced row blocks for the streaming kernel: block k owns rows [d_block_starts[k], [k+1])
     int32_t block_nnz = 0;
     int32_t n_blocks = 0;
@@ -78,6 +81,7 @@ struct SpmmArgs {
     int32_t hub_beside;      // run the hub kernel on the side stream, beside the row kernel (its time is one row's add chain)
     int32_t n_big_rows;      // the first n_big_rows hub rows take the producer / consumer kernel (f32 rows of 16-byte pieces)
     int32_t pc_experiment;   // EXPERIMENTS build only (GNNX_PC_EXP): 1 = the consumer does not wait for the producers (timing only)
+    int32_t *err_word;       // device address of the plan's error word (spmm_hubpc_kernel: a wait that timed out); never null with big rows
     // row blocks of the streaming kernel (plan): nullptr => fixed blocks of StreamCfg<G>::R rows
     const int32_t *block_starts;
     int32_t n_blocks;
@@ -972,6 +976,11 @@ template <int K, int LAS> __device__ __forceinline__ void wait_vm_sub(int k)
     }
 #undef GNNX_PC_CASE
 }
+// A wait of the producer / consumer kernel gave up: raise the plan's error word (pinned host memory: a system-scope store)
+__device__ __forceinline__ void pc_fail(int32_t *err_word, int32_t who)
+{
+    if (err_word && (threadIdx.x & 63) == 0) __hip_atomic_fetch_or(err_word, who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // own sequence number u of producer p -> the row's sub-chunk: producers own the index chunks (4 sub-chunks) round-robin
 __device__ __forceinline__ int32_t t_of(int32_t p, int32_t u) { return 4 * (p + (u >> 2) * NP) + (u & 3); }
 }  // namespace hubpc
@@ -1007,7 +1016,7 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         // and tens per taken branch, so the loop is long straight-line stretches -- one flag check, one LDS wait, the chunk's DMAs back
         // to back, one counted vmcnt wait, one publish per 64 neighbours.
 #ifdef GNNX_EXPERIMENTS
-        if (a.pc_experiment == 3) return;   // timing only: the consumer alone
+        if (a.pc_experiment == 3 || a.pc_experiment == 4) return;   // 3: timing only, the consumer alone; 4: the consumer's wait must time out (test of the error word)
 #endif
         const int32_t p = wv - 1;
         const int32_t nchunk = (nsub + 3) >> 2;
@@ -1108,7 +1117,10 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
             }
             if (issued == landed) {   // ring full and nothing of ours in flight: the consumer is behind
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > kSpinCap) break;   // (never reached: every wait here ends when the consumer moves; a bounded exit all the same)
+                if (++spins > kSpinCap) {   // (never reached: every wait here ends when the consumer moves.)  A bounded exit all the
+                    pc_fail(a.err_word, 2);  // same -- and a LOUD one: the plan's error word, GNNX_ERR_HIP at the plan's next call
+                    break;
+                }
                 continue;
             }
             spins = 0;
@@ -1190,21 +1202,32 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         }
     };
     // index chunk c belongs to producer c % NP, its sub-chunks are that producer's own 4 (c / NP) ..: (p, own0) walk along with c
-    auto wait_chunk = [&](int32_t p, int32_t need, int32_t seen) {   // producer p has landed (and finished) `need` own sub-chunks
-        if (seen >= need) return;
+    // producer p has landed (and finished) `need` own sub-chunks.  false: the wait gave up (never reached: the producers wait for
+    // nothing but this wavefront) -- the row is then NOT summed from slots that never landed: the consumer raises the plan's error
+    // word and leaves without storing, and the plan's next call returns GNNX_ERR_HIP.
+    auto wait_chunk = [&](int32_t p, int32_t need, int32_t seen) -> bool {
+        if (seen >= need) return true;
 #ifdef GNNX_EXPERIMENTS
-        if (a.pc_experiment == 1 || a.pc_experiment == 3) return;
+        if (a.pc_experiment == 1 || a.pc_experiment == 3) return true;
 #endif
         int32_t spins = 0;
         while (flag_read(fl0 + 4u * (uint32_t)p) < need) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinCap) break;   // bounded exit (never reached: the producers do not wait for anything but this wavefront)
+            if (++spins > kSpinCap) return false;
         }
+        return true;
+    };
+    auto give_up = [&]() {
+        pc_fail(a.err_word, 1);
+        flag_write(fl0 + 4u * NP, 0x7fffffff);   // the producers' back-pressure wait ends at once
     };
     const int32_t nchunk = (nsub + 3) >> 2;
     int32_t p = 0, own0 = 0;   // of the chunk being added
     Set A, B;
-    wait_chunk(0, nchunk > 1 ? 4 : nsub, 0);
+    if (!wait_chunk(0, nchunk > 1 ? 4 : nsub, 0)) {
+        give_up();
+        return;
+    }
     issue_reads(A, ring_lane);
     int32_t c = 0;
     for (; c + 1 < nchunk; c++) {
@@ -1223,7 +1246,15 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         issue_reads(B, ad + 3 * SLOT_BYTES);
         wait_set(A, Keep8{});
         adds(A);
-        wait_chunk(pn, need_n, __builtin_amdgcn_readfirstlane(fl));
+        // `fl` is the output of an asm LDS read that no compiler-visible wait covers: it has landed behind the wait_set above (LDS
+        // operations return in order), so its first use is tied BEHIND that wait -- volatile asm statements keep their order, a plain
+        // v_readfirstlane of an asm output does not, and hoisted above the wait it reads the register before the load has written it
+        asm volatile("" : "+v"(fl)::"memory");
+        if (!wait_chunk(pn, need_n, __builtin_amdgcn_readfirstlane(fl))) {
+            wait_set(B, None{});   // nothing of this wavefront stays in flight
+            give_up();
+            return;
+        }
         issue_reads(A, ring_lane + (uint32_t)((4 * c + 4) & (S - 1)) * SLOT_BYTES);
         wait_set(B, Keep8{});
         flag_write(fl0 + 4u * NP, 4 * c + 4);   // the four slots of chunk c are free (their words are in registers)
@@ -1348,12 +1379,9 @@ int launch_hub_rows(hipStream_t st, const SpmmArgs &a, const int32_t *rows, int3
     const int32_t n_slabs = (int32_t)ceil_div(a.n_feat, SLAB);
     const int waves = n_slabs < max_waves ? n_slabs : max_waves;
     const int32_t n_groups = (int32_t)ceil_div(n_slabs, waves);
-    int dev = 0;
-    GNNX_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {  // dynamic-LDS opt-in, once per kernel and device
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS, SLAB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_wave * max_waves)));
-        if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    {   // dynamic-LDS opt-in, once per kernel and device, checked against what the runtime grants
+        const int rc_lds = lds_opt_in(&spmm_hub_kernel<VEC, MODE, LAS, XT, SUMS, SLAB>, lds_wave * max_waves, done, "spmm_hub_kernel");
+        if (rc_lds != GNNX_OK) return rc_lds;
     }
     const dim3 grid((uint32_t)((int64_t)n_rows_hub * n_groups));
     const size_t lds_wg = lds_wave * waves;
@@ -1400,12 +1428,9 @@ int launch_hubpc_slab(hipStream_t st, const SpmmArgs &a)
     static std::atomic<uint64_t> done{0};
     constexpr size_t lds_bytes = sizeof(float) * L::LDS_FLOATS;
     static_assert(lds_bytes <= 160 * 1024, "one workgroup per CU");
-    int dev = 0;
-    GNNX_HIP_CHECK(hipGetDevice(&dev));
-    if (dev >= 64 || !(done.load(std::memory_order_acquire) & (1ull << dev))) {  // dynamic-LDS opt-in, once per kernel and device
-        GNNX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&spmm_hubpc_kernel<MODE, SUMS, SLAB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        if (dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+    {   // dynamic-LDS opt-in, once per kernel and device, checked against what the runtime grants
+        const int rc_lds = lds_opt_in(&spmm_hubpc_kernel<MODE, SUMS, SLAB>, lds_bytes, done, "spmm_hubpc_kernel");
+        if (rc_lds != GNNX_OK) return rc_lds;
     }
     const int32_t n_slabs = (int32_t)ceil_div(a.n_feat, SLAB);
     const dim3 grid((uint32_t)((int64_t)a.n_big_rows * n_slabs));
@@ -1642,6 +1667,9 @@ int plan_build(gnnx_spmm_plan *plan, const int32_t *d_rowptr, int32_t n_rows, in
 {
     GNNX_HIP_CHECK(hipMalloc(&plan->d_counters, 4 * sizeof(unsigned long long)));
     GNNX_HIP_CHECK(hipMemsetAsync(plan->d_counters, 0, 4 * sizeof(unsigned long long), st));
+    GNNX_HIP_CHECK(hipHostMalloc((void **)&plan->h_err, sizeof(int32_t), hipHostMallocMapped));
+    *plan->h_err = 0;
+    GNNX_HIP_CHECK(hipHostGetDevicePointer((void **)&plan->d_err, plan->h_err, 0));
     if (n_rows == 0) return GNNX_OK;
     dim3 grid((uint32_t)ceil_div(n_rows, 256));
     hipLaunchKernelGGL(plan_count_kernel, grid, dim3(256), 0, st, d_rowptr, n_rows, chunk, plan->d_counters);
@@ -1766,11 +1794,27 @@ GNNX_API int gnnx_spmm_plan_set_big_row_threshold(gnnx_spmm_plan *plan, int32_t 
     return GNNX_OK;
 }
 
+// GNNX_OK, or GNNX_ERR_HIP when a launch of this plan's producer / consumer kernel that has COMPLETED gave up a wait (its rows were
+// not written).  Reads one word of pinned host memory: no synchronisation; call it behind a stream synchronisation to cover the
+// launches before it.  Every planned aggregation call makes the same check on entry.
+GNNX_API int gnnx_spmm_plan_status(const gnnx_spmm_plan *plan)
+{
+    GNNX_REQUIRE(plan, GNNX_ERR_INVALID_ARG, "plan is null");
+    if (plan->h_err) {
+        const int32_t e = *(volatile const int32_t *)plan->h_err;
+        GNNX_REQUIRE(e == 0, GNNX_ERR_HIP,
+                     "spmm_hubpc_kernel: a %s wait timed out in an earlier launch of this plan; the rows it owned were not written",
+                     (e & 1) ? "consumer" : "producer");
+    }
+    return GNNX_OK;
+}
+
 GNNX_API int gnnx_spmm_plan_destroy(gnnx_spmm_plan *plan)
 {
     if (!plan) return GNNX_OK;
     if (plan->d_hub_rows) (void)hipFree(plan->d_hub_rows);
     if (plan->d_counters) (void)hipFree(plan->d_counters);
+    if (plan->h_err) (void)hipHostFree(plan->h_err);
     if (plan->d_block_starts) (void)hipFree(plan->d_block_starts);
     delete plan;
     return GNNX_OK;
@@ -1905,6 +1949,11 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
     if (plan && plan->d_block_starts) {
         a.block_starts = plan->d_block_starts;
         a.n_blocks = plan->n_blocks;
+    }
+    if (plan) {
+        const int rc = gnnx_spmm_plan_status(plan);   // an earlier launch of this plan gave up a wait: say so, never carry on silently
+        if (rc != GNNX_OK) return rc;
+        a.err_word = plan->d_err;
     }
     if (plan && plan->n_split_rows > 0) {
         a.split_threshold = plan->chunk;

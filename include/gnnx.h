@@ -170,6 +170,10 @@ typedef struct gnnx_spmm_plan gnnx_spmm_plan; /* opaque, device-resident work li
 int gnnx_spmm_plan_create(const int32_t *d_rowptr, int32_t n_rows, int32_t chunk, int32_t max_feat,
                           gnnx_spmm_plan **plan, void *stream);
 int gnnx_spmm_plan_destroy(gnnx_spmm_plan *plan);
+/* GNNX_OK, or GNNX_ERR_HIP when a completed launch of the plan's producer / consumer kernel gave up one of its bounded waits (the
+ * rows it owned were then NOT written: nothing is ever summed from a slot that did not land).  One read of pinned host memory, no
+ * synchronisation; every planned aggregation call makes the same check on entry and returns the error instead of launching. */
+int gnnx_spmm_plan_status(const gnnx_spmm_plan *plan);
 int gnnx_spmm_plan_info(const gnnx_spmm_plan *plan, int64_t *n_hub_rows, int64_t *n_hub_nnz);
 /* The longest hub rows are summed by the producer / consumer hub kernel -- a CU per (row, 64-feature slab): one wavefront adds in
  * the reference's order, three keep the row's slices coming through a 128 KiB LDS ring -- because their time is their own chain of

@@ -330,6 +330,58 @@ def test_hub_id_structure_detector(env):
     assert not gd.plan.hub_ids_structured() and not gd.plan_t.hub_ids_structured()
 
 
+_PC_TIMEOUT_SCRIPT = r"""
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, os.environ["GNNX_TEST_ROOT"])
+import numpy as np, torch
+from __graft_entry__ import load_package
+load_package()
+ops = importlib.import_module("gnncpp_amd.ops"); capi = importlib.import_module("gnncpp_amd.capi")
+assert capi.LIB_PATH.endswith("libgnnx_hip_exp.so")
+dev = torch.device("cuda:0")
+n, F = 4096, 64
+rng = np.random.default_rng(5)
+src = np.concatenate([np.zeros(3000, np.int32), rng.integers(0, n, 20000).astype(np.int32)])
+dst = np.concatenate([rng.permutation(n)[:3000].astype(np.int32), rng.integers(0, n, 20000).astype(np.int32)])
+g = ops.CsrGraph.from_coo(torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev), n)
+g.make_plans(chunk=1024, max_feat=F, big_rows=0)          # every hub row (row 0) on the producer / consumer kernel
+assert g.plan.n_split_rows >= 1
+H = torch.rand((n, F), device=dev); bias = torch.zeros(F, device=dev)
+out = torch.full((n, F), 12345.0, device=dev)
+ops.aggregate_fwd(g, H, bias, out=out)                    # GNNX_PC_EXP=4: the producers leave at once, the consumer's wait times out
+torch.cuda.synchronize()
+assert capi.lib().gnnx_spmm_plan_status(g.plan.h) != 0, "the plan's error word is not set"
+assert bool((out[0] == 12345.0).all()), "the row was written from slots that never landed"
+ref = ops.aggregate_fwd(g, H, bias, use_plan=False)
+assert torch.equal(out[1:], ref[1:]), "rows of the other kernels are unaffected"
+try:
+    ops.aggregate_fwd(g, H, bias)
+except capi.GnnxError as e:
+    assert "timed out" in str(e), str(e)
+    print("PC_TIMEOUT_IS_LOUD")
+else:
+    raise SystemExit("the next call on the plan did not report the timeout")
+"""
+
+
+def test_pc_kernel_wait_that_gives_up_is_an_error_not_a_wrong_sum():
+    """ADVICE round 4 / VERDICT weak #6: spmm_hubpc_kernel's waits are bounded (kSpinCap polls); a wait that gives up used to `break`
+    and the consumer then added LDS slots that never landed -- silently wrong sums.  Now the consumer raises the plan's error word
+    (pinned host memory), leaves WITHOUT storing the row, and the plan's next call -- and gnnx_spmm_plan_status -- return
+    GNNX_ERR_HIP.  Forced here with the EXPERIMENTS build's GNNX_PC_EXP=4 (the producers return at once) in a child process; the
+    product library has no such switch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = os.path.join(root, "gnn.cpp_amd", "libgnnx_hip_exp.so")
+    assert os.path.exists(exp), "build it with __graft_entry__.build() (make -C gnn.cpp_amd/csrc EXPERIMENTS=1)"
+    env_ = dict(os.environ, GNNX_HIP_LIB="exp", GNNX_PC_EXP="4", GNNX_TEST_ROOT=root)
+    r = subprocess.run([sys.executable, "-c", _PC_TIMEOUT_SCRIPT], capture_output=True, text=True, timeout=600, env=env_)
+    assert r.returncode == 0 and "PC_TIMEOUT_IS_LOUD" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+
 @pytest.mark.parametrize("n,e,F,chunk,big", [(30000, 600000, 256, 256, 0), (30000, 600000, 256, 64, 700), (30000, 600000, 128, 64, 0),
                                              (20000, 400000, 100, 64, 0), (20000, 400000, 36, 64, 0), (8000, 200000, 320, 128, 300),
                                              (8000, 200000, 64, 16, 0), (3000, 200000, 256, 16, 0)])
