@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <valarray>
 #include <vector>
@@ -126,6 +127,7 @@ struct RankStages {
     vector<int> verts, halo_f, halo_b;            // original id of local row k; NEW ids of the halo columns (forward / transposed shard)
     valarray<float> s_ext, norm, h_ext, out, g_ext, dy, dx;
     int64_t lo = 0;
+    int plan_status_fwd = 0, plan_status_bwd = 0;   // gnnx_spmm_plan_status of the shard's plans after the step
 };
 
 struct HostGraph {
@@ -203,11 +205,25 @@ static void diagnose(const Problem &p, bool hot_path_only, int world, const vect
             for (size_t f = 0; f < F && !first; f++)
                 if (q.h_ext[(nl + k) * F + f] != st[owner].h_ext[row * F + f]) fail("H halo", k * F + f, q.h_ext[(nl + k) * F + f], st[owner].h_ext[row * F + f]);
         }
-        for (size_t i = 0; i < nl && !first; i++)
-            for (size_t f = 0; f < F && !first; f++) {
-                const float want = ref.out[(size_t)q.verts[i] * F + f];
-                if (!(fabsf(q.out[i * F + f] - want) <= 1e-5f * fmaxf(1.f, fabsf(want)))) fail("out", i * F + f, q.out[i * F + f], want);
+        if (!first) {   // out: every bad row with its degree and the features that are off (a hub kernel's work item is a row x feature slab)
+            size_t bad_rows = 0;
+            for (size_t i = 0; i < nl; i++) {
+                string feats;
+                size_t nbad = 0;
+                for (size_t f = 0; f < F; f++) {
+                    const float want = ref.out[(size_t)q.verts[i] * F + f];
+                    if (!(fabsf(q.out[i * F + f] - want) <= 1e-5f * fmaxf(1.f, fabsf(want)))) {
+                        if (!nbad) fail("out", i * F + f, q.out[i * F + f], want);
+                        nbad++;
+                        if (feats.size() < 120) feats += to_string(f) + " ";
+                    }
+                }
+                if (nbad && bad_rows++ < 8)
+                    printf("DIAG world %d rank %d: out row %zu (vertex %d, %zu neighbours): %zu of %zu features off: %s\n", world, r, i, q.verts[i],
+                           g.out_nb[(size_t)q.verts[i]].size(), nbad, F, feats.c_str());
             }
+            if (bad_rows) printf("DIAG world %d rank %d: %zu rows of out are off\n", world, r, bad_rows);
+        }
         for (size_t i = 0; i < nl && !first; i++)
             for (size_t f = 0; f < F && !first; f++)
                 if (q.g_ext[i * F + f] != p.G[(size_t)q.verts[i] * F + f]) fail("G local", i * F + f, q.g_ext[i * F + f], p.G[(size_t)q.verts[i] * F + f]);
@@ -233,6 +249,9 @@ static void diagnose(const Problem &p, bool hot_path_only, int world, const vect
                 const float want = ref.dx[(size_t)q.verts[i] * p.fin + f];
                 if (!(fabsf(q.dx[i * p.fin + f] - want) <= 1e-5f * fmaxf(1.f, fabsf(want)))) fail("dX", i * p.fin + f, q.dx[i * p.fin + f], want);
             }
+        if (q.plan_status_fwd || q.plan_status_bwd)
+            printf("DIAG world %d rank %d: aggregation plan status fwd %d bwd %d (a producer / consumer wait gave up)\n", world, r, q.plan_status_fwd,
+                   q.plan_status_bwd);
         if (first) printf("DIAG world %d rank %d: first differing stage = %s (%s)\n", world, r, first, detail);
         else printf("DIAG world %d rank %d: every traced stage matches its reference%s\n", world, r,
                     hot_path_only ? "" : " (the BatchNorm stages are not traced)");
@@ -304,6 +323,8 @@ static void run_sharded(const Problem &p, bool hot_path_only, int world, const R
                 q.g_ext = *part->trace->g_ext->data();
                 q.dy = *part->trace->dy->data();
                 q.dx = dx;
+                q.plan_status_fwd = part->fwd.spmm_plan ? gnnx_spmm_plan_status(part->fwd.spmm_plan) : 0;
+                q.plan_status_bwd = part->bwd.spmm_plan ? gnnx_spmm_plan_status(part->bwd.spmm_plan) : 0;
                 // take_rows gathers the same rows on the device
                 auto full = make_shared<tensor<float>>(vector<size_t>{p.n, p.fin}, new valarray<float>(p.X), false);
                 auto mine = part->take_rows(full);
