@@ -70,7 +70,7 @@ def profiled_traffic(workload, kernel_patterns):
             continue
         if d.get("workload") != workload:
             continue
-        total, names = 0.0, []
+        total, names, l2_hit, l2_miss, l2_per = 0.0, [], 0.0, 0.0, {}
         for pat, required in kernel_patterns:
             hits = [k for k in d.get("kernels", {}) if re.search(pat, k)]
             if len(hits) > 1 or (required and len(hits) != 1):
@@ -78,8 +78,13 @@ def profiled_traffic(workload, kernel_patterns):
             for h in hits:
                 total += d["kernels"][h]["hbm_bytes_corrected"]
                 names.append(h)
+                if d["kernels"][h].get("tcc_hit") is not None:   # L2 hit rate (TCC_HIT_sum / TCC_MISS_sum pass, MI355X_MICROARCH.md section L2)
+                    l2_hit += d["kernels"][h]["tcc_hit"]
+                    l2_miss += d["kernels"][h]["tcc_miss"]
+                    l2_per[h] = d["kernels"][h].get("l2_hit_rate")
         else:
             best = (total, {"file": os.path.relpath(f, ROOT), "kernels": names, "git_head_of_profiled_build": d.get("git_head"),
+                            "l2_hit_rate": (l2_hit / (l2_hit + l2_miss)) if (l2_hit + l2_miss) > 0 else None, "l2_hit_rate_per_kernel": l2_per or None,
                             "spmm_source_sha256_of_profiled_build": d.get("spmm_source_sha256"),
                             "profiled_nnz": d.get("nnz"), "file_mtime": time.strftime("%Y-%m-%d %H:%M:%S", time.gmtime(os.path.getmtime(f)))})
     return best

@@ -819,9 +819,17 @@ __global__ __launch_bounds__(256) void spmm_hub_kernel(SpmmArgs a, const int32_t
             idx_wait(c);   // lgkmcnt(0): the values below have returned as well (LDS returns in order)
             dma_issue(slot_next, c);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]), "+v"(vv), "+v"(scv)::"memory");
+        // every value read above is an operand of the wait (no use of it may be scheduled in front); vv / scv only in the modes that READ
+        // them -- as an operand a constant 1.0 would be materialised in a register per step for nothing
+#define GNNX_HUB_VWAIT(...)                                                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                             \
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),      \
+                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) __VA_ARGS__::"memory")
+        if constexpr (has_val(MODE) && has_sc(MODE)) GNNX_HUB_VWAIT(, "+v"(vv), "+v"(scv));
+        else if constexpr (has_val(MODE)) GNNX_HUB_VWAIT(, "+v"(vv));
+        else if constexpr (has_sc(MODE)) GNNX_HUB_VWAIT(, "+v"(scv));
+        else GNNX_HUB_VWAIT();
+#undef GNNX_HUB_VWAIT
         if constexpr (sizeof(XT) == 2) {  // a bf16 is the top half of an f32: widening is exact
 #pragma unroll
             for (int j = 0; j < kHubSub; j++) v[j] = __uint_as_float(__float_as_uint(v[j]) << 16);
@@ -1202,32 +1210,30 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         }
     };
     // index chunk c belongs to producer c % NP, its sub-chunks are that producer's own 4 (c / NP) ..: (p, own0) walk along with c
-    // producer p has landed (and finished) `need` own sub-chunks.  false: the wait gave up (never reached: the producers wait for
-    // nothing but this wavefront) -- the row is then NOT summed from slots that never landed: the consumer raises the plan's error
-    // word and leaves without storing, and the plan's next call returns GNNX_ERR_HIP.
-    auto wait_chunk = [&](int32_t p, int32_t need, int32_t seen) -> bool {
-        if (seen >= need) return true;
+    // producer p has landed (and finished) `need` own sub-chunks.  A wait that gives up (never reached: the producers wait for nothing
+    // but this wavefront) sets `dead`: from then on no wait is made, the loop runs out on whatever the ring holds, and the row is NOT
+    // stored -- the consumer raises the plan's error word instead and the plan's next call returns GNNX_ERR_HIP.  (`dead` is a sticky
+    // scalar rather than an early return: an exit inside the loop changed the register allocation of the in-flight read sets, and
+    // the compiler copied them before their waits -- scripts/check_lds_asm_discipline.py checks the built kernel for exactly that.)
+    int32_t dead = 0;
+    auto wait_chunk = [&](int32_t p, int32_t need, int32_t seen) {
+        if (seen >= need || dead) return;
 #ifdef GNNX_EXPERIMENTS
-        if (a.pc_experiment == 1 || a.pc_experiment == 3) return true;
+        if (a.pc_experiment == 1 || a.pc_experiment == 3) return;
 #endif
         int32_t spins = 0;
         while (flag_read(fl0 + 4u * (uint32_t)p) < need) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > kSpinCap) return false;
+            if (++spins > kSpinCap) {
+                dead = 1;
+                break;
+            }
         }
-        return true;
-    };
-    auto give_up = [&]() {
-        pc_fail(a.err_word, 1);
-        flag_write(fl0 + 4u * NP, 0x7fffffff);   // the producers' back-pressure wait ends at once
     };
     const int32_t nchunk = (nsub + 3) >> 2;
     int32_t p = 0, own0 = 0;   // of the chunk being added
     Set A, B;
-    if (!wait_chunk(0, nchunk > 1 ? 4 : nsub, 0)) {
-        give_up();
-        return;
-    }
+    wait_chunk(0, nchunk > 1 ? 4 : nsub, 0);
     issue_reads(A, ring_lane);
     int32_t c = 0;
     for (; c + 1 < nchunk; c++) {
@@ -1250,11 +1256,7 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
         // operations return in order), so its first use is tied BEHIND that wait -- volatile asm statements keep their order, a plain
         // v_readfirstlane of an asm output does not, and hoisted above the wait it reads the register before the load has written it
         asm volatile("" : "+v"(fl)::"memory");
-        if (!wait_chunk(pn, need_n, __builtin_amdgcn_readfirstlane(fl))) {
-            wait_set(B, None{});   // nothing of this wavefront stays in flight
-            give_up();
-            return;
-        }
+        wait_chunk(pn, need_n, __builtin_amdgcn_readfirstlane(fl));
         issue_reads(A, ring_lane + (uint32_t)((4 * c + 4) & (S - 1)) * SLOT_BYTES);
         wait_set(B, Keep8{});
         flag_write(fl0 + 4u * NP, 4 * c + 4);   // the four slots of chunk c are free (their words are in registers)
@@ -1276,6 +1278,10 @@ __global__ __launch_bounds__(64 * (1 + hubpc::NP)) void spmm_hubpc_kernel(SpmmAr
                 adds_n(A, cnt_last);
             }
         }
+    }
+    if (dead) {   // a wait gave up: the sum is not the row's -- say so, store nothing
+        pc_fail(a.err_word, 1);
+        return;
     }
     if (active) {  // the epilogue of epilogue_store<1>, same op order
         float v = acc;

@@ -4,7 +4,7 @@
 # gpu-marked tests, smoke(), the round's profile set (scripts/profile_all.sh) and the default bench line.  Everything it writes lands
 # under gpurun_out/ (profiles: gpurun_out/profiles_<tag>/ -- copy them into profiles/ afterwards).
 set -euo pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}"
 mkdir -p gpurun_out
 timeout -k 10 1100 python -m pytest tests -x -q -m gpu > gpurun_out/${TAG}_gpu_tests.log 2>&1 || { tail -40 gpurun_out/${TAG}_gpu_tests.log; exit 1; }

@@ -1,11 +1,11 @@
 #!/usr/bin/env bash
 # Round profile set (run ON THE GPU BOX through gpurun, from the repo root):
 #   GIT_HEAD=$(git rev-parse --short HEAD) gpurun -- 'GIT_HEAD='$GIT_HEAD' bash scripts/profile_all.sh r03'
-# For every workload: one `rocprofv3 --kernel-trace --stats` pass and two separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE; never
+# For every workload: one `rocprofv3 --kernel-trace --stats` pass and three separate `--pmc` passes (FETCH_SIZE, WRITE_SIZE, TCC hit / miss; never
 # combined with a trace domain) of the SAME bench command; for the GEMMs one SQ-counter pass of scripts/exp_gemm.py.  Raw output
 # lands under gpurun_out/prof_<tag>_*; scripts/summarize_profile.py turns it into the small files committed under profiles/.
 set -euo pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 OUT="$ROOT/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
@@ -14,10 +14,11 @@ run_set() {  # name, bench args...
   rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_${name}_stats" -- python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings "$@" > "$OUT/prof_${TAG}_${name}_stats.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_fetch" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings "$@" > "$OUT/prof_${TAG}_${name}_fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE -f csv -d "$OUT/prof_${TAG}_${name}_write" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings "$@" > "$OUT/prof_${TAG}_${name}_write.log" 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -f csv -d "$OUT/prof_${TAG}_${name}_tcc" -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings "$@" > "$OUT/prof_${TAG}_${name}_tcc.log" 2>&1
   local nnz
   nnz=$(python3 -c "import json,sys; print([json.loads(l)['config']['nnz'] for l in open(sys.argv[1]) if l.startswith('{')][-1])" "$OUT/prof_${TAG}_${name}_stats.log")
-  (cd "$ROOT" && WORKLOAD="${WL:-rmat10m_100m_f256}" PROFILED_NNZ="$nnz" PROFILE_CMD="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings $*" \
-     python3 scripts/summarize_profile.py "${TAG}_bench_${name}" "$OUT/prof_${TAG}_${name}_stats" "$OUT/prof_${TAG}_${name}_fetch" "$OUT/prof_${TAG}_${name}_write")
+  (cd "$ROOT" && WORKLOAD="${WL:-rmat10m_100m_f256}" PROFILED_NNZ="$nnz" PROFILE_CMD="rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum TCC_MISS_sum (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-order-control --no-cpp-api --no-ceilings $*" \
+     python3 scripts/summarize_profile.py "${TAG}_bench_${name}" "$OUT/prof_${TAG}_${name}_stats" "$OUT/prof_${TAG}_${name}_fetch" "$OUT/prof_${TAG}_${name}_write" "$OUT/prof_${TAG}_${name}_tcc")
   echo "profiled $name"
 }
 WL=rmat10m_100m_f256 run_set rmat10m

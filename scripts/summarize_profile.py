@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 CSV output (gpurun_out/...) into the small summaries committed under profiles/.
 
-    python scripts/summarize_profile.py <tag> <stats_dir> [<fetch_dir> <write_dir>]
+    python scripts/summarize_profile.py <tag> <stats_dir> [<fetch_dir> <write_dir> [<tcc_dir>]]
 
 Writes profiles/<tag>_kernel_stats.csv (the --kernel-trace --stats summary, names shortened) and, when the two
 --pmc passes are given, profiles/<tag>_hbm_traffic.json with per-kernel per-launch HBM bytes:
@@ -41,12 +41,12 @@ def one(pattern):
     return f[0]
 
 
-def counters(d, counter):
+def counters(d, counter, scale=1024.0):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(one(os.path.join(d, "*", "*_counter_collection.csv")))):
         if r["Counter_Name"] == counter:
             acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) * 1024.0 for k, v in acc.items()}  # KiB -> bytes, mean per launch
+    return {k: sum(v) / len(v) * scale for k, v in acc.items()}  # (KiB -> bytes,) mean per launch
 
 
 def sq_summary(tag, sq_dir, stats_dir):
@@ -90,12 +90,17 @@ def main():
     print("wrote", out)
     if len(sys.argv) >= 5:
         fetch, write = counters(sys.argv[3], "FETCH_SIZE"), counters(sys.argv[4], "WRITE_SIZE")
+        tcc_hit = counters(sys.argv[5], "TCC_HIT_sum", 1.0) if len(sys.argv) >= 6 else {}
+        tcc_miss = counters(sys.argv[5], "TCC_MISS_sum", 1.0) if len(sys.argv) >= 6 else {}
         res = {}
         for k in sorted(set(fetch) | set(write)):
             if not re.search(r"spmm|gemm_kernel|gemm_stream_kernel|gemm_dma|colsum_stage1|splitk|rows_kernel", k):
                 continue
             fb, wb = fetch.get(k, 0.0), write.get(k, 0.0)
             res[k] = {"fetch_size_bytes_raw": fb, "write_size_bytes": wb, "hbm_bytes_corrected": 2 * fb + wb}
+            if k in tcc_hit or k in tcc_miss:   # L2 (TCC) hit rate of the kernel: requests served by the XCD L2s / all requests
+                h, m = tcc_hit.get(k, 0.0), tcc_miss.get(k, 0.0)
+                res[k].update({"tcc_hit": h, "tcc_miss": m, "l2_hit_rate": h / (h + m) if h + m > 0 else None})
         out = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.json")
         json.dump({"workload": os.environ.get("WORKLOAD", "rmat10m_100m_f256"),
                    # provenance bench.py prints beside `traffic` so that a stale file shows: the commit the profiled build was made
@@ -104,7 +109,8 @@ def main():
                    "nnz": int(os.environ["PROFILED_NNZ"]) if os.environ.get("PROFILED_NNZ") else None,
                    "command": os.environ.get("PROFILE_CMD", "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"),
                    "note": "per launch; hbm_bytes_corrected = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction, "
-                           "MI355X_MICROARCH.md section HBM; calibrate on colsum_stage1 = 4*N*F bytes read once)",
+                           "MI355X_MICROARCH.md section HBM; calibrate on colsum_stage1 = 4*N*F bytes read once); "
+                           "l2_hit_rate = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) from a third pass (MI355X_MICROARCH.md section L2)",
                    "kernels": res}, open(out, "w"), indent=1)
         print("wrote", out)
 
