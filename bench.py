@@ -690,7 +690,8 @@ class SingleGpu:
                                bytes_per_feature=2 if getattr(self, "bf16_features", False) else 4)
         hbm_model_GBps = model["hbm_bytes"] / (ms * 1e-3) / 1e9
         l2 = (tr[1].get("l2_hit_rate") if tr else None)
-        r = {"bound": "fabric behind L2",
+        r = {"bound": "hbm",   # the contract's enum (memory-bound, not MFMA-bound); WHICH part of the memory system binds: next two keys
+             "bound_is": "fabric behind L2",
              "bound_detail": "the memory system behind the XCD L2s (Infinity Cache + HBM) on a whole-row gather -- NOT the HBM pins alone: "
                              "`frac` holds the bytes that left L2 (Infinity-Cache hits included) against the 8 TB/s HBM spec; "
                              "`fractions.hbm_model_vs_hbm_spec` is the HBM-pin estimate",

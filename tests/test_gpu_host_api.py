@@ -219,6 +219,12 @@ def test_bench_contract_single_gpu_and_sharded_rehearsal():
     ro = d["roofline"]
     # the peak is a fixed hardware figure (the HBM spec); the ceilings measured in the same run (bench_kernels/ceilings.hip) ride along
     assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-9
+    # a reader of the roofline object alone can tell fabric-bound from HBM-bound: what binds is named, `frac` says what it is a
+    # fraction of, and the three readings of the launch (traffic behind L2, algorithmic bytes, HBM-side model) sit side by side
+    assert ro["bound_is"] == "fabric behind L2" and "frac_is" in ro and set(ro["fractions"]) == {
+        "traffic_behind_L2_vs_hbm_spec", "algorithmic_vs_hbm_spec", "hbm_model_vs_hbm_spec"}
+    assert 0 < ro["frac_hbm_model"] <= ro["frac_algorithmic_vs_hbm_spec"] + 1e-12 and ro["hbm_model"]["hbm_bytes"] <= ro["algorithmic_bytes_per_launch"]
+    assert abs(ro["fractions"]["hbm_model_vs_hbm_spec"] - ro["frac_hbm_model"]) < 1e-12 and "l2_hit_rate" in ro
     assert ro["peak"] == 8000.0 and 3000.0 < ro["ceilings"]["fabric_gather_GBps"] < 12000.0
     assert abs(ro["frac_algorithmic_vs_hbm_spec"] - ro["effective_GBps"] / 8000.0) < 1e-9 and "traffic_from_committed_profile" in ro
     assert 2500.0 < ro["ceilings"]["hbm_copy_GBps"] < 8000.0 and ro["effective_GBps"] > 0 and ro["avg_launch_ms"] > 0
