@@ -81,6 +81,10 @@ struct SpmmArgs {
     int32_t hub_beside;      // run the hub kernel on the side stream, beside the row kernel (its time is one row's add chain)
     int32_t n_big_rows;      // the first n_big_rows hub rows take the producer / consumer kernel (f32 rows of 16-byte pieces)
     int32_t pc_experiment;   // EXPERIMENTS build only (GNNX_PC_EXP): 1 = the consumer does not wait for the producers (timing only)
+    int32_t exp_policy;      // EXPERIMENTS build only (GNNX_SPMM_POLICY): cache policy of the streaming kernel's one-touch traffic -- 1: colidx / vals
+                             // loads nontemporal, 2: Y stores nontemporal, 4: Y stores sc1 (write-through, the line leaves L2),
+                             // 8: gathers of rows >= exp_hot_k nontemporal (hot-first vertex labels: GNNX_SPMM_HOTK)
+    int32_t exp_hot_k;
     int32_t *err_word;       // device address of the plan's error word (spmm_hubpc_kernel: a wait that timed out); never null with big rows
     // row blocks of the streaming kernel (plan): nullptr => fixed blocks of StreamCfg<G>::R rows
     const int32_t *block_starts;
@@ -308,6 +312,21 @@ __device__ __forceinline__ void epilogue_store_pre(typename Vec<VEC>::type acc, 
     V *dst = reinterpret_cast<V *>(a.Y + (int64_t)row * a.ldy + f0);
     if (a.beta) acc = add_rn(*dst, acc);
     if (a.relu_out) acc = relu_v(acc);
+#ifdef GNNX_EXPERIMENTS
+    if constexpr (VEC == 4) {
+        if (a.exp_policy & 2) {
+            __builtin_nontemporal_store(acc.x, &dst->x); __builtin_nontemporal_store(acc.y, &dst->y);
+            __builtin_nontemporal_store(acc.z, &dst->z); __builtin_nontemporal_store(acc.w, &dst->w);
+            return;
+        }
+        if (a.exp_policy & 4) {
+            typedef float v4f_store __attribute__((ext_vector_type(4)));
+            const v4f_store pk = {acc.x, acc.y, acc.z, acc.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(pk) : "memory");
+            return;
+        }
+    }
+#endif
     *dst = acc;
 }
 
@@ -439,8 +458,14 @@ struct Stream {
         ch.c = a.colidx[q];
         ch.sc = 1.f;
         ch.val = 1.f;
-        if constexpr (has_sc(MODE)) ch.sc = a.colscale[ch.c];
         if constexpr (has_val(MODE)) ch.val = a.vals[q];
+#ifdef GNNX_EXPERIMENTS
+        if (a.exp_policy & 1) {
+            ch.c = __builtin_nontemporal_load(a.colidx + q);
+            if constexpr (has_val(MODE)) ch.val = __builtin_nontemporal_load(a.vals + q);
+        }
+#endif
+        if constexpr (has_sc(MODE)) ch.sc = a.colscale[ch.c];
         return ch;
     }
 
@@ -451,8 +476,30 @@ struct Stream {
         int32_t c[B];
 #pragma unroll
         for (int u = 0; u < B; u++) c[u] = bcast<G>(ch.c, k0 + u, gbase);
+#ifdef GNNX_EXPERIMENTS
+        if constexpr (VEC == 4 && sizeof(XT) == 4) {
+            if (a.exp_policy & 8) {   // cold rows (labels >= exp_hot_k) with the streaming hint: they should not push the hot rows out of L2
 #pragma unroll
-        for (int u = 0; u < B; u++) b.v[u] = ld_x<VEC>(xf + (int64_t)c[u] * a.ldx);
+                for (int u = 0; u < B; u++) {
+                    const float *p = reinterpret_cast<const float *>(xf) + (int64_t)c[u] * a.ldx;
+                    if (c[u] < a.exp_hot_k) {
+                        b.v[u] = ld_x<VEC>(p);
+                    } else {
+                        typedef float v4f_ld __attribute__((ext_vector_type(4)));
+                        const v4f_ld t = __builtin_nontemporal_load(reinterpret_cast<const v4f_ld *>(p));
+                        b.v[u] = make_float4(t.x, t.y, t.z, t.w);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < B; u++) b.v[u] = ld_x<VEC>(xf + (int64_t)c[u] * a.ldx);
+            }
+        } else
+#endif
+        {
+#pragma unroll
+            for (int u = 0; u < B; u++) b.v[u] = ld_x<VEC>(xf + (int64_t)c[u] * a.ldx);
+        }
         if constexpr (has_sc(MODE)) {
 #pragma unroll
             for (int u = 0; u < B; u++) b.sc[u] = __int_as_float(bcast<G>(__float_as_int(ch.sc), k0 + u, gbase));
@@ -928,7 +975,7 @@ namespace hubpc {
 constexpr int NP = 3;                 // producer wavefronts
 constexpr int kSpinCap = 1 << 22;     // polls of an LDS flag before a wait gives up (seconds; a wait lasts microseconds)
 constexpr int kBigSlab = 16;          // features per workgroup
-constexpr int kMaxLdsBytes = 152000;  // the largest workgroup LDS footprint this file uses (validated: 151 584 bytes)
+constexpr int kMaxLdsBytes = 160 * 1024;  // a CU's LDS: what the device reports per workgroup (163 840) -- the launcher checks the request against the runtime's answer (lds_opt_in)
 // SLAB features per workgroup: 16 -- a row of F features is spread over F / 16 CUs.  While the row kernel streams beside it every
 // CU keeps ~128 KiB in flight and the memory system serves them at about the same rate each (~30 GB/s per CU at 8 TB/s over 256
 // CUs), so a row's rate is the number of CUs it sits on: with 64-feature slabs the 62 k-entry row of RMAT 1M / 10M took 0.51 ms
@@ -939,9 +986,14 @@ template <int MODE, int SLAB> struct Cfg {
     static constexpr int LPE = 64 / EPI;                 // lanes per neighbour
     static constexpr int IPS = kHubSub / EPI;            // DMA instructions per sub-chunk of 16 neighbours
     static constexpr int SUBF = kHubSub * SLAB;          // floats per ring slot
-    // ring slots: 128 KiB -- 64 KiB when per-entry values AND column scales ride along (the rare weighted Mode SYM): with the full ring
-    // that layout reaches 156 KiB, and workgroup LDS addresses above ~152 KB misbehaved on the MI355X boxes of this pool (wrong words
-    // from producers 1 and 2, whose index rings sat there; every layout up to 151 584 bytes is exact) -- kMaxLdsBytes keeps all of them below
+    // ring slots: 128 KiB -- 64 KiB when per-entry values AND column scales ride along (the rare weighted Mode SYM; its two extra
+    // small rings would bring the full-ring layout to 156 KiB).  Round 4 saw that 156 KiB layout "read wrong words" and capped every
+    // layout at 152 000 bytes without a cause.  Round 5 looked: the device and the runtime grant the whole 160 KiB to a workgroup, and
+    // plain LDS accesses and LDS-DMA of 4 and 16 bytes per lane hit every address up to 163 840 (bench_kernels/lds_probe.hip); the
+    // very 156 KiB layout, rebuilt from today's source, passes every mode's test and the binary lint -- it was never an addressing
+    // limit.  What is checked now: the dynamic-LDS request against device and runtime at the first launch (lds_opt_in), and the
+    // built kernels against the one hazard that does produce "wrong words" here -- a register of an in-flight LDS read touched before
+    // its wait (scripts/check_lds_asm_discipline.py).
     static constexpr bool kBoth = has_val(MODE) && has_sc(MODE);
     static constexpr int S = (kBoth && SLAB == 16 ? 16384 : 32768) / SUBF;
     static constexpr int LASC = SLAB == 64 ? (kBoth ? 1 : 2) : (kBoth ? 4 : 8);   // index chunks (4 ring slots each) in flight per producer
@@ -955,7 +1007,7 @@ template <int MODE, int SLAB> struct Cfg {
     static constexpr int FL = IR + NP * NI * kHubChunk;                // landed[NP], consumed
     static constexpr int LDS_FLOATS = FL + 8;
     static_assert(SLAB == 64 || SLAB == 16, "slice = 256 or 64 bytes");
-    static_assert(LDS_FLOATS * 4 <= kMaxLdsBytes, "stay inside the validated LDS range");
+    static_assert(LDS_FLOATS * 4 <= kMaxLdsBytes, "one workgroup per CU: the layout must fit a CU's LDS");
     static_assert((S & (S - 1)) == 0 && S >= 4 * (NP * LASC + 2), "ring: a power of two, room for everything in flight plus the chunk being added");
     static_assert(NCX >= LASC + 1 && NI > NCX, "an index chunk has landed when it is read: a chunk issued behind its DMA has landed by then");
     static_assert(LASC * OPS <= 63, "vmcnt is a 6-bit counter");
@@ -1956,6 +2008,12 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         a.block_starts = plan->d_block_starts;
         a.n_blocks = plan->n_blocks;
     }
+#ifdef GNNX_EXPERIMENTS
+    static const int policy_env = [] { const char *e = experiment_env("GNNX_SPMM_POLICY"); return e ? atoi(e) : 0; }();
+    a.exp_policy = policy_env;
+    static const int hotk_env = [] { const char *e = experiment_env("GNNX_SPMM_HOTK"); return e ? atoi(e) : 0; }();
+    a.exp_hot_k = hotk_env;
+#endif
     if (plan) {
         const int rc = gnnx_spmm_plan_status(plan);   // an earlier launch of this plan gave up a wait: say so, never carry on silently
         if (rc != GNNX_OK) return rc;
