@@ -103,11 +103,14 @@ public:
     // false (default): the reference's full layer, transform -> BatchNorm -> ReLU -> aggregation -> bias.
     // true: only the hot path of BASELINE.json (transform -> aggregation -> bias).
     bool hot_path_only = false;
-    // OPT-IN, false by default (the default is the reference's exact two-pass statistics, nn.cpp:303,312): the BatchNorm batch
-    // statistics of the full layer come out of the transform's own epilogue (gnnx_gemm_bn_stats_f32: H is never re-read for
-    // them) -- a single-pass variance finished in double, within rounding of the two-pass one but not bit-equal to it, so the
-    // layer output moves at the 1e-6 level.  Shapes the fused kernel does not cover fall back to the exact pair of calls.
-    bool fuse_bn_stats = false;
+    // true (default since round 5): the BatchNorm batch statistics of the full layer come out of the transform's own epilogue
+    // (gnnx_gemm_bn_stats_f32: H is never re-read for them) -- a shifted single-pass variance finished in double.  Neither this nor
+    // the two-pass reduction is the reference's own summation order (a sequential sum over the nodes, nn.cpp:303,312, which no
+    // parallel sum reproduces); against float64 at 10 M x 256 the two are equally accurate (variance within 3.5e-7 relative vs
+    // 3.9e-7, mean within 7e-7 sigma vs 3.5e-6 sigma: tests/test_gpu_parity.py::test_bn_stats_from_the_transform_vs_float64), and the
+    // layer output differs from the two-pass path's at the 1e-6 level.  Shapes the fused kernel does not cover (small graphs, the
+    // golden cases) take the exact pair of calls either way.  false: always the two-pass statistics.
+    bool fuse_bn_stats = true;
     // the row pitch (floats) the last forward asked the transform's output onto: out_channels, or out_channels + 64 when the graph's hub
     // ids call for the padded gather pitch (gnnx_gather_row_stride; INTEGRATION.md "Vertex order of synthetic graphs")
     size_t gathered_row_pitch = 0;

@@ -601,8 +601,8 @@ static void test_local_comm_destroy_right_after_a_collective()
     CHECK(bad == 0);
 }
 
-// GCNConv::fuse_bn_stats (opt-in): batch statistics from the transform's epilogue instead of the exact two-pass reduction -- the
-// full layer's output and gradients stay inside 1e-5 of the default path's (they are not bit-equal: single-pass variance).
+// GCNConv::fuse_bn_stats (true by default): batch statistics from the transform's epilogue instead of the two-pass reduction -- the
+// full layer's output and gradients stay inside 1e-5 of the two-pass path's (they are not bit-equal: single-pass variance).
 static void test_opt_in_bn_stats_from_the_transform_epilogue()
 {
     const Problem p = make_problem(6000, 60000, 64, 64);   // a shape the LDS-DMA product covers (M >= 2048, K % 64 == 0)

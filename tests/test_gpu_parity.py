@@ -1766,3 +1766,35 @@ def test_layer_step_captured_in_a_hip_graph_same_bits(env):
         for k in bufs:
             assert torch.equal(bufs[k], ref[k]), k
         assert torch.equal(dW, ref_dW) and torch.equal(db, ref_db)
+
+
+@pytest.mark.parametrize("n,offset", [(10_000_000, 0.0), (10_000_000, 3.0), (300_000, 3.0)])
+def test_bn_stats_from_the_transform_vs_float64(env, n, offset):
+    """The full layer's default BatchNorm statistics (GCNConv::fuse_bn_stats: gnnx_gemm_bn_stats_f32, a shifted single-pass variance
+    finished in double, out of the transform's epilogue) held to float64 AT THE BENCH SIZE (10 M x 256), beside the two-pass kernels
+    (gnnx_bn_stats_f32): neither is the reference's own sequential sum (nn.cpp:303,312), so the bar is the exact value -- the mean
+    within 1e-5 of the column's standard deviation, the variance within 1e-6 relative -- and the one-pass form must be no worse than
+    twice the two-pass form's error (+ a rounding floor).  An input offset of 3 sigma is the case a naive single pass would lose."""
+    ops, torch = env["ops"], env["torch"]
+    F = 256
+    X = ops.uniform_pm1(1, (n, F), device=env["dev"]) + offset
+    W = ops.uniform_pm1(2, (F, F), scale=F ** -0.5, device=env["dev"])
+    H, m1, v1 = ops.linear_fwd_bn_stats(X, W)
+    m2, v2 = ops.bn_stats(H)
+    assert torch.equal(H, ops.linear_fwd(X, W)), "the statistics ride along: H itself is the plain product's bits"
+    del X
+    m64 = torch.zeros(F, dtype=torch.float64, device=env["dev"])
+    q64 = torch.zeros(F, dtype=torch.float64, device=env["dev"])
+    step = 1_000_000
+    for r in range(0, n, step):
+        m64 += H[r:r + step].double().sum(0)
+    m64 /= n
+    for r in range(0, n, step):
+        q64 += ((H[r:r + step].double() - m64) ** 2).sum(0)
+    v64 = q64 / n
+    sd = v64.sqrt()
+    em1, em2 = (((m.double() - m64).abs() / sd).max().item() for m in (m1, m2))
+    ev1, ev2 = (((v.double() - v64).abs() / v64).max().item() for v in (v1, v2))
+    assert em1 <= 1e-5 and ev1 <= 1e-6, (em1, ev1)
+    assert em2 <= 1e-5 and ev2 <= 1e-6, (em2, ev2)
+    assert em1 <= 2 * em2 + 2e-7 and ev1 <= 2 * ev2 + 2e-7, (em1, em2, ev1, ev2)
