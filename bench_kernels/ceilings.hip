@@ -6,7 +6,7 @@
 //   ceil_gather_rows  every output row is the sum of `deg` whole 1-KiB rows of a table picked by an index array (uniformly random
 //                     rows): the access pattern of the aggregation (graph.cpp:208 as a CSR gather) with every structural
 //                     difficulty removed -- constant degree, no row pointers, no epilogue, table as small as the caller makes it.
-// `variant` selects the kernel shape (scripts/exp_ceilings.py sweeps them; bench.py uses the fastest, variant 0).
+// `variant` selects the kernel shape (swept in round 3; bench.py uses the fastest, variant 0).
 // Plain C ABI, device pointers, caller's stream; compiled for gfx950 only.
 #include <hip/hip_runtime.h>
 

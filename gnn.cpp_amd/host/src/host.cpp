@@ -1019,7 +1019,7 @@ GCNConv::GCNConv(size_t in_channels, size_t out_channels, float dropout)
 // Same sequence of API calls as the reference layer (graph.cpp:170-191); each lands on the device:
 //   add_self_loops          -> CSR build (dedupe, diagonal stripped), never a dense N x N
 //   lin                     -> MFMA GEMM, W^T as a view
-//   sum(-1,true) + 1, pow   -> degrees from rowptr, correctly rounded rsqrt
+//   sum(-1,true) + 1, pow   -> degrees from rowptr, s = the host libm's powf(deg, -0.5f) from the process-wide table (gnnx_degree_norm_f32)
 //   adj.mm(deg), norm *= deg-> CSR SpMV in the reference's summation order + elementwise
 //   propagate, + bias       -> CSR SpMM, row scale, bias broadcast
 tptr<float> GCNConv::forward(Data &&input)

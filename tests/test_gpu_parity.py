@@ -1154,7 +1154,10 @@ def test_multi_layer_gcn_at_baseline_sizes_vs_oracle(env, n, e, F, L, abc, seed)
         H = ops.linear_fwd(act, dev(env, Ws[l]))
         O = ops.aggregate_fwd(g, H, dev(env, bs[l]))
         xin = host(act)
-        assert_close(host(H), oracle.linear_fwd(xin, Ws[l]), f"layer {l} transform", absum=a64(xin) @ a64(Ws[l]).T)
+        # K = F <= 256: the plain 1e-5 * max(1, |ref|) bar for the transform of O(1) inputs (layer 0).  From layer 1 on the inputs are
+        # aggregated rows -- a hub row's activations reach 1e3-1e4 -- so an element of H is a cancelled sum of terms thousands of times
+        # its size, where no two correct summation orders agree to 1e-5 of the RESULT: there the condition-aware form of the bound.
+        assert_close(host(H), oracle.linear_fwd(xin, Ws[l]), f"layer {l} transform", absum=None if l == 0 else a64(xin) @ a64(Ws[l]).T)
         assert same(host(O), oracle.aggregate_fwd(rp, ci, host(H), norm_g, bs[l])), f"layer {l} aggregation not bit-exact"
         Hs.append(H)
         act = O
