@@ -111,6 +111,8 @@ public:
     // layer output differs from the two-pass path's at the 1e-6 level.  Shapes the fused kernel does not cover (small graphs, the
     // golden cases) take the exact pair of calls either way.  false: always the two-pass statistics.
     bool fuse_bn_stats = true;
+    // how many times forward() (re)built the adjacency / norm / plans from the edge list (the static-graph cache's misses)
+    size_t graph_cache_builds = 0;
     // the row pitch (floats) the last forward asked the transform's output onto: out_channels, or out_channels + 64 when the graph's hub
     // ids call for the padded gather pitch (gnnx_gather_row_stride; INTEGRATION.md "Vertex order of synthetic graphs")
     size_t gathered_row_pitch = 0;

@@ -480,6 +480,13 @@ public:
         _st->host_written();
         return h;
     }
+    // read-only host view: the device copy stays authoritative (no re-upload, no new content version -- a consumer that caches on
+    // (storage id, version), such as GCNConv's static-graph cache, is not invalidated by a READ of the edge list)
+    const std::valarray<T> *cdata()
+    {
+        materialize();
+        return _st->h();
+    }
     // device pointers for the backend (valid contents / to be overwritten)
     T *device_data()
     {
@@ -516,6 +523,7 @@ public:
         materialize();
         T *p = _st->d();
         _st->host_ok = false;
+        _st->version++;   // the content is about to change: whatever was derived from (id, version) is stale
         return p;
     }
     // storage as it is laid out ([rows, cols] of the UNtransposed buffer) + whether this tensor views it transposed

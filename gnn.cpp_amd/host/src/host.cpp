@@ -1037,6 +1037,7 @@ tptr<float> GCNConv::forward(Data &&input)
         const bool hit = _cache_adj && _cache_ei_id == ei->storage_id() && _cache_ei_version == ei->storage_version() &&
                          _cache_nodes == input.num_nodes();
         if (!hit) {
+            graph_cache_builds++;
             auto adj = edge_to_adj_mat(*ei, nullptr, input.num_nodes());
             adj->fill_diagonal_(0);  // == add_self_loops(..., fillValue 0): self loops removed (graph.cpp:172)
             auto deg = adj->sum(-1, true) + 1;

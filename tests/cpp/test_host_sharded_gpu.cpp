@@ -410,6 +410,11 @@ static void test_graph_cache_is_keyed_on_content()
     };
     CHECK(eq(*layer(data)->data(), want1));
     CHECK(eq(*layer(data)->data(), want1));  // second call: cache hit, same result
+    CHECK(layer.graph_cache_builds == 1);
+    // a READ of the edge list (const accessor, element access) does not invalidate: no re-upload, no rebuild
+    CHECK((*ei->cdata())[0] == s1[0] && (*ei)[1] == s1[1]);
+    CHECK(eq(*layer(data)->data(), want1));
+    CHECK(layer.graph_cache_builds == 1);
     // (a) edited in place: same tensor object, same size, new content
     auto *raw = ei->data();
     for (size_t i = 0; i < s2.size(); i++) {
@@ -417,6 +422,15 @@ static void test_graph_cache_is_keyed_on_content()
         (*raw)[s2.size() + i] = d2[i];
     }
     CHECK(eq(*layer(data)->data(), want2));
+    CHECK(layer.graph_cache_builds == 2);
+    // (a') rewritten in place ON THE DEVICE (device_inplace: a kernel updates the list): the version moves, the adjacency is rebuilt
+    {
+        vector<int> both(s1);
+        both.insert(both.end(), d1.begin(), d1.end());
+        detail::gx(gnnx_memcpy_h2d(ei->device_inplace(), both.data(), sizeof(int) * both.size(), detail::current_stream()), "test");
+    }
+    CHECK(eq(*layer(data)->data(), want1));
+    CHECK(layer.graph_cache_builds == 3);
     // (b) a different tensor of the same size (address reuse would look like this to a pointer key)
     auto ei3 = graph::vec_to_edge_list(s1, d1);
     data.set_edge_index(ei3.get());

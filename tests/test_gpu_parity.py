@@ -1801,3 +1801,29 @@ def test_bn_stats_from_the_transform_vs_float64(env, n, offset):
     assert em1 <= 1e-5 and ev1 <= 1e-6, (em1, ev1)
     assert em2 <= 1e-5 and ev2 <= 1e-6, (em2, ev2)
     assert em1 <= 2 * em2 + 2e-7 and ev1 <= 2 * ev2 + 2e-7, (em1, em2, ev1, ev2)
+
+
+def test_pow_is_the_libm_table_for_the_degree_exponent_and_the_device_otherwise(env):
+    """gnnx_pow_f32 (deg->pow(-0.5) of the op-by-op degree block, functional.h:253): exponent -0.5 on a vector of non-negative
+    integers is looked up in the process-wide table of the HOST libm's powf -- the same bits as the fused degree block's s -- and
+    repeated calls reuse the table; any other exponent or argument vector is evaluated on the device (tolerance-level), without the
+    table path's scan and synchronisation."""
+    import ctypes as C
+    ops, torch, capi = env["ops"], env["torch"], env["capi"]
+    src, dst, rp, ci, g = make_graph(env, 20000, 300000, seed=9)
+    deg1 = (g.rowptr[1:] - g.rowptr[:-1] + 1).to(torch.float32)
+    out = torch.empty_like(deg1)
+    for _ in range(2):
+        capi.call("gnnx_pow_f32", ops._ptr(deg1), deg1.numel(), C.c_float(-0.5), ops._ptr(out), ops._stream())
+        assert torch.equal(out, g.s), "pow(deg + 1, -0.5) is not the degree block's s"
+    x = torch.tensor([0.0, -0.0, 1.0, 4.0, 2.5, 1e6], dtype=torch.float32, device=env["dev"])
+    y = torch.empty_like(x)
+    capi.call("gnnx_pow_f32", ops._ptr(x), x.numel(), C.c_float(-0.5), ops._ptr(y), ops._stream())   # 2.5 is no integer: device path
+    ref = np.power(host(x).astype(np.float64), -0.5)
+    got = host(y).astype(np.float64)
+    assert np.isinf(got[0]) and np.isinf(got[1]) and got[0] > 0 and got[1] > 0   # pow(+-0, -0.5) = +inf (C99: only ODD integer exponents keep the sign)
+    assert np.allclose(got[2:], ref[2:], rtol=2e-7, atol=0)
+    z = torch.arange(0, 1000, dtype=torch.float32, device=env["dev"])
+    w = torch.empty_like(z)
+    capi.call("gnnx_pow_f32", ops._ptr(z), z.numel(), C.c_float(2.0), ops._ptr(w), ops._stream())   # another exponent: device pow
+    assert np.allclose(host(w), host(z).astype(np.float64) ** 2, rtol=2e-7)
