@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void fill_kernel(float *x, int64_t n, float v)
 __global__ __launch_bounds__(256) void pow_kernel(const float *x, int64_t n, float e, float *y)
 {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        y[i] = e == -0.5f ? (float)(1.0 / sqrt((double)x[i])) : powf(x[i], e);
+        y[i] = e == -0.5f ? (float)(1.0 / sqrt(x[i] == 0.f ? 0.0 : (double)x[i])) : powf(x[i], e);   // pow(-0, -0.5) = +inf (C99), not 1 / sqrt(-0)
 }
 
 // info[0] = max over i of x[i] as an integer, info[1] = 1 when some x[i] is not a non-negative integer <= kPowTableMax

@@ -20,7 +20,11 @@
  *   - return 0 (GNNX_OK) or a negative gnnx_status; gnnx_last_error() gives the message of the
  *     calling thread's last failure.  The C++ wrapper maps them to std::runtime_error with the
  *     reference's ERROR_* texts (reference include/utils.h:19-30).
- *   - one host thread per device, like the (single-threaded) reference.
+ *   - threads: every entry point may be called from any host thread; a call works on the stream it is given and keeps no state of
+ *     its own between calls beyond what its handles (plans, communicators) own -- one thread drives one handle at a time.  Host
+ *     threads that run ranks of an in-process group each use a stream of their OWN (gnnx_stream_create; the C++ layer does this
+ *     by itself), never the NULL stream; what crosses threads is ordered by the collectives (gnnx_comm.hip) and nothing else
+ *     needs to be.  Process-wide state is immutable once built (the libm table of the degree block, kernel attribute opt-ins).
  */
 #ifndef GNNX_H
 #define GNNX_H
