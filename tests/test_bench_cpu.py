@@ -40,7 +40,7 @@ def test_roofline_traffic_comes_from_the_newest_profile_of_the_same_graph():
         assert tr is not None, wl
         total, src = tr
         assert lo < total < hi, (wl, total)
-        assert src["file"].startswith("profiles/r04_") and len(src["kernels"]) in (2, 3) and src["profiled_nnz"] and src["git_head_of_profiled_build"]
+        assert src["file"].startswith("profiles/r05_") and len(src["kernels"]) in (2, 3) and src["profiled_nnz"] and src["git_head_of_profiled_build"]
         assert any("spmm_hub_kernel" in k for k in src["kernels"]) and any("spmm_stream_kernel" in k for k in src["kernels"])
         # bench.py refuses a profile made with another aggregation source: the committed one must match the tree
         assert src["spmm_source_sha256_of_profiled_build"] == spmm_sha, (wl, "re-run scripts/profile_all.sh: gnnx_spmm.hip changed since the profile")
