@@ -535,9 +535,15 @@ struct GemmFuse {
 // contribute column sums.
 // BK_ = 16: half the K-tile, so that TWO workgroups are resident per CU (4 wavefronts per SIMD as before): the C-store epilogue and
 // the K-tile barriers of one run under the MFMAs of the other.
-template <int WM_, int WN_, int FUSE, bool NG, int BK_ = 32>
+// DEFER (EXPERIMENTS build only; plain products on the 256 x 128 tile, K >= 128): the C tile does not leave through an epilogue.  Eight
+// wavefronts per CU leave every wavefront 256 VGPRs, twice what the tile needs, so the finished accumulators are parked in a second
+// set of 64 registers and stored STRAIGHT from there -- 16 rows x 64 bytes per instruction, one block row in front of each of the next
+// tile's first four K-tiles -- while the matrix pipe works on that tile.  Same bits; measured slower than the LDS-staged epilogue
+// (launch_dma_geo), kept as the record of that experiment.
+template <int WM_, int WN_, int FUSE, bool NG, int BK_ = 32, bool DEFER = false>
 __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_kernel(GemmArgs g, int64_t m_tiles, int ablate, GemmFuse fu)
 {
+    static_assert(!DEFER || (FUSE == 0 && WM_ * WN_ <= 8 && BK_ == 32), "deferred stores: plain product, at most two wavefronts per SIMD");
     (void)ablate;
     using GEO = DmaGeo<WM_, WN_, BK_>;
     constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK, NW = GEO::NW;
@@ -612,6 +618,19 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
     const uint32_t offc = (uint32_t)((wm * 64 + (lane >> 4)) * g.ldc + wn * 64 + 4 * (lane & 15)) * (uint32_t)ES;  // bytes: row L/16, col 4 (L%16)
 
     gemm_f32x4acc acc[4][4];
+    gemm_f32x4acc pend[DEFER ? 4 : 1][DEFER ? 4 : 1];   // DEFER: the previous tile's accumulators (x alpha), on their way out
+    char *pend_tile = nullptr;                          // ... and where they go (nullptr: nothing pending)
+    const uint32_t offd = (uint32_t)((wm * 64 + r16) * g.ldc + wn * 64 + 4 * q) * 4u;   // direct store: row r16, columns 4 q .. of block (i, j)
+    auto flush_row = [&](int i) {   // block row i of the pending tile: 4 stores of 16 rows x 64 bytes
+        if constexpr (DEFER) {
+            if (pend_tile) {
+                char *crow = pend_tile + (int64_t)(16 * i) * g.ldc * 4;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (!NG || wn * 64 + 16 * j + 4 * q + 4 <= n_left) *reinterpret_cast<gemm_f32x4acc *>(crow + offd + 64 * j) = pend[i][j];
+            }
+        }
+    };
     float a[2][4], b[2][4];
     gemm_f32x4acc csum = {0.f, 0.f, 0.f, 0.f};   // FUSE: column sums of this lane's 4 columns over every row it stores
     gemm_f32x4acc csq = {0.f, 0.f, 0.f, 0.f};    // FUSE 2: sums of squares (of the shifted values)
@@ -634,10 +653,18 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
         for (int64_t k0 = 0; k0 < g.K; k0 += 2 * BK) {
             const bool last = k0 + 2 * BK >= g.K;
             if (!GNNX_ABLATE(2)) issue(1, mt, k0 + BK);   // K % 64 == 0: the odd K-tile of this trip always exists
+            if constexpr (DEFER) {   // the pending tile's block rows 0 / 2 (first two trips: K >= 128) leave under this K-tile's MFMAs
+                if (k0 == 0) flush_row(0);
+                else if (k0 == 2 * BK) flush_row(2);
+            }
             if constexpr (BK == 32) { GNNX_DMA2_KTILE(0); } else { GNNX_DMA2_KTILE16(0); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if ((!last || mt_next < m_tiles) && !GNNX_ABLATE(2)) issue(0, last ? mt_next : mt, last ? 0 : k0 + 2 * BK);
+            if constexpr (DEFER) {
+                if (k0 == 0) flush_row(1);
+                else if (k0 == 2 * BK) flush_row(3);
+            }
             if constexpr (BK == 32) { GNNX_DMA2_KTILE(1); } else { GNNX_DMA2_KTILE16(1); }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -655,6 +682,14 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
         }
         const float alpha = g.alpha;
         char *ctile = reinterpret_cast<char *>(g.C) + (mt * BM * g.ldc + n0) * ES;
+        if constexpr (DEFER) {   // park the tile (every block row of the tile before it left during this tile's first four K-tiles)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) pend[i][j] = alpha != 1.0f ? acc[i][j] * alpha : acc[i][j];
+            pend_tile = ctile;
+            continue;
+        }
         if constexpr (FUSE == 0 && !NG) {
             if (GNNX_ABLATE(8)) {   // A/B: straight from the accumulators, 16 rows x 64 B per store instruction, no LDS
                 const uint32_t offd = (uint32_t)((wm * 64 + r16) * g.ldc + wn * 64 + 4 * q) * 4u;
@@ -716,6 +751,12 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
                 }
             }
         }
+    }
+    if constexpr (DEFER) {   // the last tile of this workgroup
+        flush_row(0);
+        flush_row(1);
+        flush_row(2);
+        flush_row(3);
     }
     if constexpr (FUSE == 1 || FUSE == 2) {
         // column sums of the workgroup: lanes with equal (lane & 15) in the WM wavefronts of a column group wn hold the same 4
@@ -1126,9 +1167,28 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
         hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 1, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, *fuse);
         if (partial_rows) *partial_rows = gy;
     } else {
-        int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0, NG, BKT>, lds, done_plain, "gemm_dma_kernel");
-        if (rc) return rc;
-        hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
+        bool defer = false;
+#ifdef GNNX_EXPERIMENTS
+        // A/B only (GNNX_GEMM_DEFER=1): the C tile parked in a second accumulator set and stored straight from registers under the
+        // next tile's K-tiles (gemm_dma_kernel: DEFER).  Measured SLOWER than the LDS-staged epilogue -- 10 M x 128 x 128: X.W^T 3.20
+        // against 3.07 ms, dH.W 2.98 against 2.87 -- 64-byte row segments cost more on the store path than the LDS round trip they
+        // save, even spread over the tile: the product library does not instantiate it.
+        if constexpr (WM * WN <= 8 && BKT == 32) {
+            static const int defer_env = [] { const char *e = experiment_env("GNNX_GEMM_DEFER"); return e ? atoi(e) : 0; }();
+            defer = defer_env != 0 && g.K >= 4 * BK && ablate == 0;
+            if (defer) {
+                static std::atomic<uint64_t> done_defer{0};
+                int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0, NG, BKT, true>, lds, done_defer, "gemm_dma_kernel");
+                if (rc) return rc;
+                hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0, NG, BKT, true>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
+            }
+        }
+#endif
+        if (!defer) {
+            int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 0, NG, BKT>, lds, done_plain, "gemm_dma_kernel");
+            if (rc) return rc;
+            hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 0, NG, BKT>), grid, dim3(GEO::NT), lds, st, g, m_tiles, ablate, GemmFuse{});
+        }
     }
     GNNX_LAUNCH_CHECK();
     *rows_done = m_tiles * BM;
