@@ -46,8 +46,16 @@ struct ThreadRuntime {
     void *get_stream()
     {
         if (!stream_set) {
-            gx(gnnx_stream_create(&stream), "stream");
-            stream_owned = true;
+            // diagnostic switch (tests/cpp/test_host_sharded_gpu: round 4's configuration under round 5's stage-by-stage diagnosis):
+            // every thread on the legacy NULL stream, as all rank threads were before round 5.  Never set in normal use.
+            static const bool shared_null = std::getenv("GNNCPP_SHARED_NULL_STREAM") != nullptr;
+            if (shared_null) {
+                stream = nullptr;
+                stream_owned = false;
+            } else {
+                gx(gnnx_stream_create(&stream), "stream");
+                stream_owned = true;
+            }
             stream_set = true;
         }
         return stream;
