@@ -47,3 +47,30 @@ def test_roofline_traffic_comes_from_the_newest_profile_of_the_same_graph():
     assert bench.profiled_traffic("no_such_workload", pats) is None
     # the algorithmic byte count of SURVEY.md 8(d) for the headline graph
     assert bench.spmm_bytes(10_000_000, 10_000_000, 99_100_605, 256, bias=True) == 112_195_422_968
+
+
+def test_hbm_side_model_bounds_and_limits():
+    """bench.hbm_side_model (the HBM-pin estimate of the roofline line): between the cache-perfect bound (every row once) and the
+    algorithmic count (one row per edge); a graph whose gathered matrix fits the cache is charged one touch per row; rows used once
+    are never resident; a cache of zero bytes gives the algorithmic count."""
+    import importlib.util
+
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod_cpu2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    F, n = 256, 200_000
+    g = torch.Generator().manual_seed(3)
+    deg = torch.distributions.Pareto(torch.tensor(1.0), torch.tensor(1.1)).sample((n,)).to(torch.int64).clamp(max=50_000)
+    nnz = int(deg.sum())
+    streams = 4 * (n + 1) + 4 * nnz + 4 * n + 4 * F * n
+    m = bench.hbm_side_model(deg, nnz, n, F)
+    assert streams + 4 * F * int((deg > 0).sum()) <= m["hbm_bytes"] + 4 * F * n and m["hbm_bytes"] <= streams + 4 * F * nnz
+    # everything fits (n x 1 KiB = 200 MB < 256 MiB, and the one-touch traffic between two uses of a hot row is small): most edges hit
+    assert m["resident_edge_share"] > 0.5 and m["resident_rows"] > 0
+    zero = bench.hbm_side_model(deg, nnz, n, F, cache_bytes=0)
+    assert zero["resident_rows"] == 0 and zero["hbm_bytes"] == streams + 4 * F * nnz
+    once = bench.hbm_side_model(torch.ones(n, dtype=torch.int64), n, n, F)
+    assert once["resident_rows"] == 0 and once["hbm_bytes"] == 4 * (n + 1) + 4 * n + 4 * n + 4 * F * n + 4 * F * n
+    bigger = bench.hbm_side_model(deg, nnz, n, F, cache_bytes=2 * bench.INFINITY_CACHE_BYTES)
+    assert bigger["hbm_bytes"] <= m["hbm_bytes"] and bigger["resident_rows"] >= m["resident_rows"]
