@@ -1206,6 +1206,9 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const Gemm
 #ifdef GNNX_EXPERIMENTS
     static const int geo256 = [] { const char *e = experiment_env("GNNX_GEMM_GEO256"); return e ? atoi(e) : 0; }();
     if (g.N % 256 == 0 && geo256 == 2416) return launch_dma_geo<2, 4, false, 16>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    // A/B: the 256 x 128 tile (8 wavefronts, 128 VGPRs, 98 KB of LDS per CU) for 256-wide outputs too: half of every SIMD's registers
+    // stay free for wavefronts of ANOTHER kernel (an aggregation on a second stream: scripts/exp_concurrent.py)
+    if (g.N % 256 == 0 && geo256 == 42) return launch_dma_geo<4, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
 #endif
     if (g.N % 256 == 0) return launch_dma_geo<4, 4, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
     static const int geo128 = [] { const char *e = experiment_env("GNNX_GEMM_GEO128"); return e ? atoi(e) : 0; }();

@@ -21,7 +21,7 @@ n, e, F = int(os.environ.get("N", 10_000_000)), int(os.environ.get("E", 100_000_
 src, dst = ops.rmat_edges(0, n, e, 0.57, 0.19, 0.19, device=dev)
 g = ops.CsrGraph.from_coo(src, dst, n)
 del src, dst
-g.make_plans(4096, F)
+g.make_plans(int(os.environ.get("CHUNK", 4096)), F)
 X = ops.uniform_pm1(1, (n, F), device=dev)
 W = ops.uniform_pm1(2, (F, F), scale=F ** -0.5, device=dev)
 G = ops.uniform_pm1(3, (n, F), device=dev)
