@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <valarray>
 
 #include "graph.h"
@@ -208,6 +209,34 @@ int main()
         int64_t ld3 = 0;
         h->device_pitched(ld3);
         CHECK(ld3 == (int64_t)F);   // the generic accessors made the storage contiguous
+    });
+    section("threads and streams", [] {
+        // a tensor made by another thread outlives it: its device block was allocated on that thread's stream; read here, released here
+        // (host.cpp: owner-tagged blocks -- a block released by a thread other than its owner goes back to the driver, not into a cache)
+        tptr<float> from_thread;
+        valarray<float> want;
+        std::thread t([&] {
+            auto a = randn(vector<size_t>{300, 64}), b = randn(vector<size_t>{300, 64});
+            from_thread = a + b;                         // computed on the worker's own stream
+            want = *a->data() + *b->data();
+            (void)from_thread->device_data();            // device copy alive, host copy too
+        });
+        t.join();
+        CHECK(all_zero(*from_thread->data() - want));
+        auto again = from_thread + from_thread;          // used on THIS thread's stream
+        CHECK(all_zero(*again->data() - (want + want)));
+        from_thread.reset();                             // released by a thread that does not own the block
+        // an application-supplied stream: same results, and the old (owned) stream is drained and destroyed
+        auto x = randn(vector<size_t>{257, 32}), y = randn(vector<size_t>{257, 32});
+        const valarray<float> before = *(x * y)->data();
+        void *mine = nullptr;
+        CHECK(gnnx_stream_create(&mine) == 0);
+        detail::set_current_stream(mine);
+        CHECK(detail::current_stream() == mine);
+        CHECK(all_zero(*(x * y)->data() - before));
+        detail::set_current_stream(nullptr);             // back to the NULL stream explicitly (an application's choice, never the default)
+        CHECK(all_zero(*(x * y)->data() - before));
+        CHECK(gnnx_stream_sync(mine) == 0 && gnnx_stream_destroy(mine) == 0);
     });
     if (failures == 0) printf("OK\n");
     return failures ? 1 : 0;
