@@ -79,6 +79,86 @@ __global__ __launch_bounds__(256) void colsum_stage1_vec(const float *G, int64_t
     }
 }
 
+// ---- halo pack from the PRODUCER's side: rows -> send slots (+ the column sums of the same pass) ------------------------------
+// The halo pack of the sharded step used to be a gather driven by the send list (slot -> row): every row a peer needs is read once per
+// peer.  Here the rows are walked in order, each read ONCE, and written to every slot that wants it: slots[row][kSlotsPerRow] holds the
+// row's positions in the send buffer (-1: none; a row goes to at most world - 1 <= 7 peers) -- one 32-byte load per row, issued with
+// the row itself, no dependent index chain.  SUM: the pass also produces the column sums of ALL rows, with the partials of
+// colsum_stage1_vec (fixed row ranges, group order): the same bits as gnnx_colsum_f32 -- dbias of the layer and the pack of the
+// upstream gradient in one read of G.
+constexpr int kSlotsPerRow = 8;
+template <int UNROLL, bool SUM>
+__global__ __launch_bounds__(256) void rows_to_slots_vec(const float *X, int64_t ldx, int64_t n_rows, int32_t n_feat, const int32_t *slots,
+                                                         float *send, int64_t lds, int64_t rows_per_range, int ranges_per_block, float *partial)
+{
+    __shared__ float4 red[SUM ? 256 : 1];
+    const int L = n_feat / 4;            // lanes per row (<= 256)
+    const int groups = 256 / L;          // row groups per pass
+    const int li = threadIdx.x % L, grp = threadIdx.x / L;
+    auto scatter = [&](const float4 &w, const int4 &s0, const int4 &s1, int f) {
+        const int sl[kSlotsPerRow] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int t = 0; t < kSlotsPerRow; t++) {
+            if (sl[t] < 0) break;   // slots of a row are packed to the front
+            *reinterpret_cast<float4 *>(send + (int64_t)sl[t] * lds + f) = w;
+        }
+    };
+    for (int v = 0; v < ranges_per_block; v++) {
+        const int64_t range = (int64_t)blockIdx.x * ranges_per_block + v;
+        int64_t r0 = range * rows_per_range;
+        int64_t r1 = r0 + rows_per_range < n_rows ? r0 + rows_per_range : n_rows;
+        for (int f0 = 0; f0 < n_feat; f0 += 4 * L) {  // one iteration unless F > 1024
+            float4 acc[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grp < groups && f0 + 4 * li < n_feat) {
+                const float *base = X + f0 + 4 * li;
+                int64_t r = r0 + grp;
+                for (; r + (int64_t)(UNROLL - 1) * groups < r1; r += (int64_t)UNROLL * groups) {
+                    float4 w[UNROLL];
+                    int4 sa[UNROLL], sb[UNROLL];
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+                        const int64_t row = r + (int64_t)u * groups;
+                        sa[u] = *reinterpret_cast<const int4 *>(slots + row * kSlotsPerRow);
+                        sb[u] = *reinterpret_cast<const int4 *>(slots + row * kSlotsPerRow + 4);
+                        if (SUM || sa[u].x >= 0) w[u] = *reinterpret_cast<const float4 *>(base + row * ldx);   // (without the sums a row nobody wants is not read)
+                    }
+#pragma unroll
+                    for (int u = 0; u < UNROLL; u++) {
+                        if constexpr (SUM) { acc[u].x += w[u].x; acc[u].y += w[u].y; acc[u].z += w[u].z; acc[u].w += w[u].w; }
+                        scatter(w[u], sa[u], sb[u], f0 + 4 * li);
+                    }
+                }
+                for (; r < r1; r += groups) {
+                    const int4 sa = *reinterpret_cast<const int4 *>(slots + r * kSlotsPerRow);
+                    const int4 sb = *reinterpret_cast<const int4 *>(slots + r * kSlotsPerRow + 4);
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (SUM || sa.x >= 0) w = *reinterpret_cast<const float4 *>(base + r * ldx);
+                    if constexpr (SUM) { acc[0].x += w.x; acc[0].y += w.y; acc[0].z += w.z; acc[0].w += w.w; }
+                    scatter(w, sa, sb, f0 + 4 * li);
+                }
+            }
+            if constexpr (SUM) {
+                float4 t = acc[0];
+#pragma unroll
+                for (int u = 1; u < UNROLL; u++) { t.x += acc[u].x; t.y += acc[u].y; t.z += acc[u].z; t.w += acc[u].w; }
+                red[threadIdx.x] = t;
+                __syncthreads();
+                if (grp == 0 && f0 + 4 * li < n_feat) {
+                    float4 s4 = red[li];
+                    for (int k = 1; k < groups; k++) {
+                        float4 o = red[k * L + li];
+                        s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+                    }
+                    *reinterpret_cast<float4 *>(partial + range * n_feat + f0 + 4 * li) = s4;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
 // Scalar form: thread t owns feature columns {t, t+256, ...}
 __global__ __launch_bounds__(256) void colsum_stage1(const float *G, int64_t ldg, int64_t n_rows, int32_t n_feat,
                                                       int64_t rows_per_block, float *partial)
@@ -469,6 +549,38 @@ GNNX_API int gnnx_colsum_copy_f32(const float *d_G, int64_t ldg, int64_t n_rows,
 {
     GNNX_REQUIRE(d_copy, GNNX_ERR_INVALID_ARG, "copy is null");
     return colsum_impl(d_G, ldg, n_rows, n_feat, beta, d_out, d_copy, ldc, d_workspace, workspace_bytes, stream);
+}
+
+GNNX_API int gnnx_rows_to_slots_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const int32_t *d_slots, float *d_send,
+                                    int64_t ld_send, float *d_colsum, float beta, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(n_rows >= 0 && n_feat > 0, GNNX_ERR_INVALID_ARG, "bad sizes");
+    if (n_rows == 0 && !d_colsum) return GNNX_OK;
+    GNNX_REQUIRE((n_rows == 0 || (d_X && d_slots && d_send)) && ldx >= n_feat && ld_send >= n_feat, GNNX_ERR_INVALID_ARG, "null pointer or ld < n_feat");
+    const bool vec = n_feat % 4 == 0 && ldx % 4 == 0 && ld_send % 4 == 0 && aligned16(d_X) && aligned16(d_send) && aligned16(d_slots) &&
+                     n_feat / 4 <= 256 && 256 % (n_feat / 4) == 0;
+    GNNX_REQUIRE(vec, GNNX_ERR_UNSUPPORTED, "rows of 16-byte pieces only (n_feat %% 4 == 0, n_feat / 4 a divisor of 256): use the gather pack");
+    hipStream_t st = as_stream(stream);
+    // the partials are those of gnnx_colsum_f32 (same fixed row ranges, same order): the sums are the same bits
+    const int nb = colsum_blocks(n_rows);
+    const int64_t rpb = ceil_div(n_rows > 0 ? n_rows : 1, nb);
+    if (d_colsum) {
+        const size_t need = sizeof(float) * (size_t)nb * n_feat;
+        GNNX_REQUIRE(d_workspace && workspace_bytes >= need && aligned16(d_workspace), GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+        float *partial = static_cast<float *>(d_workspace);
+        hipLaunchKernelGGL((rows_to_slots_vec<4, true>), dim3(nb), dim3(256), 0, st, d_X, ldx, n_rows, n_feat, d_slots, d_send, ld_send, rpb, 1, partial);
+        GNNX_LAUNCH_CHECK();
+        hipLaunchKernelGGL(colsum_stage2, dim3((uint32_t)ceil_div(n_feat, 64)), dim3(256), 0, st, partial, nb, n_feat, beta, d_colsum);
+        GNNX_LAUNCH_CHECK();
+        return GNNX_OK;
+    }
+    // no sums: nothing depends on the ranges -- many short ranges, eight workgroups per CU keep the stores coming
+    const int64_t rows_per = 256;
+    const int64_t blocks = ceil_div(n_rows, rows_per);
+    hipLaunchKernelGGL((rows_to_slots_vec<4, false>), dim3((uint32_t)blocks), dim3(256), 0, st, d_X, ldx, n_rows, n_feat, d_slots, d_send, ld_send, rows_per, 1,
+                       nullptr);
+    GNNX_LAUNCH_CHECK();
+    return GNNX_OK;
 }
 
 GNNX_API int gnnx_gather_row_stride(int64_t n_rows, int32_t n_feat, int64_t *ld_out)

@@ -346,6 +346,40 @@ def colsum(G, out=None, beta=0.0):
     return out
 
 
+SLOTS_PER_ROW = 8   # gnnx_rows_to_slots_f32: a row goes to at most world - 1 <= 7 peers
+
+
+def slot_table(send_idx, n_rows):
+    """[n_rows, 8] int32 for rows_to_slots: row r's positions in the send buffer (send_idx[slot] == r), ascending, packed to the
+    front, -1 behind.  None when some row has more than 7 slots (a world of more than 8 ranks: use the gather pack)."""
+    dev = send_idx.device
+    table = torch.full((max(int(n_rows), 1), SLOTS_PER_ROW), -1, dtype=torch.int32, device=dev)
+    if int(send_idx.numel()) == 0:
+        return table
+    order = torch.sort(send_idx.to(torch.int64), stable=True).indices        # slots grouped by row, ascending slot inside a row
+    rows = send_idx.to(torch.int64)[order]
+    first = torch.searchsorted(rows, rows, right=False)
+    k = torch.arange(rows.numel(), device=dev) - first                          # rank of the slot among its row's slots
+    if int(k.max()) >= SLOTS_PER_ROW - 1:
+        return None
+    table[rows, k] = order.to(torch.int32)
+    return table
+
+
+def rows_to_slots(X, table, send, colsum_out=None, beta=0.0):
+    """gnnx_rows_to_slots_f32: the halo pack from the producer's side -- every row of X read once and written to each of its send
+    slots (table = slot_table(send_idx, n_rows)); colsum_out: the column sums of all rows of X from the same pass (the bits of
+    colsum())."""
+    N, F = X.shape
+    ws, wsb = None, 0
+    if colsum_out is not None:
+        wsb = capi.colsum_workspace(N, F)
+        ws = _workspace(wsb, X.device, "colsum")
+    capi.call("gnnx_rows_to_slots_f32", _ptr(X), _ld(X), N, F, _ptr(table), _ptr(send), _ld(send), _ptr(colsum_out) if colsum_out is not None else None,
+              float(beta), _ptr(ws) if ws is not None else None, wsb, _stream())
+    return send
+
+
 def gather_row_stride(n_rows, n_feat):
     """gnnx_gather_row_stride: the row pitch (floats) for a matrix whose rows the aggregation gathers (n_feat, or n_feat + 64 for large
     matrices of 512-byte-multiple rows: spreads the hub rows of a synthetic power-law graph over the memory channels)."""

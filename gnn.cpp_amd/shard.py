@@ -165,6 +165,7 @@ class HaloSide:
         self.send_counts_k = None   # [chunk][peer]
         self.send_off = None
         self.send_idx = None        # local row ids to pack, chunk-major then peer-major
+        self.slot_table = None      # [n_local, 8] inverse of send_idx (ops.slot_table), made by a runner that packs from the producer's side
 
     def exchange_requests(self, dist, cuts, rank, world):
         """Tell every owner which of its rows this rank reads; learn which of mine the peers read."""
@@ -264,7 +265,7 @@ class _All:
         return True
 
 
-def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None, async_op=False, chunk=None):
+def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None, async_op=False, chunk=None, scatter=None, prepacked=False):
     """buf: [n_local + n_halo, F]; rows [:n_local] are this rank's; fills rows [n_local:] from the owners.
     pack(src_rows_view, idx, out) gathers rows (gnnx_gather_rows_f32 on GPU).
     native: a NativeComm => the all-to-all-v runs through the C-ABI (gnnx_halo_exchange_f32, RCCL send/recv group)
@@ -273,6 +274,9 @@ def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None, asy
     send buffer must then stay untouched until the wait).
     chunk: None = every row chunk of the plan, one after the other (a plan with one chunk: one all-to-all-v); k = only chunk k
     (HaloSide, n_chunks > 1): the local rows of chunk k must have been written, the others may still be in the making.
+    scatter(src_rows_view, slot_table, out): the pack from the producer's side (gnnx_rows_to_slots_f32: every local row read once and
+    written to each of its slots) -- used instead of `pack` when the side carries a slot table (one chunk); the same send buffer.
+    prepacked: the caller has filled send_buf already (the pack rode in another pass: ShardedBench's dbias + pack of G).
     Returns (send_buf, handle)."""
     n_send = int(side.send_idx.numel())
     if send_buf is None or send_buf.shape[0] < n_send:
@@ -282,8 +286,11 @@ def exchange_rows(dist, side, buf, n_feat, pack, send_buf=None, native=None, asy
         s0, s1 = side.send_off[k], side.send_off[k + 1]
         r0, r1 = side.n_local + side.recv_off[k], side.n_local + side.recv_off[k + 1]
         out = send_buf[s0:s1]
-        if s1 > s0:
-            pack(buf[: side.n_local], side.send_idx[s0:s1], out)
+        if s1 > s0 and not prepacked:
+            if scatter is not None and chunk is None and side.n_chunks == 1 and getattr(side, "slot_table", None) is not None:
+                scatter(buf[: side.n_local], side.slot_table, out)
+            else:
+                pack(buf[: side.n_local], side.send_idx[s0:s1], out)
         recv = buf[r0:r1]
         sc, rc = side.send_counts_k[k], side.recv_counts_k[k]
         if native is not None:
@@ -634,6 +641,14 @@ class ShardedBench:
 
         self.pack = lambda rows, idx, out: ops.gather_rows(rows, idx, out=out)
         p.compute_norm(dist, degree_norm, self.pack)
+        # the per-step packs run from the producer's side (every local row read once, written to each of its send slots); the pack of
+        # the upstream gradient rides in the pass that sums its columns (dbias).  One-chunk layouts of 16-byte row pieces only.
+        self.scatter = None
+        if n_chunks == 1 and F % 4 == 0 and 256 % (F // 4) == 0 and F // 4 <= 256:
+            for side in (p.fwd, p.bwd):
+                side.slot_table = ops.slot_table(side.send_idx, p.n_local)
+            if p.fwd.slot_table is not None and p.bwd.slot_table is not None:
+                self.scatter = lambda rows, table, out: ops.rows_to_slots(rows, table, out)
         t = torch.tensor([p.nnz_local], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
         self.nnz_total = int(t.item())
@@ -683,12 +698,17 @@ class ShardedBench:
                           "allreduce"]
         elif schedule == "sequential":
             self.names = ["gemm_xwT", "halo_fwd", "spmm_fwd", "colsum", "halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW", "allreduce"]
+            if getattr(self, "scatter", None) is not None:
+                self.names[3:5] = ["colsum_pack_halo_bwd"]
         elif schedule == "training":
             self.names = ["gemm_xwT_pack_send_chunks", "wait_halo_fwd", "spmm_fwd", "pack_send_bwd_chunks", "colsum", "wait_halo_bwd", "spmm_bwd",
                           "gemm_dX", "gemm_dW", "allreduce"]
         else:
             self.names = ["pack_send_bwd", "gemm_xwT", "pack_send_fwd", "colsum", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
                           "wait_halo_fwd", "spmm_fwd", "allreduce"]
+            if getattr(self, "scatter", None) is not None:   # dbias and the pack of G in one pass
+                self.names = ["colsum_pack_send_bwd", "gemm_xwT", "pack_send_fwd", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
+                              "wait_halo_fwd", "spmm_fwd", "allreduce"]
         self.ev = []
 
     def _reduce_params(self):
@@ -719,6 +739,14 @@ class ShardedBench:
                                   plan=self.plan_f, n_rows=nl)
         spmm_b = lambda: ops.spmm(p.bwd.rowptr, p.bwd.colidx, self.Gext, out=self.dH, vals=self.norm_nz_bwd,  # noqa: E731
                                   plan=self.plan_b, n_rows=nl)
+        def colsum_pack_exchange_b(async_op=False):
+            # dbias = colsum(G) and the pack of G's rows in ONE pass over G (gnnx_rows_to_slots_f32), then the exchange of the packed rows
+            if int(p.bwd.send_idx.numel()):
+                ops.rows_to_slots(Gl, p.bwd.slot_table, self.send_b, colsum_out=self.dbias)
+            else:
+                ops.colsum(Gl, out=self.dbias)
+            return exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=async_op, prepacked=True)
+
         if self.replicate:
             # one exchange (G, asynchronous); the whole forward chain -- transform of local AND halo rows, aggregation -- under it
             _, hb = run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True))
@@ -760,10 +788,13 @@ class ShardedBench:
             run(self._reduce_params)
         elif self.schedule == "sequential":
             run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
-            run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native))
+            run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, scatter=self.scatter))
             run(spmm_f)
-            run(lambda: ops.colsum(Gl, out=self.dbias))
-            run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native))
+            if self.scatter is not None:
+                run(colsum_pack_exchange_b)
+            else:
+                run(lambda: ops.colsum(Gl, out=self.dbias))
+                run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native))
             run(spmm_b)
             run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
             run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
@@ -772,10 +803,15 @@ class ShardedBench:
             # backward chain's exchange first: it needs no compute in front of it, and the forward chain's GEMM + pack
             # then run under it; the backward chain's SpMM + two GEMMs run under the forward exchange; what is left
             # exposed is one exchange's head and the forward SpMM at the tail.
-            _, hb = run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True))
+            if self.scatter is not None:
+                _, hb = run(lambda: colsum_pack_exchange_b(async_op=True))
+            else:
+                _, hb = run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True))
             run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
-            _, hf = run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, async_op=True))
-            run(lambda: ops.colsum(Gl, out=self.dbias))
+            _, hf = run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, async_op=True,
+                                              scatter=self.scatter))
+            if self.scatter is None:
+                run(lambda: ops.colsum(Gl, out=self.dbias))
             run(hb.wait)
             run(spmm_b)
             run(lambda: ops.gemm(self.dH, self.W, out=self.dX))

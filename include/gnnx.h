@@ -318,6 +318,14 @@ int gnnx_colsum_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes);
  * n_feat, or n_feat + 64 when a row is a multiple of 512 bytes and the matrix is large -- with a power-of-two pitch the hub rows of
  * a synthetic power-law graph (vertex ids with few one-bits) pile onto a few memory channels (forward aggregation of RMAT 10 M /
  * 100 M, F = 256, vertices as generated: 17.8 ms on pitch 256, 13.9 ms on pitch 320; 13.8 ms after relabelling the vertices). */
+/* gnnx_rows_to_slots_f32: the halo pack driven from the PRODUCER's side (the sharded step): d_slots[row][8] lists the
+ * positions of `row` in the send buffer (packed to the front, -1 behind; a row goes to at most world - 1 <= 7 peers); every row is
+ * read once and written to each of its slots: d_send[slot * ld_send + f] = d_X[row * ldx + f] -- the same send buffer the gather
+ * pack (gnnx_gather_rows_f32 by the send list) fills.  d_colsum != NULL: the column sums of ALL rows from the same pass (out[f] =
+ * beta * out[f] + sum_i X[i, f], the bits of gnnx_colsum_f32; workspace gnnx_colsum_workspace() bytes) -- the layer's dbias and the
+ * pack of the upstream gradient in one read.  Rows of 16-byte pieces (n_feat % 4 == 0, n_feat / 4 a divisor of 256). */
+int gnnx_rows_to_slots_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const int32_t *d_slots, float *d_send,
+                           int64_t ld_send, float *d_colsum, float beta, void *d_workspace, size_t workspace_bytes, void *stream);
 int gnnx_gather_row_stride(int64_t n_rows, int32_t n_feat, int64_t *ld_out);
 int gnnx_colsum_copy_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out, float *d_copy,
                          int64_t ldc, void *d_workspace, size_t workspace_bytes, void *stream);

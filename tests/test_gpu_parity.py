@@ -1827,3 +1827,39 @@ def test_pow_is_the_libm_table_for_the_degree_exponent_and_the_device_otherwise(
     w = torch.empty_like(z)
     capi.call("gnnx_pow_f32", ops._ptr(z), z.numel(), C.c_float(2.0), ops._ptr(w), ops._stream())   # another exponent: device pow
     assert np.allclose(host(w), host(z).astype(np.float64) ** 2, rtol=2e-7)
+
+
+@pytest.mark.parametrize("n,F,world", [(50_000, 256, 8), (30_000, 128, 4), (20_000, 64, 8), (5_000, 16, 3), (1_000, 256, 2)])
+def test_pack_from_the_producers_side_equals_the_gather_pack(env, n, F, world):
+    """gnnx_rows_to_slots_f32 (the sharded step's halo pack, driven by the rows instead of the send list): the send buffer equals
+    the gather pack's (gnnx_gather_rows_f32 by the send list) byte for byte -- rows that go to no peer, to one, to all world - 1;
+    with the column sums riding in the pass they are the bits of gnnx_colsum_f32, beta = 1 accumulates; a world of more than 8 ranks
+    (a row with more than 7 slots) gets no table and keeps the gather pack."""
+    ops, torch = env["ops"], env["torch"]
+    gen = torch.Generator(device="cpu").manual_seed(n + F)
+    # peer-major send list: every peer wants a random subset of the rows, ascending inside a peer (what HaloSide delivers)
+    parts = [torch.sort(torch.randperm(n, generator=gen)[: int(n * frac)]).values for frac in torch.rand(world - 1, generator=gen).tolist()]
+    parts[0] = torch.arange(n)   # one peer wants every row: rows with many slots exist
+    send_idx = torch.cat(parts).to(torch.int32).to(env["dev"])
+    X = ops.uniform_pm1(7, (n, F), device=env["dev"])
+    want = ops.gather_rows(X, send_idx)
+    table = ops.slot_table(send_idx, n)
+    assert table is not None and int((table >= 0).sum()) == send_idx.numel()
+    got = torch.full_like(want, float("nan"))
+    ops.rows_to_slots(X, table, got)
+    assert torch.equal(got, want)
+    got2 = torch.full_like(want, float("nan"))
+    sums = torch.empty(F, dtype=torch.float32, device=env["dev"])
+    ops.rows_to_slots(X, table, got2, colsum_out=sums)
+    assert torch.equal(got2, want) and torch.equal(sums, ops.colsum(X))
+    acc = ops.colsum(X)
+    ops.rows_to_slots(X, table, got2, colsum_out=acc, beta=1.0)
+    assert torch.equal(acc, ops.colsum(X, out=ops.colsum(X), beta=1.0))
+    # a strided source (rows at the head of a [local | halo] buffer are contiguous; a column slice is not): ld is honoured
+    Xp = torch.zeros((n, F + 8), dtype=torch.float32, device=env["dev"])
+    Xp[:, :F] = X
+    got3 = torch.empty_like(want)
+    ops.rows_to_slots(Xp[:, :F], table, got3)
+    assert torch.equal(got3, want)
+    too_many = torch.cat([torch.arange(n)] * 8).to(torch.int32).to(env["dev"])
+    assert ops.slot_table(too_many, n) is None
