@@ -531,6 +531,8 @@ int gnnx_halo_plan_info(const gnnx_halo_plan *plan, int64_t *n_local, int64_t *n
                         int64_t *send_rows, const int32_t **d_halo_ids, const int32_t **d_send_idx);
 int gnnx_halo_plan_set_send_list(gnnx_halo_plan *plan, const int32_t *d_want_new_ids, const int64_t *send_rows, void *stream);
 int gnnx_halo_plan_exchange_requests(gnnx_halo_plan *plan, gnnx_comm *comm, void *stream);
+/* (the pack inside gnnx_halo_exchange_rows_f32 runs from the producer's side -- gnnx_rows_to_slots_f32 on the plan's own slot table,
+ * built by gnnx_halo_plan_set_send_list -- whenever the rows are 16-byte pieces; the gather by the send list otherwise: same buffer) */
 int gnnx_halo_exchange_rows_f32(const gnnx_halo_plan *plan, gnnx_comm *comm, float *d_buf, int64_t ldb, int32_t n_feat,
                                 float *d_send_buf, void *stream);
 
