@@ -126,48 +126,59 @@ __global__ void deg_pow_table_kernel(const int32_t *rowptr, int32_t n_rows, cons
 
 // norm_i = fl(fl(sum_{j desc} s_j) * s_i), strictly sequential in the reference's matmul order (descending column)
 // => bit-identical.  N x 1 SpMV, once per graph (not on the per-step path).
-//   short rows: one lane per row;
-//   rows of >= kLongRow non-zeros (power-law hubs, a 100k-degree row would keep one lane busy for tens of ms) are
-//   appended to a list and summed by a whole wavefront each: 64 values are fetched in parallel (the next 64 already in
-//   flight), then added one by one IN ORDER through v_readlane -- same additions, same order, ~50x the load parallelism.
+//   short rows: one lane per row (norm_kernel);
+//   rows of >= kLongRow non-zeros (power-law hubs, a 100k-degree row would keep one lane busy for tens of ms) are summed by a
+//   whole wavefront each (norm_long_kernel): 64 values are fetched in parallel (the next 64 already in flight), then added one by
+//   one IN ORDER through v_readlane -- same additions, same order, ~50x the load parallelism.
+// The two kernels share NOTHING but the degree test: each finds its rows from rowptr by itself (round 4 handed the long rows over in
+// a device-side list with an atomic counter -- a memset, an appending kernel and a consuming kernel chained through a temporary;
+// when that chain broke, on a stream shared by several host threads, the consumer read a count of zero and the hubs' norm was
+// never written: DESIGN.md section 2).
 constexpr int kLongRow = 128;
 
 __global__ void norm_kernel(const int32_t *rowptr, const int32_t *colidx, int32_t n_rows, const float *s_rows,
-                            const float *s_cols, float *norm, int32_t *long_rows, int32_t *long_count)
+                            const float *s_cols, float *norm)
 {
     int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     int32_t b = rowptr[i], e = rowptr[i + 1];
-    if (e - b >= kLongRow) {
-        long_rows[atomicAdd(long_count, 1)] = i;  // list order does not matter: each row is summed independently
-        return;
-    }
+    if (e - b >= kLongRow) return;   // norm_long_kernel's
     float acc = 0.f;
     for (int32_t p = e - 1; p >= b; p--) acc = __fadd_rn(acc, s_cols[colidx[p]]);
     norm[i] = __fmul_rn(acc, s_rows[i]);
 }
 
-__global__ __launch_bounds__(256) void norm_long_kernel(const int32_t *rowptr, const int32_t *colidx, const float *s_rows,
-                                                         const float *s_cols, float *norm, const int32_t *long_rows,
-                                                         const int32_t *long_count)
+__global__ __launch_bounds__(256) void norm_long_kernel(const int32_t *rowptr, const int32_t *colidx, int32_t n_rows, const float *s_rows,
+                                                         const float *s_cols, float *norm)
 {
     const int lane = threadIdx.x & 63;
-    const int32_t n_long = *long_count;
     const int32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
-    for (int32_t k = wave; k < n_long; k += n_waves) {
-        const int32_t row = long_rows[k];
-        const int32_t b = rowptr[row], e = rowptr[row + 1];
-        float acc = 0.f;
-        int32_t q = e - 1 - lane;
-        float v = s_cols[colidx[q >= b ? q : b]];  // unpredicated; out-of-range lanes are never added
-        for (int32_t hi = e; hi > b; hi -= 64) {
-            const int32_t qn = hi - 64 - 1 - lane;  // next chunk, in flight during the serial adds below
-            const float vn = s_cols[colidx[qn >= b ? qn : b]];
-            const int cnt = hi - b < 64 ? hi - b : 64;
-            for (int j = 0; j < cnt; j++) acc = __fadd_rn(acc, __shfl(v, j, 64));
-            v = vn;
+    // a wavefront looks at 64 consecutive rows at a time (one coalesced rowptr read), then sums the long ones among them one by one
+    for (int64_t base = (int64_t)wave * 64; base < n_rows; base += (int64_t)n_waves * 64) {
+        const int64_t r = base + lane;
+        int32_t my_b = 0, my_e = 0;
+        if (r < n_rows) {
+            my_b = rowptr[r];
+            my_e = rowptr[r + 1];
         }
-        if (lane == 0) norm[row] = __fmul_rn(acc, s_rows[row]);
+        uint64_t todo = __ballot(my_e - my_b >= kLongRow);
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int32_t row = (int32_t)(base + src);
+            const int32_t b = __shfl(my_b, src, 64), e = __shfl(my_e, src, 64);
+            float acc = 0.f;
+            int32_t q = e - 1 - lane;
+            float v = s_cols[colidx[q >= b ? q : b]];  // unpredicated; out-of-range lanes are never added
+            for (int32_t hi = e; hi > b; hi -= 64) {
+                const int32_t qn = hi - 64 - 1 - lane;  // next chunk, in flight during the serial adds below
+                const float vn = s_cols[colidx[qn >= b ? qn : b]];
+                const int cnt = hi - b < 64 ? hi - b : 64;
+                for (int j = 0; j < cnt; j++) acc = __fadd_rn(acc, __shfl(v, j, 64));
+                v = vn;
+            }
+            if (lane == 0) norm[row] = __fmul_rn(acc, s_rows[row]);
+        }
     }
 }
 
@@ -596,17 +607,10 @@ GNNX_API int gnnx_degree_norm_f32(const int32_t *d_rowptr, const int32_t *d_coli
         // rows' own s: d_s when written here, else the caller's column-indexed vector is also row-indexed
         const float *s_rows = d_s ? d_s : d_s_cols;
         const float *s_cols = d_s_cols ? d_s_cols : d_s;
-        // scratch for the list of long rows (a once-per-graph build call: plain hipMalloc, freed behind a synchronisation)
-        DeviceFreeSync list_g;
-        GNNX_HIP_CHECK(hipMalloc(&list_g.p, sizeof(int32_t) * ((size_t)n_rows + 1)));
-        int32_t *list = static_cast<int32_t *>(list_g.p);
-        int32_t *count = list + n_rows;
-        GNNX_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), st));
-        hipLaunchKernelGGL(norm_kernel, grid, dim3(T), 0, st, d_rowptr, d_colidx, n_rows, s_rows, s_cols, d_norm, list, count);
+        hipLaunchKernelGGL(norm_kernel, grid, dim3(T), 0, st, d_rowptr, d_colidx, n_rows, s_rows, s_cols, d_norm);
         GNNX_LAUNCH_CHECK();
-        hipLaunchKernelGGL(norm_long_kernel, dim3(1024), dim3(256), 0, st, d_rowptr, d_colidx, s_rows, s_cols, d_norm, list, count);
-        GNNX_LAUNCH_CHECK();
-        GNNX_HIP_CHECK(hipStreamSynchronize(st));   // the list is freed on return
+        hipLaunchKernelGGL(norm_long_kernel, dim3(1024), dim3(256), 0, st, d_rowptr, d_colidx, n_rows, s_rows, s_cols, d_norm);
+        GNNX_LAUNCH_CHECK();   // (no temporary, no count handed from kernel to kernel: stream-asynchronous, nothing to free)
     }
     return GNNX_OK;
 }
