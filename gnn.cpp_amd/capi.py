@@ -106,6 +106,8 @@ _SIGS = {
     "gnnx_colsum_f32": [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp],
     "gnnx_colsum_copy_f32": [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _i64, _vp, _sz, _vp],
     "gnnx_rows_to_slots_f32": [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp, _f32, _vp, _sz, _vp],
+    "gnnx_gemm_nt_rows_to_slots_workspace": [_i64, _i64, _i64, C.POINTER(_sz)],
+    "gnnx_gemm_nt_rows_to_slots_f32": [_i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _sz, _vp],
     "gnnx_gather_row_stride": [_i64, _i32, C.POINTER(_i64)],
     "gnnx_rowscale_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],
     "gnnx_bias_add_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],

@@ -37,6 +37,7 @@ struct GemmArgs {
     float alpha, beta;
     int64_t k_per_split;  // multiple of BK
     float *slab;          // split-K partials [splits][M][N] (nullptr => write C directly)
+    int64_t k_pairs;      // gemm_dma_tn_kernel: K / 64, dealt to the gridDim.z splits as evenly as whole K-tile pairs allow
 };
 
 // Tile configuration: BM x BN output tile, BK K-step, WM x WN wavefronts (each (BM/WM) x (BN/WN), made of 32x32 MFMA tiles).
@@ -511,7 +512,7 @@ __device__ __forceinline__ void dma_16B(uint32_t voff_bytes, const float *sbase,
 }
 
 #ifdef GNNX_EXPERIMENTS
-#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // timing only -- 1: no epilogue, 2: no operand loads after the first, 4: the epilogue's LDS round trip without its stores, 8: stores straight from the accumulators (16 rows x 64 B per instruction)
+#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // timing only -- 1: no epilogue, 2: no operand loads after the first, 4: the epilogue's LDS round trip without its stores, 8: stores straight from the accumulators (16 rows x 64 B per instruction), 16: FUSE 4's list walk without its send stores
 #else
 #define GNNX_ABLATE(bit) false
 #endif
@@ -524,10 +525,16 @@ __device__ __forceinline__ void dma_16B(uint32_t voff_bytes, const float *sbase,
 // pass -- per-lane sums of d = c - shift[n] and d^2 (shift = row 0 of C: a sample value, so the single-pass variance
 // Q/M - (S/M)^2 cancels mildly), reduced per workgroup into [gridDim.y][2][N] partials and finished in double.  C itself is
 // stored unchanged.  Not the reference's two-pass arithmetic (nn.cpp:303,312): tolerance-level, next to the exact gnnx_bn_stats_f32.
+// FUSE == 4 (gnnx_gemm_nt_rows_to_slots_f32, the sharded step's transform): the halo PACK rides in the epilogue.  slots[row][8] lists
+// the send-buffer rows that row `row` of C goes to (-1 padded, packed at the front: gnnx_rows_to_slots_f32's table); every store
+// instruction of the epilogue (4 rows x 256 B, a quarter-wave per row) is repeated for each listed slot of its rows, from the same
+// registers -- the rows never come back from HBM to be packed.  A lane loads ONE dword of its row's eight (lane & 7) in front of the
+// LDS round trip and the quarter-wave shares them through ds_bpermute.  C itself is stored unchanged.
 struct GemmFuse {
     const float *ymask;      // FUSE 1: [M][N] forward output of the layer below (ld ldy), mask = ymask > 0; FUSE 2: shift[N]
-    int64_t ldy;
-    float *colsum_partial;   // FUSE 1: [gridDim.y][N]; FUSE 2: [gridDim.y][2][N]
+    int64_t ldy;             // FUSE 4: ld of `send` (elements)
+    float *colsum_partial;   // FUSE 1: [gridDim.y][N]; FUSE 2: [gridDim.y][2][N]; FUSE 4: the send buffer
+    const int32_t *slots;    // FUSE 4: [M][8]
 };
 
 // NG (N guard): the last column tile is narrower than BN (N % 4 == 0): lanes whose 16 bytes lie past column N neither load B
@@ -578,8 +585,13 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
     const int64_t n_left = g.N - n0;   // columns of this tile that exist
     const bool okb = !NG || 4 * (lane % (64 / GEO::rows_per_instr(BN))) + 4 <= n_left;   // this lane's 4 B columns
     const bool okc = !NG || wn * 64 + 4 * (lane & 15) + 4 <= n_left;                      // this lane's 4 C columns
+    // first row of M-tile mt.  The host may ask for ceil(M / BM) tiles of a plain product: the last one then starts at M - BM and
+    // overlaps its neighbour -- the shared rows are computed twice, to the same bits, and stored twice -- so that no ragged rows are
+    // left for another kernel (M >= BM).  With floor(M / BM) tiles (the column-sum epilogues) the clamp never acts.
+    const int64_t last_row0 = g.M - BM;
+    auto row0_of = [&](int64_t mt) { return mt * BM <= last_row0 ? mt * BM : last_row0; };
     auto issue = [&](int stage, int64_t mt, int64_t k0) {
-        const float *abase = g.A + mt * BM * g.lda + k0;
+        const float *abase = g.A + row0_of(mt) * g.lda + k0;
         const float *bbase = bcol + k0 * g.ldb;
 #pragma unroll
         for (int u = 0; u < (APW > BPW ? APW : BPW); u++) {
@@ -638,6 +650,16 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
     if constexpr (FUSE == 2)
         if (okc) shift4 = *reinterpret_cast<const gemm_f32x4acc *>(fu.ymask + n0 + wn * 64 + 4 * (lane & 15));
     const uint32_t offy = FUSE == 1 ? (uint32_t)((wm * 64 + (lane >> 4)) * fu.ldy + wn * 64 + 4 * (lane & 15)) * 4u : 0u;
+    // FUSE 4: the tile's slot lists (BM rows x 32 B) come into LDS by DMA with the tile's first K-tile -- two buffers behind the
+    // operand stages, alternating per tile: a wavefront that is already in the next tile must not overwrite lists its neighbours
+    // still read (they are at most one barrier apart).  The epilogue must not LOAD from global memory: vmcnt counts loads and stores
+    // in order, so waiting for a load issued behind the stores of the rows before it is waiting for those stores to be acknowledged
+    // (the first version did: + 0.26 ms on a 1.24 ms product).
+    constexpr uint32_t SLOT_BUF = (uint32_t)BM * 32u;
+    const uint32_t slot_lds = lds0 + (uint32_t)GEO::LDS_BYTES;
+    const uint32_t offs = (uint32_t)((wm * 64 + (lane >> 4)) * 8 + (lane & 7)) * 4u;   // bytes into the tile's slot lists
+    char *send_col = FUSE == 4 ? reinterpret_cast<char *>(fu.colsum_partial + n0 + wn * 64 + 4 * (lane & 15)) : nullptr;
+    uint32_t sbuf = 0;
     int64_t mt = blockIdx.y;
     if (mt < m_tiles) issue(0, mt, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -650,6 +672,11 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[i][j][r] = 0.f;
+        if constexpr (FUSE == 4) {   // one 1-KiB wave-instruction per 32 rows; lands before the barrier of the first K-tile
+            sbuf ^= SLOT_BUF;
+            if (wave < BM / 32)
+                dma_16B((uint32_t)lane * 16u, reinterpret_cast<const float *>(fu.slots + row0_of(mt) * 8 + wave * 256), slot_lds + sbuf + (uint32_t)wave * 1024u);
+        }
         for (int64_t k0 = 0; k0 < g.K; k0 += 2 * BK) {
             const bool last = k0 + 2 * BK >= g.K;
             if (!GNNX_ABLATE(2)) issue(1, mt, k0 + BK);   // K % 64 == 0: the odd K-tile of this trip always exists
@@ -681,7 +708,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
             continue;
         }
         const float alpha = g.alpha;
-        char *ctile = reinterpret_cast<char *>(g.C) + (mt * BM * g.ldc + n0) * ES;
+        char *ctile = reinterpret_cast<char *>(g.C) + (row0_of(mt) * g.ldc + n0) * ES;
         if constexpr (DEFER) {   // park the tile (every block row of the tile before it left during this tile's first four K-tiles)
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -702,7 +729,7 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
                 continue;
             }
         }
-        const char *ytile = FUSE == 1 ? reinterpret_cast<const char *>(fu.ymask + mt * BM * fu.ldy + n0) : nullptr;
+        const char *ytile = FUSE == 1 ? reinterpret_cast<const char *>(fu.ymask + row0_of(mt) * fu.ldy + n0) : nullptr;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -719,7 +746,14 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
                 for (int p = 0; p < 4; p++)
                     if (okc) ym[p] = *reinterpret_cast<const gemm_f32x4acc *>(yrow + (int64_t)(4 * p) * fu.ldy * 4 + offy);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            int32_t sl[4] = {-1, -1, -1, -1};
+            if constexpr (FUSE == 4) {   // dword (lane & 7) of the slot list of row 16 i + 4 p + lane / 16, from the tile's lists in LDS
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(sl[p]) : "v"(slot_lds + sbuf + offs), "i"((16 * i + 4 * p) * 32) : "memory");
+            }
+            if constexpr (FUSE == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(sl[0]), "+v"(sl[1]), "+v"(sl[2]), "+v"(sl[3])::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             gemm_f32x4acc o[4];
 #pragma unroll
             for (int p = 0; p < 4; p++) asm volatile("ds_read_b128 %0, %1" : "=v"(o[p]) : "v"(ep_rd + ep[p]) : "memory");
@@ -748,6 +782,23 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
                     if (GNNX_ABLATE(4)) {   // A/B: the LDS round trip without the stores
                         asm volatile("" ::"v"(o[p]));
                     } else if (okc) *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * ES + offc) = o[p];
+                }
+                if constexpr (FUSE == 4) {
+                    // the same 4 rows x 256 B once more per listed slot.  Lists are packed at the front, so the number of rounds the
+                    // wavefront needs is the longest list of its four rows: one ballot, no data-dependent exit
+                    const uint64_t has = __ballot(sl[p] >= 0);
+                    const int rounds = __builtin_popcountll((has | (has >> 16) | (has >> 32) | (has >> 48)) & 0xffull);
+#pragma unroll 1
+                    for (int k = 0; k < rounds; k += 2) {   // two lists entries per trip: the second bpermute is in flight under the first store
+                        const int32_t s0 = __builtin_amdgcn_ds_bpermute(((lane & 48) + k) << 2, sl[p]);
+                        const int32_t s1 = __builtin_amdgcn_ds_bpermute(((lane & 48) + k + 1) << 2, sl[p]);   // k + 1 <= 7
+                        if (GNNX_ABLATE(16)) {   // A/B: the list walk without its stores
+                            asm volatile("" ::"v"(s0), "v"(s1));
+                            continue;
+                        }
+                        if (s0 >= 0 && okc) *reinterpret_cast<gemm_f32x4acc *>(send_col + (int64_t)s0 * fu.ldy * 4) = o[p];
+                        if (s1 >= 0 && okc) *reinterpret_cast<gemm_f32x4acc *>(send_col + (int64_t)s1 * fu.ldy * 4) = o[p];
+                    }
                 }
             }
         }
@@ -1069,8 +1120,10 @@ __global__ __launch_bounds__(64 * WM_ * WN_) void gemm_dma_tn_kernel(GemmArgs g)
     const int wm = wave / GEO::WN, wn = wave % GEO::WN;
     const int q = lane >> 4, r16 = lane & 15;
     const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-    const int64_t kbeg = (int64_t)blockIdx.z * g.k_per_split;
-    const int64_t kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;   // (kend - kbeg) % 64 == 0 (host)
+    // split z takes K-tile pairs [z T / S, (z + 1) T / S): whole pairs, sizes differing by at most one (19 531 pairs on 256 splits
+    // are 76 or 77 each; ceil-sized ranges would leave the last two splits empty)
+    const int64_t kbeg = (int64_t)blockIdx.z * g.k_pairs / gridDim.z * 64;
+    const int64_t kend = ((int64_t)blockIdx.z + 1) * g.k_pairs / gridDim.z * 64;
     const uint32_t lds0 = (uint32_t)(uintptr_t)(gemm_lds_void_t *)lds_raw;
     constexpr uint32_t B0 = 2 * GEO::AT_STAGE_BYTES;
     // DMA: wave-instruction (wave + NW u) covers 1 (256-wide) or 2 (128-wide) k rows; a lane moves 4 consecutive m (n)
@@ -1140,7 +1193,10 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
     constexpr int BM = GEO::BM, BN = GEO::BN, BK = GEO::BK;
     if ((int64_t)BM * g.lda >= (1ll << 28) || (int64_t)BK * g.ldb >= (1ll << 28) || (int64_t)BM * g.ldc >= (1ll << 28))
         return GNNX_OK;  // per-lane BYTE offsets are 32-bit
-    const int64_t m_tiles = g.M / BM, cols = ceil_div(g.N, (int64_t)BN);
+    // plain products (and the send-slot epilogue) cover ragged last rows with one more, overlapping tile (gemm_dma_kernel: row0_of)
+    const bool cover = (!fuse && fuse_mode != 3) || (fuse && fuse_mode == 4);
+    const int64_t m_tiles = cover ? ceil_div(g.M, (int64_t)BM) : g.M / BM, cols = ceil_div(g.N, (int64_t)BN);
+    if (g.M < BM) return GNNX_OK;
     constexpr size_t lds = GEO::LDS_BYTES;   // 4 x 4: 2 x (32 KB + 34 KB) = 132 KB; 4 x 2: 2 x (32 KB + 17 KB) = 98 KB; 2 x 2: 66 KB
     constexpr int wg_per_cu = 160 * 1024 / lds >= 2 ? 2 : 1;   // resident workgroups: as many as the LDS of a CU holds
     static const int wgpcu_env = [] { const char *e = experiment_env("GNNX_GEMM_WGPCU"); return e ? atoi(e) : 0; }();   // A/B: resident workgroups per CU
@@ -1149,7 +1205,17 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
     static std::atomic<uint64_t> done_plain{0}, done_fuse{0}, done_stats{0};
     static const int ablate = [] { const char *e = experiment_env("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     const dim3 grid((uint32_t)cols, (uint32_t)gy, 1);
-    if (fuse_mode == 3) {
+    if (fuse && fuse_mode == 4) {
+        if constexpr (NG || BKT != 32) return GNNX_OK;
+        else {
+            if (fuse->ldy % 4 || !aligned16(fuse->colsum_partial)) return GNNX_OK;
+            static std::atomic<uint64_t> done_send{0};
+            constexpr size_t lds_send = lds + 2 * (size_t)BM * 32;   // + the two slot-list buffers
+            int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 4, false, 32>, lds_send, done_send, "gemm_dma_kernel");
+            if (rc) return rc;
+            hipLaunchKernelGGL((gemm_dma_kernel<WM, WN, 4, false, 32>), grid, dim3(GEO::NT), lds_send, st, g, m_tiles, ablate, *fuse);
+        }
+    } else if (fuse_mode == 3) {
         static std::atomic<uint64_t> done_bf16{0};
         int rc = lds_opt_in(&gemm_dma_kernel<WM, WN, 3, NG, BKT>, lds, done_bf16, "gemm_dma_kernel");
         if (rc) return rc;
@@ -1191,7 +1257,7 @@ int launch_dma_geo(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const 
         }
     }
     GNNX_LAUNCH_CHECK();
-    *rows_done = m_tiles * BM;
+    *rows_done = m_tiles * BM < g.M ? m_tiles * BM : g.M;
     return GNNX_OK;
 }
 
@@ -1210,7 +1276,42 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const Gemm
     // stay free for wavefronts of ANOTHER kernel (an aggregation on a second stream: scripts/exp_concurrent.py)
     if (g.N % 256 == 0 && geo256 == 42) return launch_dma_geo<4, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
 #endif
-    if (g.N % 256 == 0) return launch_dma_geo<4, 4, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    // The last, partly filled round of tiles (1.25 M rows x 256: 4 882 tiles of 256 x 256 on 256 CUs = 19 rounds and 18 tiles that cost
+    // a 20th; 1 M rows x 128: 15 rounds and 66 tiles) goes to a launch of its own on SMALLER tiles, so that it occupies many CUs for a
+    // fraction of a round: 128 x 128 (4 wavefronts) or 256 x 128 (8).  Same MFMA chain per output element in every geometry: same
+    // bits.  Plain products and the send-slot epilogue only (the column-sum epilogues index their partials by workgroup).
+    static const int tail_env = [] { const char *e = experiment_env("GNNX_GEMM_TAIL"); return e ? atoi(e) : 1; }();
+    const bool plain = (!fuse && fuse_mode != 3) || (fuse && fuse_mode == 4);
+    const int64_t mt256 = g.M / 256, r = mt256 % kNumCU;
+    auto with_tail = [&](auto main_geo, auto tail_geo) -> int {   // whole rounds on the main geometry, the rest on the tail's
+        GemmArgs gm = g;
+        gm.M = (mt256 - r) * 256;
+        int64_t rows_main = 0;
+        int rc = main_geo(gm, fuse, &rows_main);
+        *rows_done = rows_main;
+        if (rc || rows_main != gm.M) return rc;
+        GemmArgs gt = g;
+        gt.A += rows_main * g.lda;
+        gt.C += rows_main * g.ldc;
+        gt.M = g.M - rows_main;
+        GemmFuse ft{};
+        if (fuse) {
+            ft = *fuse;
+            ft.slots += rows_main * 8;
+        }
+        int64_t rows_tail = 0;
+        rc = tail_geo(gt, fuse ? &ft : nullptr, &rows_tail);
+        *rows_done = rows_main + rows_tail;
+        return rc;
+    };
+    if (g.N % 256 == 0) {
+        auto g44 = [&](const GemmArgs &a, const GemmFuse *f, int64_t *rows) { return launch_dma_geo<4, 4, false>(a, st, rows, f, partial_rows, fuse_mode); };
+        auto g42 = [&](const GemmArgs &a, const GemmFuse *f, int64_t *rows) { return launch_dma_geo<4, 2, false>(a, st, rows, f, partial_rows, fuse_mode); };
+        auto g22 = [&](const GemmArgs &a, const GemmFuse *f, int64_t *rows) { return launch_dma_geo<2, 2, false>(a, st, rows, f, partial_rows, fuse_mode); };
+        if (tail_env > 0 && plain && g.N == 256 && mt256 > kNumCU && r > 0 && r <= kNumCU / 4) return with_tail(g44, g22);   // a quarter of a round
+        if (tail_env > 0 && plain && g.N == 256 && mt256 > kNumCU && r > 0 && r <= kNumCU / 2) return with_tail(g44, g42);   // half
+        return launch_dma_geo<4, 4, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    }
     static const int geo128 = [] { const char *e = experiment_env("GNNX_GEMM_GEO128"); return e ? atoi(e) : 0; }();
     if (geo128 == 22) {   // A/B: 128 x 128 tiles, two resident workgroups of 4 wavefronts per CU
         if (g.N % 128 == 0) return launch_dma_geo<2, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
@@ -1222,7 +1323,14 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const Gemm
         return launch_dma_geo<4, 2, true, 16>(g, st, rows_done, fuse, partial_rows, fuse_mode);
     }
 #endif
-    if (g.N % 128 == 0) return launch_dma_geo<4, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    if (g.N % 128 == 0) {
+        if (tail_env > 0 && geo128 == 0 && plain && g.N == 128 && mt256 > kNumCU && r > 0 && r <= kNumCU / 2) {   // 128 x 128: half a round
+            auto g42 = [&](const GemmArgs &a, const GemmFuse *f, int64_t *rows) { return launch_dma_geo<4, 2, false>(a, st, rows, f, partial_rows, fuse_mode); };
+            auto g22 = [&](const GemmArgs &a, const GemmFuse *f, int64_t *rows) { return launch_dma_geo<2, 2, false>(a, st, rows, f, partial_rows, fuse_mode); };
+            return with_tail(g42, g22);
+        }
+        return launch_dma_geo<4, 2, false>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    }
     return launch_dma_geo<4, 2, true>(g, st, rows_done, fuse, partial_rows, fuse_mode);
 }
 
@@ -1297,7 +1405,7 @@ GNNX_API int gnnx_gemm_workspace(int transA, int transB, int64_t M, int64_t N, i
     *bytes = 0;
     if (transA && M > 0 && N > 0 && K > 0) {
         int splits = choose_splits(M, N, K);
-        if (splits > 1) *bytes = sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
+        if (splits > 1) *bytes = sizeof(float) * (size_t)(splits + 1) * (size_t)M * (size_t)N;   // + the slab of the last K % 64 rows
     } else if (!transA && transB && dma_shape_ok(M, N, K)) {
         *bytes = sizeof(float) * (size_t)K * (size_t)N;  // W^T as [K][N] for the LDS-DMA kernel
     }
@@ -1444,7 +1552,7 @@ GNNX_API int gnnx_gemm_bn_stats_f32(int64_t M, int64_t N, int64_t K, const float
     GemmArgs g{};
     g.M = M; g.N = N; g.K = K; g.A = d_X; g.lda = ldx; g.B = wt; g.ldb = N; g.C = d_H; g.ldc = ldh; g.alpha = 1.f; g.beta = 0.f;
     g.k_per_split = K;
-    GemmFuse fu{shift, 0, partial};
+    GemmFuse fu{shift, 0, partial, nullptr};
     int64_t rows = 0, prow = 0;
     int rc = launch_dma(g, st, &rows, &fu, &prow, 2);
     if (rc) return rc;
@@ -1533,10 +1641,13 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     const int bk = tile_dims(M, N).bk;
     int64_t ksteps = ceil_div(K > 0 ? K : 1, bk);
     g.k_per_split = ceil_div(ksteps, splits) * bk;
-    if (transA && !transB && splits > 1 && dma_tn_shape_ok(M, N, K))
-        g.k_per_split = ceil_div(ceil_div(K, 64), splits) * 64;  // the LDS-DMA loop takes K-tiles in pairs
+    // dW = dH^T . X over a row count that is no multiple of 64 (a shard's 1.25 M rows): the LDS-DMA kernel takes the whole K-tile
+    // pairs, the generic kernel the last K % 64 rows into one more slab, added last by the in-order reduction
+    const int64_t k_dma = transA && !transB && splits > 1 && dma_tn_shape_ok(M, N, K - K % 64) ? K - K % 64 : 0;
+    if (k_dma > 0) g.k_per_split = ceil_div(k_dma / 64, splits) * 64;  // the LDS-DMA loop takes K-tiles in pairs
+    const int slabs = splits + (k_dma > 0 && k_dma < K ? 1 : 0);
     if (splits > 1) {
-        size_t need = sizeof(float) * (size_t)splits * (size_t)M * (size_t)N;
+        size_t need = sizeof(float) * (size_t)slabs * (size_t)M * (size_t)N;
         GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu",
                      workspace_bytes, need);
         g.slab = static_cast<float *>(d_workspace);
@@ -1576,20 +1687,86 @@ GNNX_API int gnnx_gemm_f32(int transA, int transB, int64_t M, int64_t N, int64_t
     }
     int rc;
     // dW = dH^T . X on the LDS-DMA loop: both operands k-major, whole 256 x 256 tiles, K in whole pairs of K-tiles per split
-    const bool dma_tn = dma_env > 0 && !a_kc && !b_kc && splits > 1 && g.slab && dma_tn_shape_ok(M, N, K) && g.k_per_split % 64 == 0 &&
+    const bool dma_tn = dma_env > 0 && !a_kc && !b_kc && splits > 1 && g.slab && k_dma > 0 && g.k_per_split % 64 == 0 &&
                         lda % 4 == 0 && ldb % 4 == 0 && aligned16(d_A) && aligned16(d_B) && aligned16(g.slab) &&
                         32 * lda < (1ll << 28) && 32 * ldb < (1ll << 28);
-    if (dma_tn) rc = launch_dma_tn(g, splits, st);
-    else if (a_kc && b_kc) rc = launch<true, true>(g, splits, va, vb, st);
+    int reduce_slabs = splits;
+    if (dma_tn) {
+        GemmArgs gk = g;
+        gk.K = k_dma;
+        gk.k_pairs = k_dma / 64;
+        rc = launch_dma_tn(gk, splits, st);
+        if (rc == GNNX_OK && k_dma < K) {   // the last K % 64 rows: one workgroup per output tile, into slab `splits`
+            GemmArgs gr = g;
+            gr.A = d_A + k_dma * lda;
+            gr.B = d_B + k_dma * ldb;
+            gr.K = K - k_dma;
+            gr.k_per_split = ceil_div(gr.K, (int64_t)bk) * bk;
+            gr.slab = g.slab + (size_t)splits * (size_t)M * (size_t)N;
+            rc = launch<false, false>(gr, 1, va, vb, st);
+            reduce_slabs = splits + 1;
+        }
+    } else if (k_dma > 0) {   // the DMA kernel declined (alignment): the generic kernel's own split of all K rows
+        g.k_per_split = ceil_div(ksteps, splits) * bk;
+        rc = launch<false, false>(g, splits, va, vb, st);
+    } else if (a_kc && b_kc) rc = launch<true, true>(g, splits, va, vb, st);
     else if (a_kc && !b_kc) rc = launch<true, false>(g, splits, va, vb, st);
     else if (!a_kc && b_kc) rc = launch<false, true>(g, splits, va, vb, st);
     else rc = launch<false, false>(g, splits, va, vb, st);
     if (rc != GNNX_OK) return rc;
     if (splits > 1) {
         const int64_t blocks = ceil_div(M * N, 32);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, g.slab, splits, M, N, alpha, beta,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((uint32_t)blocks), dim3(256), 0, st, g.slab, reduce_slabs, M, N, alpha, beta,
                            d_C, ldc);
         GNNX_LAUNCH_CHECK();
+    }
+    return GNNX_OK;
+}
+
+// ---- H = X . W^T with the halo pack in the product's epilogue (the sharded step's transform) ---------------------------
+// Every row of H listed in d_slots (gnnx_rows_to_slots_f32's table) is ALSO stored to its send-buffer rows, from the registers the
+// epilogue stores H from: same bits as gnnx_gemm_f32 followed by gnnx_rows_to_slots_f32, without the pass that reads H back.  Rows the
+// LDS-DMA kernel does not take (a ragged tail of < 256 rows, shapes off its grid) go through exactly those two calls.
+GNNX_API int gnnx_gemm_nt_rows_to_slots_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes)
+{
+    GNNX_REQUIRE(bytes && M >= 0 && N >= 0 && K >= 0, GNNX_ERR_INVALID_ARG, "bad arguments");
+    *bytes = sizeof(float) * (size_t)K * (size_t)N + 64;   // W^T [K][N]
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_gemm_nt_rows_to_slots_f32(int64_t M, int64_t N, int64_t K, const float *d_X, int64_t ldx, const float *d_W, int64_t ldw,
+                                            float *d_H, int64_t ldh, const int32_t *d_slots, float *d_send, int64_t ld_send,
+                                            void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    GNNX_REQUIRE(M >= 0 && N > 0 && K > 0 && N < (1ll << 31), GNNX_ERR_INVALID_ARG, "bad sizes");
+    if (M == 0) return GNNX_OK;
+    GNNX_REQUIRE(d_X && d_W && d_H && d_slots && d_send && ldx >= K && ldw >= K && ldh >= N && ld_send >= N, GNNX_ERR_INVALID_ARG,
+                 "null pointer or ld");
+    GNNX_REQUIRE(N % 4 == 0 && N / 4 <= 256 && 256 % (N / 4) == 0 && ldh % 4 == 0 && ld_send % 4 == 0 && aligned16(d_H) && aligned16(d_send) &&
+                     aligned16(d_slots),
+                 GNNX_ERR_UNSUPPORTED, "rows of 16-byte pieces only, as gnnx_rows_to_slots_f32 (N %% 4 == 0, N / 4 a divisor of 256)");
+    size_t need = 0;
+    gnnx_gemm_nt_rows_to_slots_workspace(M, N, K, &need);
+    GNNX_REQUIRE(d_workspace && workspace_bytes >= need, GNNX_ERR_WORKSPACE, "workspace %zu < required %zu", workspace_bytes, need);
+    hipStream_t st = as_stream(stream);
+    int64_t rows = 0;
+    if (dma_shape_ok(M, N, K) && N % 128 == 0 && aligned16(d_workspace)) {
+        float *wt = static_cast<float *>(d_workspace);
+        hipLaunchKernelGGL(gemm_transpose_w_kernel, dim3((uint32_t)ceil_div(K, 32), (uint32_t)ceil_div(N, 32)), dim3(256), 0, st, d_W, ldw, N, K, wt, N);
+        GNNX_LAUNCH_CHECK();
+        GemmArgs g{};
+        g.M = M; g.N = N; g.K = K; g.A = d_X; g.lda = ldx; g.B = wt; g.ldb = N; g.C = d_H; g.ldc = ldh; g.alpha = 1.f; g.beta = 0.f;
+        g.k_per_split = K;
+        GemmFuse fu{nullptr, ld_send, d_send, d_slots};
+        int rc = launch_dma(g, st, &rows, &fu, nullptr, 4);
+        if (rc) return rc;
+    }
+    if (rows < M) {   // what the kernel left: the plain product, then the pack as a pass of its own
+        const int64_t mr = M - rows;
+        int rc = gnnx_gemm_f32(0, 1, mr, N, K, 1.f, d_X + rows * ldx, ldx, d_W, ldw, 0.f, d_H + rows * ldh, ldh, d_workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        rc = gnnx_rows_to_slots_f32(d_H + rows * ldh, ldh, mr, (int32_t)N, d_slots + rows * 8, d_send, ld_send, nullptr, 0.f, nullptr, 0, stream);
+        if (rc) return rc;
     }
     return GNNX_OK;
 }

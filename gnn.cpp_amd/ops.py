@@ -380,6 +380,20 @@ def rows_to_slots(X, table, send, colsum_out=None, beta=0.0):
     return send
 
 
+def linear_fwd_rows_to_slots(X, W, out, table, send):
+    """gnnx_gemm_nt_rows_to_slots_f32: H = X . W^T (linear_fwd's bits) with the halo pack in the product's epilogue -- every row of H
+    listed in `table` (slot_table) also stored to its rows of `send`, from the registers H is stored from (rows_to_slots' bytes without
+    the pass that reads H back)."""
+    M, K = X.shape
+    N = W.shape[0]
+    wsb = C.c_size_t(0)
+    capi.call("gnnx_gemm_nt_rows_to_slots_workspace", M, N, K, C.byref(wsb))
+    ws = _workspace(wsb.value, X.device, "gemm")
+    capi.call("gnnx_gemm_nt_rows_to_slots_f32", M, N, K, _ptr(X), _ld(X), _ptr(W), _ld(W), _ptr(out), _ld(out), _ptr(table), _ptr(send), _ld(send),
+              _ptr(ws), wsb.value, _stream())
+    return out
+
+
 def gather_row_stride(n_rows, n_feat):
     """gnnx_gather_row_stride: the row pitch (floats) for a matrix whose rows the aggregation gathers (n_feat, or n_feat + 64 for large
     matrices of 512-byte-multiple rows: spreads the hub rows of a synthetic power-law graph over the memory channels)."""

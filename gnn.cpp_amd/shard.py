@@ -700,6 +700,7 @@ class ShardedBench:
             self.names = ["gemm_xwT", "halo_fwd", "spmm_fwd", "colsum", "halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW", "allreduce"]
             if getattr(self, "scatter", None) is not None:
                 self.names[3:5] = ["colsum_pack_halo_bwd"]
+                self.names[0] = "gemm_xwT_pack_send_fwd"
         elif schedule == "training":
             self.names = ["gemm_xwT_pack_send_chunks", "wait_halo_fwd", "spmm_fwd", "pack_send_bwd_chunks", "colsum", "wait_halo_bwd", "spmm_bwd",
                           "gemm_dX", "gemm_dW", "allreduce"]
@@ -707,7 +708,8 @@ class ShardedBench:
             self.names = ["pack_send_bwd", "gemm_xwT", "pack_send_fwd", "colsum", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
                           "wait_halo_fwd", "spmm_fwd", "allreduce"]
             if getattr(self, "scatter", None) is not None:   # dbias and the pack of G in one pass
-                self.names = ["colsum_pack_send_bwd", "gemm_xwT", "pack_send_fwd", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
+                # ... and the pack of H in the epilogue of the product that makes it
+                self.names = ["colsum_pack_send_bwd", "gemm_xwT_pack_send_fwd", "send_fwd", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
                               "wait_halo_fwd", "spmm_fwd", "allreduce"]
         self.ev = []
 
@@ -746,6 +748,12 @@ class ShardedBench:
             else:
                 ops.colsum(Gl, out=self.dbias)
             return exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=async_op, prepacked=True)
+
+        def transform():
+            # H = X . W^T; with a slot table the rows other ranks need leave for the send buffer from the product's epilogue
+            if self.scatter is not None and int(p.fwd.send_idx.numel()):
+                return ops.linear_fwd_rows_to_slots(self.X, self.W, Hl, p.fwd.slot_table, self.send_f)
+            return ops.linear_fwd(self.X, self.W, out=Hl)
 
         if self.replicate:
             # one exchange (G, asynchronous); the whole forward chain -- transform of local AND halo rows, aggregation -- under it
@@ -787,8 +795,8 @@ class ShardedBench:
             run(lambda: ops.gemm(self.dH, self.X, transA=True, out=self.dW))
             run(self._reduce_params)
         elif self.schedule == "sequential":
-            run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
-            run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, scatter=self.scatter))
+            run(transform)
+            run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, prepacked=self.scatter is not None))
             run(spmm_f)
             if self.scatter is not None:
                 run(colsum_pack_exchange_b)
@@ -807,9 +815,9 @@ class ShardedBench:
                 _, hb = run(lambda: colsum_pack_exchange_b(async_op=True))
             else:
                 _, hb = run(lambda: exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True))
-            run(lambda: ops.linear_fwd(self.X, self.W, out=Hl))
+            run(transform)
             _, hf = run(lambda: exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, async_op=True,
-                                              scatter=self.scatter))
+                                              prepacked=self.scatter is not None))
             if self.scatter is None:
                 run(lambda: ops.colsum(Gl, out=self.dbias))
             run(hb.wait)

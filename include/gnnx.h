@@ -326,6 +326,17 @@ int gnnx_colsum_workspace(int64_t n_rows, int32_t n_feat, size_t *bytes);
  * pack of the upstream gradient in one read.  Rows of 16-byte pieces (n_feat % 4 == 0, n_feat / 4 a divisor of 256). */
 int gnnx_rows_to_slots_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_t n_feat, const int32_t *d_slots, float *d_send,
                            int64_t ld_send, float *d_colsum, float beta, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* gnnx_gemm_nt_rows_to_slots_f32: the sharded step's transform with the halo pack in the product's epilogue (the product
+ * replaces nn::Linear::forward, /root/reference/src/nn.cpp:205-211, as gnnx_gemm_f32(0, 1, ...) does).  H[M][N] = X[M][K] . W[N][K]^T,
+ * and every row of H listed in d_slots ([M][8], gnnx_rows_to_slots_f32's table) is ALSO stored to its send-buffer rows from the
+ * registers the epilogue stores H from: the same bits in H and in d_send as gnnx_gemm_f32 followed by gnnx_rows_to_slots_f32, without
+ * the pass that reads H back.  Shapes off the LDS-DMA kernel's grid (and the ragged last rows) run exactly those two calls.  Rows of
+ * 16-byte pieces, as gnnx_rows_to_slots_f32.  Workspace: gnnx_gemm_nt_rows_to_slots_workspace() bytes (W^T). */
+int gnnx_gemm_nt_rows_to_slots_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes);
+int gnnx_gemm_nt_rows_to_slots_f32(int64_t M, int64_t N, int64_t K, const float *d_X, int64_t ldx, const float *d_W, int64_t ldw,
+                                   float *d_H, int64_t ldh, const int32_t *d_slots, float *d_send, int64_t ld_send,
+                                   void *d_workspace, size_t workspace_bytes, void *stream);
 int gnnx_gather_row_stride(int64_t n_rows, int32_t n_feat, int64_t *ld_out);
 int gnnx_colsum_copy_f32(const float *d_G, int64_t ldg, int64_t n_rows, int32_t n_feat, float beta, float *d_out, float *d_copy,
                          int64_t ldc, void *d_workspace, size_t workspace_bytes, void *stream);

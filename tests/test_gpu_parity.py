@@ -1863,3 +1863,61 @@ def test_pack_from_the_producers_side_equals_the_gather_pack(env, n, F, world):
     assert torch.equal(got3, want)
     too_many = torch.cat([torch.arange(n)] * 8).to(torch.int32).to(env["dev"])
     assert ops.slot_table(too_many, n) is None
+
+
+@pytest.mark.parametrize("M,F,world", [(256 * (256 + 18) + 100, 256, 8),    # 256 whole tiles per CU round + 18 left: 128 x 128 tail + ragged rows
+                                       (256 * (256 + 100) + 5, 256, 4),    # 100 left: 256 x 128 tail
+                                       (256 * 40, 256, 8),                  # less than a round: no tail launch
+                                       (256 * (256 + 66) + 3, 128, 8),      # 128 wide: 256 x 128 tiles, 128 x 128 tail
+                                       (256 * 9 + 17, 64, 3),               # narrow output: guarded column tile -> product, then the pack pass
+                                       (1000, 256, 2)])                     # below the LDS-DMA kernel's sizes: the two calls it replaces
+def test_transform_with_the_pack_in_its_epilogue(env, M, F, world):
+    """gnnx_gemm_nt_rows_to_slots_f32 (the sharded step's transform: the halo pack rides in the product's epilogue): H has the bits of
+    gnnx_gemm_f32's X . W^T and the send buffer is the gather pack of H, byte for byte -- rows that go to no peer, to one, to all
+    world - 1, across the main launch, the smaller-tile launch of the last partial round and the ragged rows.  The smaller-tile launch
+    itself: its rows equal the same rows multiplied at the head of a product that has no tail (every geometry runs the same MFMA chain
+    per output element)."""
+    ops, torch = env["ops"], env["torch"]
+    gen = torch.Generator(device="cpu").manual_seed(M + F)
+    parts = [torch.sort(torch.randperm(M, generator=gen)[: int(M * frac)]).values for frac in (0.6 * torch.rand(world - 1, generator=gen)).tolist()]
+    parts[-1] = torch.arange(0, M, 3)   # (rows with many slots exist wherever the random subsets overlap)
+    send_idx = torch.cat(parts).to(torch.int32).to(env["dev"])
+    table = ops.slot_table(send_idx, M)
+    X = ops.uniform_pm1(11, (M, F), device=env["dev"])
+    W = ops.uniform_pm1(12, (F, F), scale=F ** -0.5, device=env["dev"])
+    H_ref = ops.linear_fwd(X, W)
+    want = ops.gather_rows(H_ref, send_idx)
+    H = torch.full_like(H_ref, float("nan"))
+    send = torch.full_like(want, float("nan"))
+    ops.linear_fwd_rows_to_slots(X, W, H, table, send)
+    assert torch.equal(H, H_ref)
+    assert torch.equal(send, want)
+    # strided destinations: H at the head of a wider buffer (the [local | halo] buffer on the gather pitch), send buffer likewise
+    Hp = torch.zeros((M, F + 64), dtype=torch.float32, device=env["dev"])
+    sp = torch.zeros((want.shape[0], F + 8), dtype=torch.float32, device=env["dev"])
+    ops.linear_fwd_rows_to_slots(X, W, Hp[:, :F], table, sp[:, :F])
+    assert torch.equal(Hp[:, :F], H_ref) and torch.equal(sp[:, :F], want)
+    assert float(Hp[:, F:].abs().max()) == 0.0 and float(sp[:, F:].abs().max()) == 0.0
+    # the last partial round against a product without one: 2048 of its rows multiplied at the head of an 8-tile product
+    if M >= 256 * 256 + 2048:
+        r0 = (M // 256) // 256 * 256 * 256
+        assert torch.equal(ops.linear_fwd(X[r0:r0 + 2048].contiguous(), W), H_ref[r0:r0 + 2048])
+
+
+@pytest.mark.parametrize("K,F", [(64 * 1024 + 64 * 5 + 17, 256), (64 * 1500 + 63, 128), (64 * 1100, 256)])
+def test_weight_gradient_over_a_row_count_off_the_k_tile_grid(env, K, F):
+    """dW = dH^T . X over a shard's rows (1.25 M is no multiple of 64): the LDS-DMA kernel takes the whole K-tile pairs -- dealt to the
+    splits evenly, 76 or 77 pairs each, none empty -- and the last K % 64 rows arrive through one more slab of the in-order reduction.
+    Against float64 at the GEMM bar, 1e-5 * max(1, |ref|) (the reference's own sum order over 10^5 rows is no closer to float64), run
+    to run identical, and beta = 1 accumulates on top."""
+    ops, torch = env["ops"], env["torch"]
+    dH = ops.uniform_pm1(41, (K, F), device=env["dev"])
+    X = ops.uniform_pm1(42, (K, F), device=env["dev"])
+    ref = dH.double().t() @ X.double()
+    a = ops.gemm(dH, X, transA=True)
+    b = ops.gemm(dH, X, transA=True)
+    assert torch.equal(a, b)
+    assert (a.double() - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    c = a.clone()
+    ops.gemm(dH, X, transA=True, out=c, beta=1.0)
+    assert (c.double() - 2 * ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
