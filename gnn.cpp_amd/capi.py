@@ -154,6 +154,8 @@ _SIGS = {
     "gnnx_halo_plan_set_send_list": [_vp, _vp, C.POINTER(_i64), _vp],
     "gnnx_halo_plan_exchange_requests": [_vp, _vp, _vp],
     "gnnx_halo_exchange_rows_f32": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
+    "gnnx_halo_plan_slot_table": [_vp, C.POINTER(_vp)],
+    "gnnx_halo_exchange_packed_f32": [_vp, _vp, _vp, _i64, _i32, _vp, _vp],
     "gnnx_halo_exchange_f32": [_vp, _vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _i32, _vp],
     "gnnx_allreduce_sum_f32": [_vp, _vp, _i64, _vp],
     "gnnx_gather_rows_f32": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp],

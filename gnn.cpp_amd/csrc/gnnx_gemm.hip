@@ -512,7 +512,7 @@ __device__ __forceinline__ void dma_16B(uint32_t voff_bytes, const float *sbase,
 }
 
 #ifdef GNNX_EXPERIMENTS
-#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // timing only -- 1: no epilogue, 2: no operand loads after the first, 4: the epilogue's LDS round trip without its stores, 8: stores straight from the accumulators (16 rows x 64 B per instruction), 16: FUSE 4's list walk without its send stores
+#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // timing only -- 1: no epilogue, 2: no operand loads after the first, 4: the epilogue's LDS round trip without its stores, 8: stores straight from the accumulators (16 rows x 64 B per instruction), 16: FUSE 4's list walk without its send stores, 32: non-temporal C stores
 #else
 #define GNNX_ABLATE(bit) false
 #endif
@@ -781,6 +781,8 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
                 } else {
                     if (GNNX_ABLATE(4)) {   // A/B: the LDS round trip without the stores
                         asm volatile("" ::"v"(o[p]));
+                    } else if (GNNX_ABLATE(32)) {   // A/B: C leaves with the non-temporal policy
+                        if (okc) __builtin_nontemporal_store(o[p], reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * ES + offc));
                     } else if (okc) *reinterpret_cast<gemm_f32x4acc *>(crow + (int64_t)(4 * p) * g.ldc * ES + offc) = o[p];
                 }
                 if constexpr (FUSE == 4) {

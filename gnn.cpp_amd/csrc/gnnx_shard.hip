@@ -500,3 +500,25 @@ GNNX_API int gnnx_halo_exchange_rows_f32(const gnnx_halo_plan *plan, gnnx_comm *
     return gnnx_halo_exchange_f32(comm, d_send_buf, plan->send_rows.data(), d_buf + plan->n_local * ldb, plan->recv_rows.data(), n_feat,
                                   stream);
 }
+
+// The plan's slot table (gnnx_rows_to_slots_f32's [n_local][8] inverse of the send list; NULL: a world of more than 8 ranks, or no send
+// list yet) for producers that pack while they produce (gnnx_gemm_nt_rows_to_slots_f32), and the exchange of a send buffer such a
+// producer has filled.
+GNNX_API int gnnx_halo_plan_slot_table(const gnnx_halo_plan *plan, const int32_t **d_slots)
+{
+    GNNX_REQUIRE(plan && d_slots, GNNX_ERR_INVALID_ARG, "bad arguments");
+    *d_slots = plan->n_send > 0 ? plan->d_slots : nullptr;
+    return GNNX_OK;
+}
+
+GNNX_API int gnnx_halo_exchange_packed_f32(const gnnx_halo_plan *plan, gnnx_comm *comm, float *d_buf, int64_t ldb, int32_t n_feat,
+                                           const float *d_send_buf, void *stream)
+{
+    GNNX_REQUIRE(plan && comm && n_feat >= 0 && ldb >= n_feat, GNNX_ERR_INVALID_ARG, "bad arguments");
+    GNNX_REQUIRE(plan->n_send >= 0, GNNX_ERR_INVALID_ARG, "the send list has not been set yet");
+    GNNX_REQUIRE(ldb == n_feat || plan->n_halo == 0, GNNX_ERR_UNSUPPORTED, "the halo tail must be densely packed (ldb == n_feat)");
+    if (plan->world == 1) return GNNX_OK;
+    GNNX_REQUIRE(d_buf && (plan->n_send == 0 || d_send_buf), GNNX_ERR_INVALID_ARG, "null buffer");
+    return gnnx_halo_exchange_f32(comm, d_send_buf, plan->send_rows.data(), d_buf + plan->n_local * ldb, plan->recv_rows.data(), n_feat,
+                                  stream);
+}

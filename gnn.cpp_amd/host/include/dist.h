@@ -89,6 +89,9 @@ public:
     void ensure_spmm_plans(int32_t n_feat);
     // exchange rows of a [n_local + n_halo, n_feat] device buffer: fills the halo tail from the owners
     void exchange(const Side &s, float *d_buf, int32_t n_feat);
+    // ... of a send buffer its producer has already filled (the transform's epilogue: cyg::detail::SendSlotsRequest)
+    void exchange_packed(const Side &s, float *d_buf, int32_t n_feat, const float *d_send);
+    size_t packed_transforms = 0;   // how many transforms packed their send rows themselves (tests read it)
 
 private:
     size_t _n = 0;

@@ -235,6 +235,15 @@ tptr<T> matmul(const tptr<T> &lhs, const tptr<T> &rhs)
                 rq->done = true;
                 return out;
             }
+            // the sharded layer's transform: rows other ranks need leave for the send buffer from the product's epilogue
+            const bool pieces = N % 4 == 0 && N / 4 <= 256 && 256 % (N / 4) == 0 && ldc % 4 == 0;
+            if (detail::SendSlotsRequest *rq = pieces ? detail::SendSlotsRequest::take((size_t)M, (size_t)N) : nullptr) {
+                detail::gx(gnnx_gemm_nt_rows_to_slots_workspace(M, N, K, &wsb), "matmul");
+                detail::gx(gnnx_gemm_nt_rows_to_slots_f32(M, N, K, A, lda, B, ldb, C, ldc, rq->slots, rq->send, N,
+                                                          wsb ? detail::workspace(wsb) : nullptr, wsb, st), "matmul");
+                rq->done = true;
+                return out;
+            }
         }
         detail::gx(gnnx_gemm_workspace(ta, tb, M, N, K, &wsb), "matmul");
         detail::gx(gnnx_gemm_f32(ta, tb, M, N, K, 1.0f, A, lda, B, ldb, 0.0f, C, ldc, wsb ? detail::workspace(wsb) : nullptr,

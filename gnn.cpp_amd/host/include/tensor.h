@@ -99,6 +99,37 @@ struct BnStatsRequest {
     }
 };
 
+// The sharded layer (graph::GCNConv::forward_sharded): the next product X[M,K] . W[N,K]^T with M x N outputs is asked to store the rows
+// other ranks need into the halo plan's send buffer as well, from its epilogue (gnnx_gemm_nt_rows_to_slots_f32; slots = the plan's
+// [M][8] table, send = [n_send][N] dense).  Same per-thread one-shot pattern; `done` tells the requester whether a product took it --
+// if not (rows that are no 16-byte pieces), the exchange packs as before.
+struct SendSlotsRequest {
+    size_t rows, cols;
+    const int32_t *slots;
+    float *send;
+    bool done = false;
+    static SendSlotsRequest *&pending()
+    {
+        static thread_local SendSlotsRequest *p = nullptr;
+        return p;
+    }
+    SendSlotsRequest(size_t rows_, size_t cols_, const int32_t *slots_, float *send_) : rows(rows_), cols(cols_), slots(slots_), send(send_)
+    {
+        if (slots && send) pending() = this;
+    }
+    ~SendSlotsRequest()
+    {
+        if (pending() == this) pending() = nullptr;
+    }
+    static SendSlotsRequest *take(size_t rows, size_t cols)
+    {
+        SendSlotsRequest *p = pending();
+        if (!p || p->rows != rows || p->cols != cols) return nullptr;
+        pending() = nullptr;
+        return p;
+    }
+};
+
 inline uint64_t next_store_id()
 {
     static std::atomic<uint64_t> counter{0};

@@ -172,6 +172,12 @@ void Partition::exchange(const Side &s, float *d_buf, int32_t n_feat)
     // same stream (RCCL) or the exchange has completed (local transport)
 }
 
+void Partition::exchange_packed(const Side &s, float *d_buf, int32_t n_feat, const float *d_send)
+{
+    if (comm->world() == 1) return;
+    gx(gnnx_halo_exchange_packed_f32(s.plan, comm->handle(), d_buf, n_feat, n_feat, d_send, current_stream()), "halo exchange");
+}
+
 std::vector<int> Partition::local_vertices()
 {
     std::vector<int32_t> owner(_n), nid(_n);
@@ -217,6 +223,7 @@ public:
     tptr<float> mean, var;  // global batch statistics (BatchNorm mode)
     float eps = 1e-5f;
     bool use_bn = false, has_beta = false;
+    const float *packed_send = nullptr;   // forward only: the send buffer of h's rows, filled by the transform's epilogue (or null)
     ShardedAggregateOp() { name = "GCNShardedAggregate"; }
 
     tptr<float> forward(const tptr<float> &h, const tptr<float> &bias, const tptr<float> &gamma, const tptr<float> &beta)
@@ -248,7 +255,8 @@ public:
         Scratch hext_buf(in_place ? 0 : sizeof(float) * ((size_t)nl * f + halo_elems));   // back to the pool on every exit path
         float *hext = in_place ? h->device_data() : hext_buf.as<float>();
         if (!in_place && nl) gx(gnnx_memcpy_d2d(hext, h->device_data(), sizeof(float) * (size_t)nl * f, st), "aggregate");
-        part->exchange(part->fwd, hext, f);
+        if (packed_send) part->exchange_packed(part->fwd, hext, f, packed_send);   // the transform's epilogue filled the send buffer
+        else part->exchange(part->fwd, hext, f);
         auto snapshot = [&](const float *src, size_t rows) {
             auto t = std::make_shared<tensor<float>>(tensor<float>::device_tag{}, std::vector<size_t>{std::max<size_t>(rows, 1), (size_t)f}, false);
             if (rows) gx(gnnx_memcpy_d2d(t->device_out(), src, sizeof(float) * rows * (size_t)f, st), "trace");
@@ -347,12 +355,22 @@ tptr<float> GCNConv::forward_sharded(const tptr<float> &x)
 {
     if (x->rank() != 2 || x->shape()[0] != _part->num_local()) throw std::runtime_error(ERROR_SIZE_MISMATCH);
     tptr<float> h;
+    // the rows other ranks need leave for the send buffer from the transform's epilogue (tensor.h: SendSlotsRequest); the buffer lives
+    // until the exchange inside the aggregation op below has been issued, then goes back to this thread's pool (same stream)
+    const int32_t *slots = nullptr;
+    if (_part->comm->world() > 1) gx(gnnx_halo_plan_slot_table(_part->fwd.plan, &slots), "halo plan");
+    Scratch send(slots ? sizeof(float) * (size_t)std::max<int64_t>(_part->fwd.n_send, 1) * (size_t)_out_channels : 0);
+    bool packed = false;
     {   // the product's output [n_local, F_out] gets room for the halo rows behind it (tensor.h: TailReservation)
         cyg::detail::TailReservation halo_rows(_part->num_local() * _out_channels, (size_t)_part->fwd.n_halo * _out_channels);
+        cyg::detail::SendSlotsRequest send_rows(_part->num_local(), _out_channels, slots, slots ? send.as<float>() : nullptr);
         h = (*get_module("lin"))(x);
+        packed = send_rows.done;
     }
+    if (packed) _part->packed_transforms++;
     auto op = std::make_unique<ShardedAggregateOp>();
     op->part = _part;
+    op->packed_send = packed ? send.as<float>() : nullptr;
     tptr<float> gamma, beta;
     if (!hot_path_only) {
         auto *bn = dynamic_cast<nn::BatchNorm *>(get_module("bnorm").get());

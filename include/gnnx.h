@@ -546,6 +546,13 @@ int gnnx_halo_plan_exchange_requests(gnnx_halo_plan *plan, gnnx_comm *comm, void
  * built by gnnx_halo_plan_set_send_list -- whenever the rows are 16-byte pieces; the gather by the send list otherwise: same buffer) */
 int gnnx_halo_exchange_rows_f32(const gnnx_halo_plan *plan, gnnx_comm *comm, float *d_buf, int64_t ldb, int32_t n_feat,
                                 float *d_send_buf, void *stream);
+/* A producer that packs while it produces (gnnx_gemm_nt_rows_to_slots_f32: the transform's epilogue; gnnx_rows_to_slots_f32 with the
+ * column sums: the upstream gradient's dbias pass) takes the plan's slot table ([n_local][8]; NULL when the plan has none: more than
+ * 8 ranks, or no rows to send) and hands the filled send buffer ([n_send][n_feat], dense) to gnnx_halo_exchange_packed_f32 -- the
+ * exchange step of gnnx_halo_exchange_rows_f32 without its pack. */
+int gnnx_halo_plan_slot_table(const gnnx_halo_plan *plan, const int32_t **d_slots);
+int gnnx_halo_exchange_packed_f32(const gnnx_halo_plan *plan, gnnx_comm *comm, float *d_buf, int64_t ldb, int32_t n_feat,
+                                  const float *d_send_buf, void *stream);
 
 /* ------------------------------------------------------------------ synthetic inputs ------------- */
 /* Counter-based SplitMix64 generators, bit-identical to gnn.cpp_amd/synth.py. */

@@ -332,6 +332,10 @@ static void run_sharded(const Problem &p, bool hot_path_only, int world, const R
                 bool same = mv.size() == xl->size();
                 for (size_t i = 0; same && i < mv.size(); i++) same = mv[i] == (*xl)[i];
                 if (!same) errors[rank] = "take_rows differs from the host gather";
+                // widths of 16-byte row pieces: the transform packed its send rows in its own epilogue (the stage trace above compared
+                // the halo rows that arrived from it); other widths keep the pack inside the exchange
+                const bool pieces = p.fout % 4 == 0 && p.fout / 4 <= 256 && 256 % (p.fout / 4) == 0;
+                if (part->packed_transforms != (pieces && part->fwd.n_send > 0 ? 1u : 0u)) errors[rank] = "the transform's epilogue pack was not (or wrongly) taken";
             } catch (const std::exception &ex) {
                 errors[rank] = ex.what();
                 comms[rank].reset();  // peers blocked in a collective fail instead of hanging
@@ -648,6 +652,13 @@ int main()
         for (bool hot : {true, false}) {
             const Result ref = run_unsharded(p, hot);
             for (int world : {2, 4}) run_sharded(p, hot, world, ref);
+        }
+        // a width the LDS-DMA product takes (K % 64 == 0, N % 128 == 0, >= 2048 local rows): the transform's send rows leave from the
+        // product kernel's own epilogue (gemm_dma_kernel, FUSE 4), not from the two calls it falls back to on other shapes
+        {
+            const Problem wide = make_problem(12000, 150000, 64, 128);
+            const Result wref = run_unsharded(wide, true);
+            for (int world : {2, 4}) run_sharded(wide, true, world, wref);
         }
         // more ranks than structure: 40 nodes over 8 ranks, some peers exchange nothing
         const Problem tiny = make_problem(40, 90, 5, 4);

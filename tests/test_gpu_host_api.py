@@ -170,7 +170,9 @@ def test_sharded_layer_through_the_cpp_api():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, GNNCPP_TEST_DIAGNOSE="1"))
     assert r.returncode == 0 and r.stdout.strip().endswith("SHARDED_HOST_OK"), r.stdout[-6000:] + r.stderr[-3000:]
     diag = [ln for ln in r.stdout.splitlines() if ln.startswith("DIAG ")]
-    assert len(diag) == 2 * (2 + 4) + 8, diag   # hot path and full layer at world 2 and 4, the tiny graph at world 8
+    # hot path and full layer at world 2 and 4, the 128-wide layer (send rows from the product kernel's epilogue) at 2 and 4, the tiny
+    # graph at world 8
+    assert len(diag) == 2 * (2 + 4) + (2 + 4) + 8, diag
     assert all("every traced stage matches" in ln for ln in diag), diag
 
 
