@@ -643,11 +643,14 @@ class ShardedBench:
         p.compute_norm(dist, degree_norm, self.pack)
         # the per-step packs run from the producer's side (every local row read once, written to each of its send slots); the pack of
         # the upstream gradient rides in the pass that sums its columns (dbias).  One-chunk layouts of 16-byte row pieces only.
+        # (chunked layouts too: a row's slots are positions in the chunk-major send buffer, and chunk k's segment holds rows of chunk k only)
         self.scatter = None
-        if n_chunks == 1 and F % 4 == 0 and 256 % (F // 4) == 0 and F // 4 <= 256:
+        self.tables = False
+        if F % 4 == 0 and 256 % (F // 4) == 0 and F // 4 <= 256:
             for side in (p.fwd, p.bwd):
                 side.slot_table = ops.slot_table(side.send_idx, p.n_local)
-            if p.fwd.slot_table is not None and p.bwd.slot_table is not None:
+            self.tables = p.fwd.slot_table is not None and p.bwd.slot_table is not None
+            if self.tables and n_chunks == 1:
                 self.scatter = lambda rows, table, out: ops.rows_to_slots(rows, table, out)
         t = torch.tensor([p.nnz_local], dtype=torch.int64, device=dev)
         dist.all_reduce(t)
@@ -704,6 +707,8 @@ class ShardedBench:
         elif schedule == "training":
             self.names = ["gemm_xwT_pack_send_chunks", "wait_halo_fwd", "spmm_fwd", "pack_send_bwd_chunks", "colsum", "wait_halo_bwd", "spmm_bwd",
                           "gemm_dX", "gemm_dW", "allreduce"]
+            if getattr(self, "tables", False):   # dbias and the pack of G in one pass, then the chunks' exchanges
+                self.names[3:5] = ["colsum_pack_bwd", "send_bwd_chunks"]
         else:
             self.names = ["pack_send_bwd", "gemm_xwT", "pack_send_fwd", "colsum", "wait_halo_bwd", "spmm_bwd", "gemm_dX", "gemm_dW",
                           "wait_halo_fwd", "spmm_fwd", "allreduce"]
@@ -774,21 +779,32 @@ class ShardedBench:
             #             chunk is multiplied (chunk-major halo tail: HaloSide);
             #   backward: G's rows leave chunk by chunk (pack k+1 while chunk k is on the links), dbias = colsum(G) under the exchange.
             # (A multi-layer step also has dW_l under the exchange of G_{l-1}: ShardedGcnStack.loss_and_backward.)
+            packed_f = self.tables and int(p.fwd.send_idx.numel()) > 0
+            packed_b = self.tables and int(p.bwd.send_idx.numel()) > 0
+
             def fwd_pipeline():
                 hs = []
                 for k in range(p.n_chunks):
                     r0, r1 = p.row_chunks[k], p.row_chunks[k + 1]
-                    if r1 > r0:
+                    if r1 > r0 and packed_f:   # the chunk's send rows leave from the product's epilogue, into the chunk's segment
+                        ops.linear_fwd_rows_to_slots(self.X[r0:r1], self.W, Hl[r0:r1], p.fwd.slot_table[r0:r1], self.send_f)
+                    elif r1 > r0:
                         ops.linear_fwd(self.X[r0:r1], self.W, out=Hl[r0:r1])
-                    hs.append(exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, async_op=True, chunk=k)[1])
+                    hs.append(exchange_rows(dist, p.fwd, self.Hext, self.F, self.pack, self.send_f, self.native, async_op=True, chunk=k,
+                                            prepacked=packed_f)[1])
                 return _All(hs)
 
             hf = run(fwd_pipeline)
             run(hf.wait)
             run(spmm_f)
-            hb = run(lambda: _All([exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True, chunk=k)[1]
+            if self.tables:   # G is read ONCE for dbias and for its pack; the chunks leave one after the other
+                run(lambda: ops.rows_to_slots(Gl, p.bwd.slot_table, self.send_b, colsum_out=self.dbias) if packed_b
+                    else ops.colsum(Gl, out=self.dbias))
+            hb = run(lambda: _All([exchange_rows(dist, p.bwd, self.Gext, self.F, self.pack, self.send_b, self.native, async_op=True, chunk=k,
+                                                 prepacked=packed_b)[1]
                                    for k in range(p.n_chunks)]))
-            run(lambda: ops.colsum(Gl, out=self.dbias))
+            if not self.tables:
+                run(lambda: ops.colsum(Gl, out=self.dbias))
             run(hb.wait)
             run(spmm_b)
             run(lambda: ops.gemm(self.dH, self.W, out=self.dX))
