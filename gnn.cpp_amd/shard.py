@@ -477,11 +477,22 @@ class ShardedGcnStack:
         ns = max(int(p.fwd.send_idx.numel()), int(p.bwd.send_idx.numel()), 1)
         self.send = torch.empty((ns, fmax), dtype=torch.float32, device=dev)
         self._saved = None
+        # a layer's transform packs its send rows in its own epilogue (gnnx_gemm_nt_rows_to_slots_f32) wherever the output rows are
+        # 16-byte pieces; the table does not depend on the width (chunked layouts too: a chunk's segment holds rows of that chunk only)
+        self.table_f = None
+        if p.world > 1 and int(p.fwd.send_idx.numel()) and hasattr(ops, "slot_table"):
+            self.table_f = ops.slot_table(p.fwd.send_idx, nl)
 
-    def _exchange(self, side, buf, F, async_op=False, chunk=None):
+    def _send_view(self, F):
+        return self.send.view(-1)[: self.send.shape[0] * F].view(-1, F)
+
+    def _packs_in_epilogue(self, F):
+        return self.table_f is not None and F % 4 == 0 and F // 4 <= 256 and 256 % (F // 4) == 0
+
+    def _exchange(self, side, buf, F, async_op=False, chunk=None, prepacked=False):
         if self.p.world > 1:
-            return exchange_rows(self.dist, side, buf, F, self.pack, self.send.view(-1)[: self.send.shape[0] * F].view(-1, F), self.native,
-                                 async_op=async_op, chunk=chunk)[1]
+            return exchange_rows(self.dist, side, buf, F, self.pack, self._send_view(F), self.native, async_op=async_op, chunk=chunk,
+                                 prepacked=prepacked)[1]
         return _Done()
 
     def forward(self, X_local):
@@ -497,9 +508,12 @@ class ShardedGcnStack:
             handles = []
             for k in range(p.n_chunks):
                 r0, r1 = p.row_chunks[k], p.row_chunks[k + 1]
-                if r1 > r0:
+                packed = self._packs_in_epilogue(F)
+                if r1 > r0 and packed:
+                    ops.linear_fwd_rows_to_slots(h[r0:r1], self.W[l], self.Hext[l][r0:r1], self.table_f[r0:r1], self._send_view(F))
+                elif r1 > r0:
                     ops.linear_fwd(h[r0:r1], self.W[l], out=self.Hext[l][r0:r1])
-                handles.append(self._exchange(p.fwd, self.Hext[l], F, async_op=True, chunk=k))
+                handles.append(self._exchange(p.fwd, self.Hext[l], F, async_op=True, chunk=k, prepacked=packed))
             for hd in handles:
                 hd.wait()
             Y = ops.spmm(p.fwd.rowptr, p.fwd.colidx, self.Hext[l], rowscale=p.norm, bias=self.b[l], plan=self.plan_f, n_rows=nl,
