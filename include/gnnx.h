@@ -332,7 +332,8 @@ int gnnx_rows_to_slots_f32(const float *d_X, int64_t ldx, int64_t n_rows, int32_
  * and every row of H listed in d_slots ([M][8], gnnx_rows_to_slots_f32's table) is ALSO stored to its send-buffer rows from the
  * registers the epilogue stores H from: the same bits in H and in d_send as gnnx_gemm_f32 followed by gnnx_rows_to_slots_f32, without
  * the pass that reads H back.  Shapes off the LDS-DMA kernel's grid (and the ragged last rows) run exactly those two calls.  Rows of
- * 16-byte pieces, as gnnx_rows_to_slots_f32.  Workspace: gnnx_gemm_nt_rows_to_slots_workspace() bytes (W^T). */
+ * 16-byte pieces, as gnnx_rows_to_slots_f32.  Workspace: gnnx_gemm_nt_rows_to_slots_workspace() bytes (W^T).  As there, every listed
+ * slot must be a row of d_send (the table is the caller's: gnnx_halo_plan_slot_table, or built like it) -- the kernels do not check. */
 int gnnx_gemm_nt_rows_to_slots_workspace(int64_t M, int64_t N, int64_t K, size_t *bytes);
 int gnnx_gemm_nt_rows_to_slots_f32(int64_t M, int64_t N, int64_t K, const float *d_X, int64_t ldx, const float *d_W, int64_t ldw,
                                    float *d_H, int64_t ldh, const int32_t *d_slots, float *d_send, int64_t ld_send,
