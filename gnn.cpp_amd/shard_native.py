@@ -78,6 +78,18 @@ class NativeHaloSide:
     def exchange_rows(self, comm, buf, send_buf):
         capi.call("gnnx_halo_exchange_rows_f32", self.h, comm, ops._ptr(buf), buf.stride(0), buf.shape[1], ops._ptr(send_buf), ops._stream())
 
+    def slot_table(self, device):
+        """gnnx_halo_plan_slot_table: the plan's own [n_local, 8] table (a copy; None when the plan has none)."""
+        p = C.c_void_p()
+        capi.call("gnnx_halo_plan_slot_table", self.h, C.byref(p))
+        if not p.value:
+            return None
+        return self._copy_i32(p.value, self.n_local * 8, device).view(-1, 8)
+
+    def exchange_packed(self, comm, buf, send_buf):
+        """gnnx_halo_exchange_packed_f32: the exchange of a send buffer its producer has filled (ops.linear_fwd_rows_to_slots)."""
+        capi.call("gnnx_halo_exchange_packed_f32", self.h, comm, ops._ptr(buf), buf.stride(0), buf.shape[1], ops._ptr(send_buf), ops._stream())
+
     def __del__(self):
         try:
             capi.lib().gnnx_halo_plan_destroy(self.h)

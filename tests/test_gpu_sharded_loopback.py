@@ -231,6 +231,23 @@ def test_cabi_plan_equals_shard_py_plan_and_drives_a_step(world):
             assert torch.equal(Hext[nl:], H[pt.orig_ids(pt.fwd.halo)])
             out = ops.spmm(pn.fwd.rowptr, pn.fwd.colidx, Hext, rowscale=norm, n_rows=nl)
             assert torch.equal(out, out_ref[v]), "forward aggregation over the C-ABI plan is not bit-identical"
+            # the plan's own slot table is the inverse of its send list, and a transform that packs in its epilogue + the exchange of
+            # the packed buffer (gnnx_halo_plan_slot_table / gnnx_gemm_nt_rows_to_slots_f32 / gnnx_halo_exchange_packed_f32: what
+            # GCNConv::forward_sharded runs) fills the same [local | halo] buffer as product -> exchange with its own pack
+            table = pn.fwd.slot_table(dev)
+            Xl = ops.uniform_pm1(seed + 5, (n, F), device=dev)[v].contiguous()
+            Wt = ops.uniform_pm1(seed + 6, (F, F), scale=F ** -0.5, device=dev)
+            want = torch.zeros_like(Hext)
+            ops.linear_fwd(Xl, Wt, out=want[:nl])
+            pn.fwd.exchange_rows(comms[rank], want, sbuf)          # (collective calls: unconditional on every rank)
+            got = torch.zeros_like(Hext)
+            if pn.fwd.n_send:
+                assert table is not None and torch.equal(table, ops.slot_table(pt.fwd.send_idx, nl))
+                ops.linear_fwd_rows_to_slots(Xl, Wt, got[:nl], table, sbuf[: pn.fwd.n_send])
+            else:
+                ops.linear_fwd(Xl, Wt, out=got[:nl])
+            pn.fwd.exchange_packed(comms[rank], got, sbuf)
+            assert torch.equal(got, want), "the packed exchange differs from the exchange with its own pack"
             # backward: rows of G and the per-column norm for the transposed shard
             Gext = torch.zeros((nl + pn.bwd.n_halo, F), dtype=torch.float32, device=dev)
             Gext[:nl] = G[v]
