@@ -842,6 +842,198 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
     }
 }
 
+#ifdef GNNX_EXPERIMENTS
+// (EXPERIMENTS build only, GNNX_GEMM_W128=1: a record of what does NOT lift the 128-wide products -- DESIGN.md section 4.2.  Same bits
+// as gemm_dma_kernel<4, 2>; 10 M x 128 x 128: 2.83 ms against 2.82.  With its stores aimed at L2-resident rows 2.54, with its loads
+// 2.52, with both 2.45 = 0.85 of the matrix peak: the loop's nine LDS reads per eight MFMAs cost what the barriers cost the
+// 256 x 128 tile.  A first version -- strips of 32 rows, ten reads per sixteen MFMAs, two stages -- ran 2.70 against 2.76.)
+// ---- 128-wide products without a barrier: C[M][128] = A[M][128] . B[128][128] (K = N = 128: BASELINE configs[2]) ----------------------
+// At this width bytes and flops are nearly balanced and a K-tile of gemm_dma_kernel<4, 2> lasts only 3.4 us: its one-K-tile prefetch
+// distance no longer covers an HBM round trip once the C stores share the memory pipeline (loop alone 0.90 of the matrix peak, with
+// loads 0.89, with loads AND stores 0.74), and `s_waitcnt vmcnt(0)` behind a tile's first K-tile waits for the previous tile's stores
+// to be acknowledged, because vmcnt counts loads and stores in one order.  Here
+//   * W (64 KB) is loaded into LDS once and stays (k-major operand image, 68 KB); a wavefront owns a STRIP of 16 rows x all 128
+//     columns and brings its own operand rows into its own ring of four 2-KB stages: after the barrier behind the load of W no
+//     wavefront waits for another, and the two wavefronts of a SIMD drift apart (one's epilogue under the other's MFMAs);
+//   * the ring is THREE K-tiles ahead of the multiply (stage = K-tile index: a strip is four K-tiles), and every wait is counted:
+//     `vmcnt(12)` / `vmcnt(4)` leave the two younger K-tiles (2 DMA instructions each) AND the last strip's 8 stores in flight -- no
+//     wait ever waits for a store (first strip of a wavefront: no stores yet, vmcnt(4));
+//   * same MFMA chain per output element as gemm_dma_kernel (D = mfma(b, a) over k = 0 .. 127 in steps of 4): same bits;
+//   * per k-group 1 a-fragment + 8 b-fragments (one ds_read_b32 each, precomputed addresses + immediates) feed 8 MFMAs;
+//   * C leaves through a 2-KB staging area of the wavefront's own, 16 rows x 32 columns at a time: a store instruction covers
+//     8 rows x 128 B (whole lines);
+//   * loads are never predicated: past the last strip the ring re-reads the last strip (so that the counts above stay exact), and
+//     the last strip starts at M - 16, overlapping its neighbour (same values stored twice).
+struct W128 {
+    static constexpr int NW = 8, NT = 64 * NW, ROWS = 16;                    // wavefronts per workgroup, rows per strip
+    using G = DmaGeo<4, 2, 32>;                                              // (the operand images of the 256 x 128 tile: BK = 32, BN = 128)
+    static constexpr int B_TILE_BYTES = G::B_STAGE_BYTES;                    // one K-tile of W: 16 pieces of 272 words
+    static constexpr int B_BYTES = 4 * B_TILE_BYTES;                         // K = 128
+    static constexpr int A_STAGE_BYTES = ROWS * 32 * 4;                      // 2 KB
+    static constexpr int WAVE_BYTES = 4 * A_STAGE_BYTES + 2048;              // ring of four stages + C staging
+    static constexpr int LDS_BYTES = B_BYTES + NW * WAVE_BYTES;              // 68 KB + 80 KB
+};
+
+template <int KT, int KG>
+__device__ __forceinline__ void w128_read_group(float &a, float (&b)[8], const uint32_t (&ak)[8], uint32_t bk_lo, uint32_t bk_hi)
+{
+    lds_read_b32<KT * W128::A_STAGE_BYTES>(a, ak[KG]);
+    // K-tiles 0, 1 through bk_lo, 2, 3 through bk_hi (= bk_lo + 2 K-tiles): the ds_read offset is a 16-bit immediate
+    constexpr int SB = (KT & 1) * W128::B_TILE_BYTES + W128::G::kgroup_off(128, KG);
+    const uint32_t bk = KT < 2 ? bk_lo : bk_hi;
+    lds_read_b32<SB + 0 * 64>(b[0], bk);
+    lds_read_b32<SB + 1 * 64>(b[1], bk);
+    lds_read_b32<SB + 2 * 64>(b[2], bk);
+    lds_read_b32<SB + 3 * 64>(b[3], bk);
+    lds_read_b32<SB + 4 * 64>(b[4], bk);
+    lds_read_b32<SB + 5 * 64>(b[5], bk);
+    lds_read_b32<SB + 6 * 64>(b[6], bk);
+    lds_read_b32<SB + 7 * 64>(b[7], bk);
+}
+
+#define GNNX_W128_WAIT(N, set)                                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[set]), "+v"(b[set][0]), "+v"(b[set][1]), "+v"(b[set][2]), "+v"(b[set][3]),      \
+                 "+v"(b[set][4]), "+v"(b[set][5]), "+v"(b[set][6]), "+v"(b[set][7])::"memory")
+#define GNNX_W128_MFMA(set) \
+    _Pragma("unroll") for (int j_ = 0; j_ < 8; j_++) acc[j_] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[set][j_], a[set], acc[j_], 0, 0, 0)
+#define GNNX_W128_STEP(KT, KG, cur, nxt)                                           \
+    w128_read_group<KT, KG + 1>(a[nxt], b[nxt], ak, bk_lo, bk_hi);                 \
+    GNNX_W128_WAIT(9, cur);                                                        \
+    GNNX_W128_MFMA(cur)
+#define GNNX_W128_KTILE(KT)                                                        \
+    w128_read_group<KT, 0>(a[0], b[0], ak, bk_lo, bk_hi);                          \
+    GNNX_W128_STEP(KT, 0, 0, 1);                                                   \
+    GNNX_W128_STEP(KT, 1, 1, 0);                                                   \
+    GNNX_W128_STEP(KT, 2, 0, 1);                                                   \
+    GNNX_W128_STEP(KT, 3, 1, 0);                                                   \
+    GNNX_W128_STEP(KT, 4, 0, 1);                                                   \
+    GNNX_W128_STEP(KT, 5, 1, 0);                                                   \
+    GNNX_W128_STEP(KT, 6, 0, 1);                                                   \
+    GNNX_W128_WAIT(0, 1);                                                          \
+    GNNX_W128_MFMA(1)
+
+__global__ __launch_bounds__(W128::NT, 1) void gemm_w128_kernel(GemmArgs g, int64_t n_strips, int ablate)
+{
+    (void)ablate;
+    using G = W128::G;
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];   // [W: 4 K-tiles][per wavefront: ring of 4 stages, C staging]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, r16 = lane & 15;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(gemm_lds_void_t *)lds_raw;
+    const uint32_t a0 = lds0 + (uint32_t)W128::B_BYTES + (uint32_t)wave * (uint32_t)W128::WAVE_BYTES;   // this wavefront's stage 0
+
+    // ---- W into LDS, once: K-tile t = 16 wave-instructions (two k rows of 128 floats each: rows I and I + 16 of the K-tile)
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int inst = wave + W128::NW * u;   // 0 .. 63: K-tile inst / 16, instruction inst % 16
+        const int t = inst >> 4, I = inst & 15;
+        const int krow = 32 * t + G::krow_of(128, I, lane);
+        dma_16B((uint32_t)(krow * g.ldb + 4 * (lane % 32)) * 4u, g.B, lds0 + (uint32_t)(t * W128::B_TILE_BYTES + I * G::B_PIECE_BYTES));
+    }
+    // ---- this wavefront's operand DMA: instruction u of a K-tile brings rows 8 u .. 8 u + 7 (128 bytes each) of the strip
+    uint32_t offa[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int row = 8 * u + lane / 8;
+        const int kg = (lane % 8) ^ G::a_xor(row);
+        offa[u] = (uint32_t)(row * g.lda + 4 * kg) * 4u;
+    }
+    const int64_t last_row0 = g.M - W128::ROWS;
+    const int64_t last_strip = n_strips - 1;
+    auto row0_of = [&](int64_t s) { return s * W128::ROWS <= last_row0 ? s * W128::ROWS : last_row0; };
+    auto issue = [&](int kt, int64_t strip) {   // K-tile kt of `strip` (clamped to the last strip: never predicated) into stage kt
+        const float *abase = g.A + row0_of(GNNX_ABLATE(2) ? 0 : (strip < last_strip ? strip : last_strip)) * g.lda + 32 * kt;   // A/B 2: every strip re-reads strip 0 (L2 hits)
+        dma_16B(offa[0], abase, a0 + (uint32_t)(kt * W128::A_STAGE_BYTES));
+        dma_16B(offa[1], abase, a0 + (uint32_t)(kt * W128::A_STAGE_BYTES + 1024));
+    };
+    // ---- fragment addresses
+    uint32_t ak[8];
+    {
+        const uint32_t xa = (uint32_t)(G::a_xor(r16) << 4);
+#pragma unroll
+        for (int kg = 0; kg < 8; kg++) ak[kg] = a0 + (uint32_t)(r16 * G::A_ROW_BYTES + 4 * q) + (((uint32_t)kg << 4) ^ xa);
+    }
+    const uint32_t bk_lo = lds0 + (uint32_t)(q * G::KPIECE_BYTES + r16 * 4);
+    const uint32_t bk_hi = bk_lo + 2u * W128::B_TILE_BYTES;
+    // ---- C staging: 16 rows x 32 columns (128 B per row); 16-byte column c of row r is stored at c ^ ((r >> 1) & 7): conflict-free
+    // for the writers (16 rows of one 16-byte column) and the readers (8 columns of two rows)
+    const uint32_t ep = a0 + 4u * W128::A_STAGE_BYTES;
+    const uint32_t ep_wr0 = ep + (uint32_t)(r16 * 128) + (uint32_t)(((uint32_t)q ^ (((uint32_t)r16 >> 1) & 7u)) << 4);         // block j even
+    const uint32_t ep_wr1 = ep + (uint32_t)(r16 * 128) + (uint32_t)(((uint32_t)(4 + q) ^ (((uint32_t)r16 >> 1) & 7u)) << 4);   // block j odd
+    const int rr = lane >> 3, rc = lane & 7;   // reader: row rr (+ 8 p), 16-byte column rc
+    const uint32_t ep_rd0 = ep + (uint32_t)(rr * 128) + (uint32_t)(((uint32_t)rc ^ (((uint32_t)rr >> 1) & 7u)) << 4);
+    const uint32_t ep_rd1 = ep + (uint32_t)((rr + 8) * 128) + (uint32_t)(((uint32_t)rc ^ (((uint32_t)(rr + 8) >> 1) & 7u)) << 4);
+    const uint32_t offc = (uint32_t)(rr * g.ldc + 4 * rc) * 4u;   // row rr, columns 4 rc .. of a 32-column group
+
+    const int64_t stride = (int64_t)gridDim.x * W128::NW;
+    int64_t strip = (int64_t)blockIdx.x * W128::NW + wave;
+    issue(0, strip);
+    issue(1, strip);
+    issue(2, strip);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // W and K-tile 0 have landed (K-tiles 1, 2 may be on their way)
+    __syncthreads();   // W is complete in LDS (the only barrier of the kernel)
+    gemm_f32x4acc acc[8];
+    float a[2], b[2][8];
+    const float alpha = g.alpha;
+    // one strip: K-tile kt is multiplied while K-tiles kt + 1 .. kt + 3 (the last ones: the NEXT strip's first) are in flight or landed.
+    // STORES = the number of store instructions of the previous strip's epilogue that may still be in flight (0 on a wavefront's
+    // first strip, else 8): the waits count them so that they are never waited for.
+    auto strip_body = [&](auto stores_tag, int64_t cur, int64_t next) {
+        constexpr int STORES = decltype(stores_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[j][r] = 0.f;
+        issue(3, cur);
+        GNNX_W128_KTILE(0);
+        // K-tile 1 must have landed; younger: K-tiles 2, 3 (4 instructions) and, issued between K-tile 1's and 2's DMA, the last strip's stores
+        if constexpr (STORES == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        issue(0, next);
+        GNNX_W128_KTILE(1);
+        if constexpr (STORES == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // K-tile 2; younger: 3, next 0, and the stores (behind K-tile 2's DMA)
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        issue(1, next);
+        GNNX_W128_KTILE(2);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // K-tile 3; younger: next 0, next 1 (the last strip's stores are older than K-tile 3's DMA)
+        issue(2, next);
+        GNNX_W128_KTILE(3);
+        // ---- epilogue: four groups of 32 columns through the staging area
+        char *ctile = reinterpret_cast<char *>(g.C + row0_of(cur) * g.ldc);
+#pragma unroll
+        for (int c4 = 0; c4 < 4; c4++) {
+            gemm_f32x4acc v0 = acc[2 * c4], v1 = acc[2 * c4 + 1];
+            if (alpha != 1.0f) {
+                v0 = v0 * alpha;
+                v1 = v1 * alpha;
+            }
+            asm volatile("ds_write_b128 %0, %1" ::"v"(ep_wr0), "v"(v0) : "memory");
+            asm volatile("ds_write_b128 %0, %1" ::"v"(ep_wr1), "v"(v1) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            gemm_f32x4acc o0, o1;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(o0) : "v"(ep_rd0) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(o1) : "v"(ep_rd1) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o0), "+v"(o1)::"memory");
+            char *cg = (GNNX_ABLATE(1) ? reinterpret_cast<char *>(g.C + (int64_t)wave * 16 * g.ldc) : ctile) + 128 * c4;   // wave-uniform: columns 32 c4 .. (A/B 1: every strip stores over the same rows: L2 absorbs them)
+            *reinterpret_cast<gemm_f32x4acc *>(cg + offc) = o0;
+            *reinterpret_cast<gemm_f32x4acc *>(cg + (int64_t)8 * g.ldc * 4 + offc) = o1;
+        }
+        // the next strip's K-tile 0 must have landed; younger: its K-tiles 1, 2 (4 instructions) and the 8 stores above
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    };
+    if (strip < n_strips) {
+        strip_body(std::integral_constant<int, 0>{}, strip, strip + stride);
+        for (strip += stride; strip < n_strips; strip += stride) strip_body(std::integral_constant<int, 8>{}, strip, strip + stride);
+    }
+}
+#undef GNNX_W128_KTILE
+#undef GNNX_W128_STEP
+#undef GNNX_W128_MFMA
+#undef GNNX_W128_WAIT
+#endif  // GNNX_EXPERIMENTS
+
 // Split-K partials -> C in a FIXED order (deterministic, no float atomics): 8 lane groups each sum a contiguous eighth of the
 // slabs for 32 consecutive elements (128-byte coalesced reads), then the eight partial sums are combined left to right.
 // (One thread walking all slabs of its element was a chain of up to 1024 dependent loads: 0.31 ms next to a 0.30 ms GEMM
@@ -1323,6 +1515,24 @@ int launch_dma(const GemmArgs &g, hipStream_t st, int64_t *rows_done, const Gemm
     if (geo128 == 4216) {   // A/B: the 256 x 128 tile on K-tiles of 16, two resident workgroups per CU
         if (g.N % 128 == 0) return launch_dma_geo<4, 2, false, 16>(g, st, rows_done, fuse, partial_rows, fuse_mode);
         return launch_dma_geo<4, 2, true, 16>(g, st, rows_done, fuse, partial_rows, fuse_mode);
+    }
+#endif
+#ifdef GNNX_EXPERIMENTS
+    static const int w128_env = [] { const char *e = experiment_env("GNNX_GEMM_W128"); return e ? atoi(e) : 0; }();
+    if (w128_env > 0 && geo128 == 0 && !fuse && fuse_mode != 3 && g.N == 128 && g.K == 128 && (int64_t)W128::ROWS * g.lda < (1ll << 28) &&
+        (int64_t)128 * g.ldb < (1ll << 28) && g.M >= W128::ROWS) {
+        // A/B: K = N = 128 with W resident in LDS, a strip of 16 rows per wavefront, no barrier in the loop (gemm_w128_kernel)
+        static std::atomic<uint64_t> done_w128{0};
+        int rc = lds_opt_in(&gemm_w128_kernel, (size_t)W128::LDS_BYTES, done_w128, "gemm_w128_kernel");
+        if (rc) return rc;
+        const int64_t n_strips = ceil_div(g.M, (int64_t)W128::ROWS);
+        int64_t gx = ceil_div(n_strips, (int64_t)W128::NW);
+        if (gx > kNumCU) gx = kNumCU;
+        static const int ablate = [] { const char *e = experiment_env("GNNX_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+        hipLaunchKernelGGL(gemm_w128_kernel, dim3((uint32_t)gx), dim3(W128::NT), (size_t)W128::LDS_BYTES, st, g, n_strips, ablate);
+        GNNX_LAUNCH_CHECK();
+        *rows_done = g.M;
+        return GNNX_OK;
     }
 #endif
     if (g.N % 128 == 0) {
