@@ -945,6 +945,12 @@ __global__ __launch_bounds__(W128::NT, 1) void gemm_w128_kernel(GemmArgs g, int6
     auto row0_of = [&](int64_t s) { return s * W128::ROWS <= last_row0 ? s * W128::ROWS : last_row0; };
     auto issue = [&](int kt, int64_t strip) {   // K-tile kt of `strip` (clamped to the last strip: never predicated) into stage kt
         const float *abase = g.A + row0_of(GNNX_ABLATE(2) ? 0 : (strip < last_strip ? strip : last_strip)) * g.lda + 32 * kt;   // A/B 2: every strip re-reads strip 0 (L2 hits)
+        if (GNNX_ABLATE(4)) {   // A/B 4 (timing only, wrong products): the same bytes as ONE contiguous 2-KB run per K-tile instead of 16 row slices of 128 B
+            const float *cbase = g.A + row0_of(strip < last_strip ? strip : last_strip) * g.lda + 512 * kt;
+            dma_16B((uint32_t)lane * 16u, cbase, a0 + (uint32_t)(kt * W128::A_STAGE_BYTES));
+            dma_16B((uint32_t)lane * 16u + 1024u, cbase, a0 + (uint32_t)(kt * W128::A_STAGE_BYTES + 1024));
+            return;
+        }
         dma_16B(offa[0], abase, a0 + (uint32_t)(kt * W128::A_STAGE_BYTES));
         dma_16B(offa[1], abase, a0 + (uint32_t)(kt * W128::A_STAGE_BYTES + 1024));
     };
