@@ -1621,8 +1621,17 @@ SideStream *side_stream(hipStream_t caller)
         int cur = 0;
         if (hipGetDevice(&cur) != hipSuccess) return nullptr;
         if (cur != dev && hipSetDevice(dev) != hipSuccess) return nullptr;
-        const bool ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess &&
-                        hipStreamCreateWithFlags(&s.stream2, hipStreamNonBlocking) == hipSuccess &&
+        // Priorities, for the QUEUES they come with: HIP maps streams of one priority onto a small pool of hardware queues, and two
+        // streams that share a queue are not independent -- a kernel packet that follows another kernel of ITS stream carries the
+        // barrier bit and waits for every packet in front of it in the queue, the other stream's too.  With the producer / consumer
+        // kernel's stream on the caller's queue the row kernel started only when that kernel had finished (one rank of eight: 1.97
+        // instead of 1.79 ms per aggregation on the runs that drew that mapping; kernel timeline in DESIGN_HISTORY.md).  The three
+        // priority classes have queue pools of their own: high for the chain-bound kernel of the longest rows (it should never wait
+        // for a CU), low for the hub kernel that fills what the row kernel leaves.
+        int prio_low = 0, prio_high = 0;
+        if (hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_low = prio_high = 0;
+        const bool ok = hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_low) == hipSuccess &&
+                        hipStreamCreateWithPriority(&s.stream2, hipStreamNonBlocking, prio_high) == hipSuccess &&
                         hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) == hipSuccess &&
                         hipEventCreateWithFlags(&s.join, hipEventDisableTiming) == hipSuccess &&
                         hipEventCreateWithFlags(&s.join2, hipEventDisableTiming) == hipSuccess;
@@ -1682,7 +1691,8 @@ int launch_mode(const SpmmArgs &a_in, const gnnx_spmm_plan *plan, int pro, hipSt
         joiner.to = st;
     }
     if (a.n_big_rows > 0) {
-        // the longest rows -- each a chain of dependent adds, a CU of its own per (row, slab) -- always beside everything else
+        // the longest rows -- each a chain of dependent adds, a CU of its own per (row, slab) -- always beside everything else, on the
+        // high-priority side stream (side_stream(): a hardware queue of its own)
         GNNX_HIP_CHECK(hipStreamWaitEvent(side->stream2, side->fork, 0));
         joiner.used2 = true;   // from here on every exit path joins the stream back into the caller's (an error return included)
         const int rc = launch_hubpc(mode, side->stream2, a);
@@ -2044,9 +2054,11 @@ int spmm_impl(int32_t n_rows, int32_t n_cols, int32_t n_feat, const int32_t *d_r
         static const int pc_off = [] { const char *e = experiment_env("GNNX_PC_OFF"); return e ? atoi(e) : 0; }();
         if (pc_off) a.n_big_rows = 0;
 #endif
-        if (a.n_big_rows > 0 && a.n_big_rows < a.n_hub_rows)   // what is left for spmm_hub_kernel: is IT bound by its longest row's chain?
-            a.hub_beside = hub_is_chain_bound(plan->h_hub_degrees[(size_t)a.n_big_rows], plan->n_hub_nnz - plan->h_hub_prefix[(size_t)a.n_big_rows],
-                                              n_feat, 4);
+        // With the chain-bound rows on the producer / consumer kernel (beside everything, on a queue of its own) what is left for
+        // spmm_hub_kernel goes IN FRONT of the row kernel: three kernels at once share one fabric, and the one that loses is the chain
+        // kernel, which then ends last (one rank of eight 8.65 -> 8.43 ms per step, RMAT 1M / 10M F = 128 2.41 -> 2.34, products-shaped
+        // 11.87 -> 11.74: GNNX_SPMM_SIDE A/B on one box each, round 5).  Round 4's rule put it beside whenever its bytes were few.
+        if (a.n_big_rows > 0) a.hub_beside = 0;
     }
     if (x_bf16 && !vec4) {
         // bf16 rows that are not 8-byte pieces (n_feat % 4 != 0 or an unaligned X): LDS-DMA moves one DWORD per lane whatever the
