@@ -117,9 +117,19 @@ def contiguous_partition(weight, world):
     return owner, nid, cuts
 
 
+ROUND_ROWS = 256 * 256   # one round of the transform's 256-row tiles over the 256 CUs
+
+
 def chunk_bounds(n_rows, n_chunks):
-    """Row-chunk boundaries [n_chunks + 1] of a rank's local rows: chunk k = rows [(n k) // K, (n (k+1)) // K)."""
-    return [(int(n_rows) * k) // int(n_chunks) for k in range(int(n_chunks) + 1)]
+    """Row-chunk boundaries [n_chunks + 1] of a rank's local rows: chunk k = rows [(n k) // K, (n (k+1)) // K) -- moved to the nearest
+    multiple of ROUND_ROWS when chunks are at least two rounds long, so that a chunk's product is whole rounds of tiles (1.25 M rows in
+    four chunks: 5 + 5 + 4 + 5.07 rounds instead of four times 4.77, each rounded up to 5).  A pure function of (n_rows, n_chunks):
+    every rank derives every owner's boundaries from the partition's cuts."""
+    n, K = int(n_rows), int(n_chunks)
+    b = [(n * k) // K for k in range(K + 1)]
+    if K > 1 and n // K >= 2 * ROUND_ROWS:
+        b = [0] + [min(max((x + ROUND_ROWS // 2) // ROUND_ROWS * ROUND_ROWS, 0), n) for x in b[1:-1]] + [n]
+    return b
 
 
 class HaloSide:
