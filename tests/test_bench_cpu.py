@@ -74,3 +74,23 @@ def test_hbm_side_model_bounds_and_limits():
     assert once["resident_rows"] == 0 and once["hbm_bytes"] == 4 * (n + 1) + 4 * n + 4 * n + 4 * F * n + 4 * F * n
     bigger = bench.hbm_side_model(deg, nnz, n, F, cache_bytes=2 * bench.INFINITY_CACHE_BYTES)
     assert bigger["hbm_bytes"] <= m["hbm_bytes"] and bigger["resident_rows"] >= m["resident_rows"]
+
+
+def test_row_chunks_fall_on_whole_rounds_of_tiles():
+    """shard.chunk_bounds: the row chunks of the pipelined exchange -- plain n k / K cuts for small shards, the nearest multiple of a
+    round of tiles (256 CUs x 256 rows) once a chunk is two rounds long; always n_chunks + 1 ascending bounds from 0 to n."""
+    import importlib
+
+    from __graft_entry__ import load_package
+    load_package()
+    shard = importlib.import_module("gnncpp_amd.shard")
+    assert shard.chunk_bounds(1000, 4) == [0, 250, 500, 750, 1000]
+    assert shard.chunk_bounds(0, 4) == [0, 0, 0, 0, 0] and shard.chunk_bounds(7, 1) == [0, 7]
+    R = shard.ROUND_ROWS
+    assert shard.chunk_bounds(1_250_000, 4) == [0, 5 * R, 10 * R, 14 * R, 1_250_000]
+    for n in (2 * R * 4, 2 * R * 4 + 1, 1_250_000, 10_000_000, 123_456_789):
+        for K in (2, 3, 4, 8):
+            b = shard.chunk_bounds(n, K)
+            assert len(b) == K + 1 and b[0] == 0 and b[-1] == n and all(x < y for x, y in zip(b, b[1:]))
+            if n // K >= 2 * R:
+                assert all(x % R == 0 for x in b[1:-1])
