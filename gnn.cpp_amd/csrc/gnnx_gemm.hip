@@ -512,7 +512,7 @@ __device__ __forceinline__ void dma_16B(uint32_t voff_bytes, const float *sbase,
 }
 
 #ifdef GNNX_EXPERIMENTS
-#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // timing only -- 1: no epilogue, 2: no operand loads after the first, 4: the epilogue's LDS round trip without its stores, 8: stores straight from the accumulators (16 rows x 64 B per instruction), 16: FUSE 4's list walk without its send stores, 32: non-temporal C stores
+#define GNNX_ABLATE(bit) ((ablate & (bit)) != 0)  // timing only -- 1: no epilogue, 2: no operand loads after the first, 4: the epilogue's LDS round trip without its stores, 8: stores straight from the accumulators (16 rows x 64 B per instruction), 16: FUSE 4's list walk without its send stores, 32: non-temporal C stores, 64: non-temporal send stores
 #else
 #define GNNX_ABLATE(bit) false
 #endif
@@ -796,6 +796,11 @@ __global__ __launch_bounds__(64 * WM_ * WN_, BK_ == 16 ? 4 : 1) void gemm_dma_ke
                         const int32_t s1 = __builtin_amdgcn_ds_bpermute(((lane & 48) + k + 1) << 2, sl[p]);   // k + 1 <= 7
                         if (GNNX_ABLATE(16)) {   // A/B: the list walk without its stores
                             asm volatile("" ::"v"(s0), "v"(s1));
+                            continue;
+                        }
+                        if (GNNX_ABLATE(64)) {   // A/B: the send rows leave with the non-temporal policy (nothing on this GPU reads them again)
+                            if (s0 >= 0 && okc) __builtin_nontemporal_store(o[p], reinterpret_cast<gemm_f32x4acc *>(send_col + (int64_t)s0 * fu.ldy * 4));
+                            if (s1 >= 0 && okc) __builtin_nontemporal_store(o[p], reinterpret_cast<gemm_f32x4acc *>(send_col + (int64_t)s1 * fu.ldy * 4));
                             continue;
                         }
                         if (s0 >= 0 && okc) *reinterpret_cast<gemm_f32x4acc *>(send_col + (int64_t)s0 * fu.ldy * 4) = o[p];
