@@ -21,7 +21,19 @@ run_set() {  # name, bench args...
      python3 scripts/summarize_profile.py "${TAG}_bench_${name}" "$OUT/prof_${TAG}_${name}_stats" "$OUT/prof_${TAG}_${name}_fetch" "$OUT/prof_${TAG}_${name}_write" "$OUT/prof_${TAG}_${name}_tcc")
   echo "profiled $name"
 }
-if [ -z "${ONLY_SHARD:-}" ]; then   # (ONLY_SHARD=1: just the sharded rank at the end)
+# one rank of eight of the sharded step (exchange stubbed; DESIGN.md section 6): per-rank compute of ranks 0 and 7 in both schedules -- the
+# first run of the script only warms the box up -- and the kernel timeline of rank 0.  FIRST: after the counter passes below a box runs
+# every kernel launch some 50 us slower for a while (the profiling power state lingers), which a step of ~25 launches shows
+python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 > "$OUT/prof_${TAG}_shard_warmup.log" 2>&1 || true
+python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 > "$OUT/prof_${TAG}_shard_overlap.log" 2>&1
+python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 --schedule training > "$OUT/prof_${TAG}_shard_training.log" 2>&1
+cat "$OUT/prof_${TAG}_shard_overlap.log" "$OUT/prof_${TAG}_shard_training.log" | grep '^{' > "$ROOT/profiles/${TAG}_shard_compute_per_rank.jsonl"
+rocprofv3 --kernel-trace -f csv -d "$OUT/prof_${TAG}_rank0" -- python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0 > "$OUT/prof_${TAG}_rank0.log" 2>&1
+python3 "$ROOT/scripts/trace_to_text.py" "$OUT/prof_${TAG}_rank0" --last 19 \
+  --header "rocprofv3 --kernel-trace -- python3 scripts/exp_shard_compute.py 8 --ranks 0   (rank 0 of 8 of RMAT 10M/100M F=256, overlap schedule, exchange stubbed; git ${GIT_HEAD:-?})" \
+  > "$ROOT/profiles/${TAG}_shard_rank0_trace.txt"
+echo "profiled one rank of eight"
+if [ -z "${ONLY_SHARD:-}" ]; then   # (ONLY_SHARD=1: just the sharded rank above)
 WL=rmat10m_100m_f256 run_set rmat10m
 WL=rmat1m_10m_f128 run_set rmat1m_10m_f128 --workload rmat1m_10m_f128
 WL=products_2p4m_62m_f100 run_set products_2p4m_62m_f100 --workload products_2p4m_62m_f100
@@ -42,16 +54,5 @@ TALL_ONLY=1 FS=128 rocprofv3 --kernel-trace --stats -f csv -d "$OUT/prof_${TAG}_
 (cd "$ROOT" && python3 scripts/summarize_profile.py --sq "${TAG}_gemm128_sq_counters" "$OUT/prof_${TAG}_gemm128_sq" "$OUT/prof_${TAG}_gemm128_stats")
 echo "profiled gemm128 sq"
 fi
-# one rank of eight of the sharded step (exchange stubbed; DESIGN.md section 6): per-rank compute of ranks 0 and 7 in both schedules -- the
-# first run of the script only warms the box up -- and the kernel timeline of rank 0
-python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 > "$OUT/prof_${TAG}_shard_warmup.log" 2>&1 || true
-python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 > "$OUT/prof_${TAG}_shard_overlap.log" 2>&1
-python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 --schedule training > "$OUT/prof_${TAG}_shard_training.log" 2>&1
-cat "$OUT/prof_${TAG}_shard_overlap.log" "$OUT/prof_${TAG}_shard_training.log" | grep '^{' > "$ROOT/profiles/${TAG}_shard_compute_per_rank.jsonl"
-rocprofv3 --kernel-trace -f csv -d "$OUT/prof_${TAG}_rank0" -- python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0 > "$OUT/prof_${TAG}_rank0.log" 2>&1
-python3 "$ROOT/scripts/trace_to_text.py" "$OUT/prof_${TAG}_rank0" --last 19 \
-  --header "rocprofv3 --kernel-trace -- python3 scripts/exp_shard_compute.py 8 --ranks 0   (rank 0 of 8 of RMAT 10M/100M F=256, overlap schedule, exchange stubbed; git ${GIT_HEAD:-?})" \
-  > "$ROOT/profiles/${TAG}_shard_rank0_trace.txt"
-echo "profiled one rank of eight"
 # nothing but gpurun_out/ travels back from the GPU box: leave a copy of the summaries there (the builder moves them into profiles/)
 mkdir -p "$OUT/profiles_${TAG}" && cp "$ROOT"/profiles/${TAG}_* "$OUT/profiles_${TAG}/"
