@@ -24,7 +24,7 @@ run_set() {  # name, bench args...
 # one rank of eight of the sharded step (exchange stubbed): per-rank compute of ranks 0 and 7 in both schedules -- the
 # first run of the script only warms the box up -- and the kernel timeline of rank 0.  FIRST: after the counter passes below a box runs
 # every kernel launch some 50 us slower for a while (the profiling power state lingers), which a step of ~25 launches shows
-python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 > "$OUT/prof_${TAG}_shard_warmup.log" 2>&1 || true
+for i in 1 2; do python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 > "$OUT/prof_${TAG}_shard_warmup.log" 2>&1 || true; done   # (a fresh box launches slowly at first: the step's ~25 launches then show gaps of 30-40 us each -- `wait_*` entries of 0.03 instead of 0.005 ms say so)
 python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 > "$OUT/prof_${TAG}_shard_overlap.log" 2>&1
 python3 "$ROOT/scripts/exp_shard_compute.py" 8 --ranks 0,7 --schedule training > "$OUT/prof_${TAG}_shard_training.log" 2>&1
 cat "$OUT/prof_${TAG}_shard_overlap.log" "$OUT/prof_${TAG}_shard_training.log" | grep '^{' > "$ROOT/profiles/${TAG}_shard_compute_per_rank.jsonl"
