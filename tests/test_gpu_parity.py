@@ -1898,6 +1898,11 @@ def test_transform_with_the_pack_in_its_epilogue(env, M, F, world):
     ops.linear_fwd_rows_to_slots(X, W, Hp[:, :F], table, sp[:, :F])
     assert torch.equal(Hp[:, :F], H_ref) and torch.equal(sp[:, :F], want)
     assert float(Hp[:, F:].abs().max()) == 0.0 and float(sp[:, F:].abs().max()) == 0.0
+    # nothing is written outside the send rows: the buffer sits between two sentinel rows
+    guard = torch.full((want.shape[0] + 2, F), 7.0, dtype=torch.float32, device=env["dev"])
+    H2 = torch.empty_like(H_ref)
+    ops.linear_fwd_rows_to_slots(X, W, H2, table, guard[1:-1])
+    assert torch.equal(guard[1:-1], want) and bool((guard[0] == 7.0).all()) and bool((guard[-1] == 7.0).all()) and torch.equal(H2, H_ref)
     # the last partial round against a product without one: 2048 of its rows multiplied at the head of an 8-tile product
     if M >= 256 * 256 + 2048:
         r0 = (M // 256) // 256 * 256 * 256
