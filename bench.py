@@ -475,8 +475,11 @@ def main():
 def sharded_roofline(st):
     """N > 1: the slowest rank's forward aggregation, ALGORITHMIC bytes (one feature row per local non-zero) / time against the HBM
     spec -- no PMC traffic and no in-run ceiling exist for a shard (the N = 1 line carries those)."""
-    r = {"bound": "hbm", "kernel": "forward aggregation of one rank (spmm_hub_kernel + spmm_stream_kernel), slowest rank",
+    r = {"bound": "hbm", "bound_is": "fabric behind L2",
+         "kernel": "forward aggregation of one rank (spmm_hub_kernel + spmm_stream_kernel, spmm_hubpc_kernel beside), slowest rank",
          "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+         "frac_is": "ALGORITHMIC bytes (one feature row per non-zero: every cache hit charged as an HBM read, so above 1 is possible) / "
+                    "launch time / HBM spec -- a shard has no PMC traffic figure; the N = 1 line carries the three readings side by side",
          "achieved_is": "algorithmic_bytes_per_launch / avg_launch_ms", "peak_is": "HBM spec"}
     if st.get("spmm_fwd_ms"):
         B = spmm_bytes(st["local_rows"], st["local_rows"], st["local_nnz"], st["features"], bias=True)
