@@ -1926,3 +1926,29 @@ def test_weight_gradient_over_a_row_count_off_the_k_tile_grid(env, K, F):
     c = a.clone()
     ops.gemm(dH, X, transA=True, out=c, beta=1.0)
     assert (c.double() - 2 * ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_transform_with_the_pack_edge_cases(env):
+    """gnnx_gemm_nt_rows_to_slots_f32 at its edges: no row listed anywhere (the send buffer is not touched), every row listed seven
+    times (a world of 8: each row to every peer), an empty product, and the error for rows that are no 16-byte pieces."""
+    ops, capi, torch = env["ops"], env["capi"], env["torch"]
+    dev_ = env["dev"]
+    M, F = 256 * 20 + 9, 256
+    X = ops.uniform_pm1(21, (M, F), device=dev_)
+    W = ops.uniform_pm1(22, (F, F), scale=F ** -0.5, device=dev_)
+    H_ref = ops.linear_fwd(X, W)
+    none = torch.full((M, ops.SLOTS_PER_ROW), -1, dtype=torch.int32, device=dev_)
+    send = torch.full((4, F), 3.0, dtype=torch.float32, device=dev_)
+    H = torch.empty_like(H_ref)
+    ops.linear_fwd_rows_to_slots(X, W, H, none, send)
+    assert torch.equal(H, H_ref) and bool((send == 3.0).all())
+    send_idx = torch.cat([torch.arange(M)] * 7).to(torch.int32).to(dev_)    # peer-major: every peer wants every row
+    table = ops.slot_table(send_idx, M)
+    assert table is not None and int((table[:, :7] >= 0).sum()) == 7 * M and bool((table[:, 7] == -1).all())
+    send7 = torch.empty((7 * M, F), dtype=torch.float32, device=dev_)
+    ops.linear_fwd_rows_to_slots(X, W, H, table, send7)
+    assert torch.equal(send7, H_ref.repeat(7, 1)) and torch.equal(H, H_ref)
+    ops.linear_fwd_rows_to_slots(X[:0], W, H[:0], table[:0], send7)          # M == 0: nothing to do, no error
+    Wn = ops.uniform_pm1(23, (6, F), scale=F ** -0.5, device=dev_)           # 6 output columns: rows of 24 bytes
+    with pytest.raises(capi.GnnxError):
+        ops.linear_fwd_rows_to_slots(X, Wn, torch.empty((M, 6), dtype=torch.float32, device=dev_), table, torch.empty((7 * M, 6), dtype=torch.float32, device=dev_))
