@@ -489,15 +489,26 @@ class ShardedGcnStack:
         self._saved = None
         # a layer's transform packs its send rows in its own epilogue (gnnx_gemm_nt_rows_to_slots_f32) wherever the output rows are
         # 16-byte pieces; the table does not depend on the width (chunked layouts too: a chunk's segment holds rows of that chunk only)
-        self.table_f = None
-        if p.world > 1 and int(p.fwd.send_idx.numel()) and hasattr(ops, "slot_table"):
-            self.table_f = ops.slot_table(p.fwd.send_idx, nl)
+        self.table_f = self.table_b = None
+        if p.world > 1 and hasattr(ops, "slot_table"):
+            if int(p.fwd.send_idx.numel()):
+                self.table_f = ops.slot_table(p.fwd.send_idx, nl)
+            if int(p.bwd.send_idx.numel()):   # the gradient's rows are packed from the producer's side too (every local row read once)
+                self.table_b = ops.slot_table(p.bwd.send_idx, nl)
 
     def _send_view(self, F):
         return self.send.view(-1)[: self.send.shape[0] * F].view(-1, F)
 
     def _packs_in_epilogue(self, F):
         return self.table_f is not None and F % 4 == 0 and F // 4 <= 256 and 256 % (F // 4) == 0
+
+    def _exchange_gradient(self, buf, F):
+        """The backward side's exchange of the rows at the head of `buf`: packed by gnnx_rows_to_slots_f32 where the rows are 16-byte
+        pieces, by the send list otherwise; asynchronous."""
+        if self.p.world > 1 and self.table_b is not None and F % 4 == 0 and F // 4 <= 256 and 256 % (F // 4) == 0:
+            self.ops.rows_to_slots(buf[: self.p.n_local], self.table_b, self._send_view(F))
+            return self._exchange(self.p.bwd, buf, F, async_op=True, prepacked=True)
+        return self._exchange(self.p.bwd, buf, F, async_op=True)
 
     def _exchange(self, side, buf, F, async_op=False, chunk=None, prepacked=False):
         if self.p.world > 1:
@@ -539,7 +550,7 @@ class ShardedGcnStack:
         ops, p, nl, dist = self.ops, self.p, self.p.n_local, self.dist
         L = len(self.W)
         loss, G = ops.softmax_ce(logits_local, target_local, colsum_out=self.db[L - 1], n_total=n_total, grad_out=self.Gext[L - 1][:nl])
-        pending = self._exchange(p.bwd, self.Gext[L - 1], self.dims[L], async_op=True)
+        pending = self._exchange_gradient(self.Gext[L - 1], self.dims[L])
         for l in reversed(range(L)):
             h, _ = self._saved[l]
             pending.wait()
@@ -547,7 +558,7 @@ class ShardedGcnStack:
             if l > 0:   # G_{l-1} = (dH . W_l) (.) (Y_{l-1} > 0) straight into the next exchange's buffer, db_{l-1} from the same epilogue;
                 # its exchange starts at once and the layer's weight gradient is computed under it
                 ops.gemm_relu_colsum(dH, self.W[l], h, out=self.Gext[l - 1][:nl], colsum_out=self.db[l - 1])
-                pending = self._exchange(p.bwd, self.Gext[l - 1], self.dims[l], async_op=True)
+                pending = self._exchange_gradient(self.Gext[l - 1], self.dims[l])
             ops.gemm(dH, h, transA=True, out=self.dW[l])
         if p.world > 1:
             for t in self.dW + self.db + [loss]:
